@@ -1,0 +1,238 @@
+/*
+ * diral_env.h - C-ABI of libdiral_env.so: the MI355X-native, batched V2V
+ * resource-allocation environment step.
+ *
+ * The reference (gundoganalperen/DIRAL) has NO FFI/plugin layer: the env is a
+ * duck-typed Python object (`TestEnv`, envs/test_env.py:6) that agents and the
+ * driver call directly.  This header is the boundary a maintainer would bind
+ * with ctypes to replace that object's hot path; every entry point names the
+ * reference method(s) it replaces.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types.  Every data pointer is a
+ *    DEVICE pointer (HBM) unless its name ends in `_host`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    entry points that take a stream only ENQUEUE work on it (no host sync, no
+ *    allocation) - safe inside hipGraph capture.
+ *  - B = parallel envs (independent episodes), N = num_users, A = num_channels,
+ *    S = state_space.  Batched arrays are row-major [B][N], [B][N][A], [B][N][S].
+ *  - return value: 0 = DIRAL_OK, <0 = DiralStatus error; diral_env_strerror().
+ *  - a handle is bound to one device and is NOT thread-safe.
+ */
+#ifndef DIRAL_ENV_H
+#define DIRAL_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIRAL_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------- */
+typedef enum DiralStatus {
+  DIRAL_OK = 0,
+  DIRAL_ERR_BAD_ARG = -1,      /* null pointer, bad size, bad enum            */
+  DIRAL_ERR_BAD_CONFIG = -2,   /* config the reference itself cannot run, or a
+                                  combination this build rejects */
+  DIRAL_ERR_UNSUPPORTED = -3,  /* valid reference config outside this build's
+                                  limits (e.g. N > 256)                        */
+  DIRAL_ERR_HIP = -4,          /* a HIP runtime call failed; see strerror      */
+  DIRAL_ERR_NO_DEVICE = -5,    /* no gfx950 device / device index out of range */
+  DIRAL_ERR_ACTION_RANGE = -6, /* an action outside [0, A) was seen (sticky flag
+                                  raised by the step kernel; test_env.py:592)   */
+  DIRAL_ERR_SEQ_OVERFLOW = -7  /* more than DIRAL_MAX_SLOTS steps since reset   */
+} DiralStatus;
+
+/* ---- config flags: the booleans of the `EnvironmentTest` YAML block -------- */
+enum {
+  DIRAL_F_MOBILITY          = 1u << 0,  /* mobility            test_env.py:14  */
+  DIRAL_F_MOBILITY_VARY     = 1u << 1,  /* mobility_vary       test_env.py:15  */
+  DIRAL_F_TOY_WEIGHTS       = 1u << 2,  /* congestion_test     test_env.py:48, network.py:284-290 */
+  DIRAL_F_ADD_ACTION        = 1u << 3,  /* State.add_action    test_env.py:29  */
+  DIRAL_F_ACTION_REAL       = 1u << 4,  /* State.action_index == "real" (else "binary") test_env.py:32 */
+  DIRAL_F_ADD_CHANNEL_OBS   = 1u << 5,  /* State.add_channel_obs test_env.py:41 */
+  DIRAL_F_ADD_REWARD        = 1u << 6,  /* State.add_reward    test_env.py:28  */
+  DIRAL_F_ADD_INDEX         = 1u << 7,  /* State.add_index     test_env.py:30  */
+  DIRAL_F_ADD_VELOCITY      = 1u << 8,  /* State.add_velocity  test_env.py:31  */
+  DIRAL_F_ADD_POSITION      = 1u << 9,  /* State.add_position  test_env.py:34  */
+  DIRAL_F_ADD_POSDIST       = 1u << 10, /* State.add_positional_dist test_env.py:35 */
+  DIRAL_F_ADD_POSDIST_PIGGY = 1u << 11, /* State.add_positional_dist_piggy test_env.py:36 */
+  DIRAL_F_FINGERPRINT       = 1u << 12, /* enable_fingerprint  test_env.py:19  */
+  DIRAL_F_PROPORTIONAL_FAIR = 1u << 13, /* proportional_fair   test_env.py:22  */
+  DIRAL_F_DESIGN_TOPOLOGY   = 1u << 14, /* enable_design_topology test_env.py:16 */
+  /* build extensions (no reference counterpart) */
+  DIRAL_F_TRACK_ARRIVAL     = 1u << 16, /* keep last_arrival_time[N][N] (network.py:39-42)
+                                           so diral_env_info_age() works        */
+  DIRAL_F_TRACK_PRR         = 1u << 17  /* accumulate PRR metrics in my_step too */
+};
+
+/* One env configuration = the `EnvironmentTest` block (test_env.py:12-48) plus
+ * its nested `State` block (test_env.py:26-41) and the driver's
+ * `episode_interval` (main_test.py:226).  `State.piggybacking` (test_env.py:33)
+ * is not representable: it must be False (out of scope). */
+typedef struct DiralCfg {
+  uint32_t struct_bytes;        /* = sizeof(DiralCfg); ABI guard               */
+  uint32_t flags;               /* DIRAL_F_*                                   */
+  int32_t  num_users;           /* N  test_env.py:12                           */
+  int32_t  num_channels;        /* A  test_env.py:13 (= action space, :44)     */
+  int32_t  num_bins;            /* K  State.num_bins test_env.py:40            */
+  int32_t  reward_design;       /* 1..5  test_env.py:20                        */
+  int32_t  state_type;          /* State.type 1|2  test_env.py:27              */
+  int32_t  posdist_type;        /* State.add_positional_dist_type 1|2  :37     */
+  int32_t  episode_interval;    /* main_test.py:226 (25); done = t%EI == EI-1  */
+  int32_t  info_age_limit;      /* 20: table entry valid iff last_updated < 20 (network.py:547) */
+  int32_t  pf_threshold;        /* 10  test_env.py:89                          */
+  int32_t  reserved0;
+  double   pf_penalty;          /* -10 test_env.py:90                          */
+  double   highway_length;      /* L   test_env.py:18                          */
+  double   highway_height;      /* 2   network.py:31                           */
+  double   communication_range; /* Rc  test_env.py:21                          */
+  double   bin_range;           /* Rb  test_env.py:24                          */
+} DiralCfg;
+
+/* which reference step function a diral_env_step() call replaces */
+typedef enum DiralStepMode {
+  DIRAL_STEP_MY_STEP = 0,   /* TestEnv.my_step         test_env.py:124-266 */
+  DIRAL_STEP_MY_STEP_CH = 1,/* TestEnv.my_step_ch      test_env.py:351-443 */
+  DIRAL_STEP_DESIGN = 2     /* TestEnv.my_step_design  test_env.py:269-349 */
+} DiralStepMode;
+
+/* element type of the floating-point OUTPUT buffers (state, reward, chobs).
+ * The arithmetic is always float64, like the reference; F32 is a final cast. */
+typedef enum DiralDType { DIRAL_F32 = 0, DIRAL_F64 = 1 } DiralDType;
+
+/* limits of this build */
+#define DIRAL_MAX_USERS    256
+#define DIRAL_MAX_CHANNELS 256
+#define DIRAL_MAX_BINS     64
+#define DIRAL_MAX_SLOTS    16777214   /* steps between resets (24-bit sequence numbers) */
+
+/* per-env episode metric columns written by diral_env_metrics() */
+enum {
+  DIRAL_M_SLOTS = 0,        /* steps taken since reset/clear                    */
+  DIRAL_M_SUM_REWARD,       /* sum over slots and agents of reward              */
+  DIRAL_M_TX_SOLE,          /* #transmissions alone on their resource           */
+  DIRAL_M_TX_COLLIDED,      /* #transmissions sharing their resource            */
+  DIRAL_M_PRR_SUM,          /* sum over transmissions of R (test_env.py:402-405; 1 for a sole tx) */
+  DIRAL_M_PRR_CNT,          /* #transmissions that R was summed over            */
+  DIRAL_M_COLUMNS
+};
+
+typedef struct DiralEnv DiralEnv;   /* opaque handle */
+
+/* ---- pure host helpers ----------------------------------------------------- */
+
+/* Fill *cfg with the reference's defaults (test_env.py:12-48 kwargs.setdefault
+ * values; State flags all off; episode_interval 25). */
+void diral_cfg_defaults(DiralCfg* cfg);
+
+/* Replaces TestEnv.get_state_space() (test_env.py:492; sizing :49-85).
+ * Returns S >= 0, or a negative DiralStatus for an invalid config. */
+int diral_env_state_space(const DiralCfg* cfg);
+
+/* 0 if `cfg` can be run by this build, else the DiralStatus explaining why. */
+int diral_env_validate(const DiralCfg* cfg);
+
+const char* diral_env_strerror(int status);
+int diral_env_abi_version(void);
+
+/* ---- lifetime ---------------------------------------------------------------- */
+
+/* Replaces TestEnv.__init__ -> Network.__init__ (test_env.py:7-107,
+ * network.py:15-67) for B independent envs on HIP device `device`.
+ * Allocates all persistent state in HBM; tables zeroed (vehicle.py:24-33). */
+int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out);
+int diral_env_destroy(DiralEnv* env);
+
+/* bytes of HBM the handle owns (for sizing batches against 288 GB) */
+int64_t diral_env_hbm_bytes(const DiralEnv* env);
+
+/* ---- topology / reset ------------------------------------------------------- */
+
+/* Replaces Network.initialize_mobility_topology (network.py:92-119) /
+ * reset_positions (network.py:181-187).  x0,y0,v0: [B][N] float64 device
+ * arrays; any may be NULL => drawn on device from `seed`
+ * (x0 integer-uniform in [0,L), y0 = 0, v0 ~ U(1.1,2.7) or 1.7 if
+ * mobility_vary).  Zeroes tables, arrival stamps, pf counters and metrics. */
+int diral_env_reset(DiralEnv* env, const double* x0, const double* y0,
+                    const double* v0, uint64_t seed, void* stream);
+
+/* ---- the hot path ----------------------------------------------------------- */
+
+/* One time-slot for all B envs in ONE fused launch.  Replaces, per env,
+ *   my_step / my_step_ch / my_step_design (per `mode`) followed by
+ *   obtain_state(obs, actions, rewards, episode, epsilon) (test_env.py:527-583).
+ * actions   [B][N] int32 in [0,A)
+ * t         the driver's time_step (used for `done`, arrival stamps)
+ * state_out [B][N][S] (dtype `out_dtype`), NULL => observation not built
+ * rew_out   [B][N]    (dtype `out_dtype`), NULL allowed
+ * done_out  [B] uint8, NULL allowed: t % episode_interval == episode_interval-1
+ * chobs_out [B][N][A] (dtype `out_dtype`), NULL allowed: the `obs` dict of the
+ *           reference step (test_env.py:143, 206, 228, 240)
+ * episode, epsilon: only used with DIRAL_F_FINGERPRINT (test_env.py:577-579) */
+int diral_env_step(DiralEnv* env, int mode, const int32_t* actions, int64_t t,
+                   void* state_out, void* rew_out, uint8_t* done_out,
+                   void* chobs_out, int out_dtype, double episode,
+                   double epsilon, void* stream);
+
+/* Observation only, no state change: replaces a stand-alone
+ * TestEnv.obtain_state(obs, acts, rewards, episode, eps) (test_env.py:527-583)
+ * on the CURRENT tables/positions.  chobs_in [B][N][A] and rew_in [B][N] are
+ * float64 device arrays (NULL allowed when the State flags do not use them). */
+int diral_env_observe(DiralEnv* env, const int32_t* actions,
+                      const double* chobs_in, const double* rew_in,
+                      void* state_out, int out_dtype, double episode,
+                      double epsilon, void* stream);
+
+/* Replaces TestEnv.update_velocity -> Network.update_velocity
+ * (test_env.py:498-504, network.py:208-223).  draws [B][N] uint8 in {1,2,3}
+ * (random.randrange(1,4)); NULL => drawn on device from `seed`.
+ * No-op unless DIRAL_F_MOBILITY_VARY. */
+int diral_env_update_velocity(DiralEnv* env, const uint8_t* draws,
+                              uint64_t seed, void* stream);
+
+/* Replaces TestEnv.sample (test_env.py:116-122): uniform actions [B][N]. */
+int diral_env_sample(DiralEnv* env, int32_t* actions_out, uint64_t seed,
+                     void* stream);
+
+/* Replaces Network.get_information_age(t) (network.py:560-574):
+ * out [B][100] int32.  Needs DIRAL_F_TRACK_ARRIVAL. */
+int diral_env_info_age(DiralEnv* env, int64_t t, int32_t* out, void* stream);
+
+/* ---- state export / import (checkpoint, golden replay, debugging) --------- */
+
+/* Reference-shaped copies of the env state, all device pointers, any NULL
+ * skipped.  pos_x,pos_y,vel [B][N] f64; tab_seq, tab_age [B][N][N] int32 and
+ * tab_x, tab_y [B][N][N] f64 indexed [env][viewer][subject]
+ * (Vehicle.pos_of_neighbors, vehicle.py:20-33; age saturates at 255);
+ * last_arrival [B][N][N] int32 indexed [env][tx][rx] (network.py:39-42). */
+int diral_env_export_state(DiralEnv* env, double* pos_x, double* pos_y,
+                           double* vel, int32_t* tab_seq, int32_t* tab_age,
+                           double* tab_x, double* tab_y, int32_t* last_arrival,
+                           void* stream);
+int diral_env_import_state(DiralEnv* env, const double* pos_x,
+                           const double* pos_y, const double* vel,
+                           const int32_t* tab_seq, const int32_t* tab_age,
+                           const double* tab_x, const int32_t* last_arrival,
+                           void* stream);
+
+/* ---- metrics ------------------------------------------------------------------ */
+
+/* out [B][DIRAL_M_COLUMNS] float64 device array; clear != 0 zeroes the
+ * accumulators afterwards. */
+int diral_env_metrics(DiralEnv* env, double* out, int clear, void* stream);
+
+/* Sticky device-side error flags (action range, sequence overflow) raised by
+ * kernels since the last call.  SYNCHRONISES `stream`.  Returns DIRAL_OK or the
+ * first error. */
+int diral_env_check(DiralEnv* env, void* stream);
+
+/* last HIP error string seen by this handle (host-side, for DIRAL_ERR_HIP) */
+const char* diral_env_last_hip_error(const DiralEnv* env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIRAL_ENV_H */

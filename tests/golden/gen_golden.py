@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the reference env.
+
+Runs ONLY in the build container (needs /root/reference, which does not exist
+on the GPU box).  The reference is imported, driven with seeded inputs, and its
+inputs + outputs are recorded as small .npz fixtures under tests/golden/.
+Nothing of the reference's source is stored - only data.
+
+Reference entry points exercised (all under /root/reference/envs):
+  TestEnv.my_step            test_env.py:124-266
+  TestEnv.my_step_design     test_env.py:269-349
+  TestEnv.my_step_ch         test_env.py:351-443
+  TestEnv.obtain_state       test_env.py:527-583
+  TestEnv.reset_mobility_env test_env.py:479-484
+  Network.update_velocity    network.py:208-223
+  Network.get_information_age network.py:560-574
+
+Usage:  python tests/golden/gen_golden.py        (rewrites tests/golden/*.npz)
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+
+REF = "/root/reference/envs"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):
+    from test_env import TestEnv  # noqa: E402  (the reference)
+    import network as ref_network  # noqa: E402
+
+
+# The `EnvironmentTest` block of configs/4ue_3r_toy/*_b20_*_dis_07.yaml:45-71,
+# restated as data (values only).
+TOY = dict(
+    congestion_test=True, load_positions=False, num_channels=3, num_users=4,
+    mobility=True, mobility_vary=False, highway_length=100,
+    enable_fingerprint=False, reward_design=2, communication_range=250,
+    State=dict(type=2, add_action=True, add_reward=False, add_index=False,
+               add_velocity=False, action_index="binary", piggybacking=False,
+               add_position=False, add_positional_dist=False,
+               add_positional_dist_piggy=True, add_positional_dist_type=2,
+               add_channel_obs=False, num_bins=20),
+)
+
+
+def cfg_with(base=None, state=None, **kw):
+    c = json.loads(json.dumps(base or TOY))
+    c.update(kw)
+    if state:
+        c["State"].update(state)
+    return c
+
+
+def big_cfg(N, A, L, **kw):
+    return cfg_with(num_users=N, num_channels=A, highway_length=L,
+                    congestion_test=False, **kw)
+
+
+def make_env(cfg):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return TestEnv(**json.loads(json.dumps(cfg)))
+
+
+def set_init(env, x0, y0, v0):
+    """Overwrite the random topology (network.py:92-119) with recorded values,
+    keeping the reference's own scalar types (np.int64 positions, float v)."""
+    for u, veh in enumerate(env.network.vehicles):
+        veh.pos_x = np.int64(x0[u]) if float(x0[u]).is_integer() else float(x0[u])
+        veh.pos_y = np.int64(y0[u]) if float(y0[u]).is_integer() else float(y0[u])
+        veh.pos = [veh.pos_x, veh.pos_y]
+        veh.velocity = float(v0[u])
+
+
+def tables(env):
+    N = env.NUM_USERS
+    seq = np.zeros((N, N), np.int64)
+    age = np.zeros((N, N), np.int64)
+    tx = np.zeros((N, N), np.float64)
+    ty = np.zeros((N, N), np.float64)
+    for u, veh in enumerate(env.network.vehicles):
+        for k in range(N):
+            e = veh.pos_of_neighbors[k]
+            seq[u, k] = e["seq_number"]
+            age[u, k] = e["last_updated"]
+            tx[u, k] = e["xpos"]
+            ty[u, k] = e["ypos"]
+    return seq, age, tx, ty
+
+
+def last_arrival(env):
+    N = env.NUM_USERS
+    la = np.zeros((N, N), np.int64)
+    for t in range(N):
+        for r in range(N):
+            la[t, r] = env.network.last_arrival_time[t][r]
+    return la
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
+             full_tables=True, episode_eps=None):
+    """steps: list of (mode, actions, t).  vel_updates: {step_index: draws[N]}
+    applied AFTER that step (main_test.py:226-233 order)."""
+    env = make_env(cfg)
+    N, A = env.NUM_USERS, env.NUM_CHANNELS
+    if isinstance(init, str) and init == "fixed4":
+        env.reset_mobility_env()
+    elif isinstance(init, str) and init == "design6":
+        pass  # enable_design_topology builds it in the constructor
+    else:
+        set_init(env, *init)
+    x0 = np.array([float(v.pos_x) for v in env.network.vehicles])
+    y0 = np.array([float(v.pos_y) for v in env.network.vehicles])
+    v0 = np.array([float(v.velocity) for v in env.network.vehicles])
+
+    rec = dict(rews=[], chobs=[], state=[], pos_x=[], vel=[], ia=[])
+    tab = dict(step=[], seq=[], age=[], x=[], y=[], la=[])
+    tab_sha = []
+    vel_updates = vel_updates or {}
+    for si, (mode, acts, t) in enumerate(steps):
+        acts = np.asarray(acts, dtype=np.int32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if mode == "step":
+                obs, rews = env.my_step(acts, t)
+            elif mode == "ch":
+                obs, rews = env.my_step_ch(acts, t)
+            elif mode == "design":
+                obs, rews = env.my_step_design(acts, t)
+            else:
+                raise ValueError(mode)
+            ep, eps = (episode_eps[si] if episode_eps else (0, 1))
+            st = env.obtain_state(obs, acts, list(rews), ep, eps)
+        rec["rews"].append(np.array(rews, dtype=np.float64))
+        rec["chobs"].append(np.array([obs[u] for u in range(N)], dtype=np.float64))
+        rec["state"].append(np.array([np.asarray(s, dtype=np.float64) for s in st]))
+        rec["pos_x"].append(np.array([float(v.pos_x) for v in env.network.vehicles]))
+        rec["ia"].append(np.array(env.network.get_information_age(t), dtype=np.int64))
+        if si in vel_updates:
+            draws = list(vel_updates[si])
+            with mock.patch.object(ref_network.random, "randrange",
+                                   side_effect=lambda a, b: draws.pop(0)):
+                env.update_velocity()
+        rec["vel"].append(np.array([float(v.velocity) for v in env.network.vehicles]))
+        seq, age, tx, ty = tables(env)
+        la = last_arrival(env)
+        tab_sha.append([sha(seq), sha(age), sha(tx), sha(ty), sha(la)])
+        if full_tables and (si % table_every == 0 or si == len(steps) - 1):
+            tab["step"].append(si)
+            tab["seq"].append(seq)
+            tab["age"].append(age)
+            tab["x"].append(tx)
+            tab["y"].append(ty)
+            tab["la"].append(la)
+
+    out = dict(
+        cfg=np.array(json.dumps(cfg)),
+        x0=x0, y0=y0, v0=v0,
+        modes=np.array([s[0] for s in steps]),
+        actions=np.array([s[1] for s in steps], dtype=np.int32),
+        tsteps=np.array([s[2] for s in steps], dtype=np.int64),
+        vel_update_steps=np.array(sorted(vel_updates), dtype=np.int64),
+        vel_update_draws=np.array([vel_updates[k] for k in sorted(vel_updates)],
+                                  dtype=np.uint8).reshape(len(vel_updates), N),
+        episode_eps=np.array(episode_eps if episode_eps else
+                             [(0, 1)] * len(steps), dtype=np.float64),
+        state_space=np.int64(env.get_state_space()),
+        table_sha=np.array(tab_sha),
+    )
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    for k, v in tab.items():
+        out["tab_" + k] = np.array(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s N=%-3d A=%-2d steps=%-3d  %7.1f KB" % (
+        name, N, A, len(steps), os.path.getsize(path) / 1024))
+
+
+def rand_init(rng, N, L, vary):
+    # network.py:103-110: x=randint(0,L) (integer valued), y=randint(0,1)=0,
+    # v = 1.7 if mobility_vary else uniform(1.1, 2.7)
+    x0 = rng.integers(0, L, size=N).astype(np.float64)
+    y0 = np.zeros(N)
+    v0 = np.full(N, 1.7) if vary else rng.uniform(1.1, 2.7, size=N)
+    return x0, y0, v0
+
+
+def rand_steps(rng, mode, T, N, A, sticky=0.0):
+    acts = rng.integers(0, A, size=N)
+    steps = []
+    for t in range(T):
+        new = rng.integers(0, A, size=N)
+        keep = rng.random(N) < sticky
+        acts = np.where(keep, acts, new)
+        steps.append((mode, acts.copy(), t))
+    return steps
+
+
+def main():
+    toy_actions = [[0, 1, 2, 0], [0, 0, 0, 0], [1, 1, 2, 2], [2, 2, 2, 1]]
+
+    # ---- G1: fixed 4-UE topology, every reward design, both step kinds -----
+    for rd in (1, 2, 3, 4, 5):
+        run_case("g1_step_rd%d" % rd, cfg_with(reward_design=rd), "fixed4",
+                 [("step", a, t) for t, a in enumerate(toy_actions)])
+    for rd in (2, 3, 4):
+        run_case("g1_ch_rd%d" % rd, cfg_with(reward_design=rd), "fixed4",
+                 [("ch", a, t) for t, a in enumerate(toy_actions)])
+    run_case("g1_design", cfg_with(), "fixed4",
+             [("design", a, 0) for a in toy_actions])
+    for nb in (10, 40):
+        run_case("g1_step_rd2_b%d" % nb, cfg_with(state=dict(num_bins=nb)),
+                 "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+    # longer toy run past the ghost-entry phase (19 slots)
+    rng = np.random.default_rng(11)
+    run_case("g1_step_rd2_long", cfg_with(), "fixed4",
+             rand_steps(rng, "step", 60, 4, 3), table_every=10)
+    # non-toy weights branch (network.py:291-295) on the toy topology
+    run_case("g1_step_rd1_nontoy", cfg_with(reward_design=1, congestion_test=False,
+                                            communication_range=1),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+
+    # ---- state-vector flag coverage (test_env.py:49-85, 527-583) -----------
+    allflags = dict(add_reward=True, add_index=True, add_velocity=True,
+                    add_position=True, add_channel_obs=True)
+    run_case("g1_flags_all", cfg_with(state=allflags, enable_fingerprint=True),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)],
+             episode_eps=[(0, 1.0), (0, 0.99), (1, 0.98), (1, 0.5)])
+    run_case("g1_flags_real_type1",
+             cfg_with(state=dict(action_index="real", type=1, add_channel_obs=True)),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+    run_case("g1_flags_nopiggy",
+             cfg_with(state=dict(add_positional_dist_piggy=False, add_channel_obs=True)),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+    run_case("g1_pf", cfg_with(proportional_fair=True), "fixed4",
+             [("step", [0, 0, 1, 2], t) for t in range(14)] +
+             [("step", [0, 1, 1, 2], 14), ("step", [0, 0, 1, 2], 15)],
+             table_every=8)
+    # secondary observation modes
+    run_case("g1_posdist_full", cfg_with(state=dict(add_positional_dist=True)),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+    run_case("g1_posdist_type1", cfg_with(state=dict(add_positional_dist_type=1)),
+             "fixed4", [("step", a, t) for t, a in enumerate(toy_actions)])
+
+    # ---- G2: 3-UE line, multi-hop ordering ----------------------
+    line = cfg_with(num_users=3, num_channels=3, highway_length=1000,
+                    congestion_test=False)
+    init3 = (np.array([0., 200., 400.]), np.zeros(3), np.array([1.5, 1.5, 1.5]))
+    run_case("g2_line_012", line, init3, [("step", [0, 1, 2], 0), ("step", [0, 1, 2], 1)])
+    run_case("g2_line_210", line, init3, [("step", [2, 1, 0], 0), ("step", [2, 1, 0], 1)])
+
+    # ---- G3: 6-UE design topology, two communication ranges ----------------
+    for rc in (100, 250):
+        d6 = cfg_with(num_users=6, num_channels=4, highway_length=2000,
+                      congestion_test=False, enable_design_topology=True,
+                      communication_range=rc)
+        rng = np.random.default_rng(30 + rc)
+        st = rand_steps(rng, "design", 6, 6, 4) + rand_steps(rng, "step", 6, 6, 4) \
+            + rand_steps(rng, "ch", 6, 6, 4)
+        run_case("g3_design6_rc%d" % rc, d6, "design6", st, table_every=6)
+
+    # ---- G4: C2-shaped 64 UE / 32 res --------------------------------------
+    rng = np.random.default_rng(1234)
+    c2 = big_cfg(64, 32, 2000)
+    run_case("g4_c2_step", c2, rand_init(rng, 64, 2000, False),
+             rand_steps(rng, "step", 40, 64, 32), table_every=39, full_tables=True)
+    rng = np.random.default_rng(1235)
+    run_case("g4_c2_ch", c2, rand_init(rng, 64, 2000, False),
+             rand_steps(rng, "ch", 24, 64, 32, sticky=0.5), full_tables=False)
+    rng = np.random.default_rng(1236)
+    c2v = big_cfg(64, 32, 2000, mobility_vary=True, reward_design=1,
+                  state=dict(add_channel_obs=True, add_reward=True))
+    run_case("g4_c2_vary_rd1", c2v, rand_init(rng, 64, 2000, True),
+             rand_steps(rng, "step", 30, 64, 32, sticky=0.8),
+             vel_updates={24: rng.integers(1, 4, size=64)}, full_tables=False)
+    rng = np.random.default_rng(1237)
+    run_case("g4_c2_design", c2, rand_init(rng, 64, 2000, False),
+             rand_steps(rng, "design", 8, 64, 32), full_tables=False)
+
+    # ---- G5: C3-shaped 256 UE / 64 res, congested --------------------------
+    rng = np.random.default_rng(2345)
+    run_case("g5_c3_step", big_cfg(256, 64, 4000),
+             rand_init(rng, 256, 4000, False),
+             rand_steps(rng, "step", 5, 256, 64), full_tables=False)
+
+    # ---- G6: C5-shaped 128 UE / 64 res, mobility_vary ----------------------
+    rng = np.random.default_rng(3456)
+    run_case("g6_c5_vary", big_cfg(128, 64, 4000, mobility_vary=True),
+             rand_init(rng, 128, 4000, True),
+             rand_steps(rng, "step", 30, 128, 64),
+             vel_updates={24: rng.integers(1, 4, size=128)}, full_tables=False)
+
+    # ---- odd sizes: N not a multiple of 64, A > N, A = 1 -------------------
+    rng = np.random.default_rng(4567)
+    run_case("g8_n70_a5", big_cfg(70, 5, 1500), rand_init(rng, 70, 1500, False),
+             rand_steps(rng, "step", 12, 70, 5), full_tables=False)
+    rng = np.random.default_rng(4568)
+    run_case("g8_n5_a9_ch", big_cfg(5, 9, 300, reward_design=3, communication_range=120),
+             rand_init(rng, 5, 300, False),
+             rand_steps(rng, "ch", 25, 5, 9), table_every=24)
+    rng = np.random.default_rng(4569)
+    run_case("g8_n33_a1", big_cfg(33, 1, 800), rand_init(rng, 33, 800, False),
+             rand_steps(rng, "step", 4, 33, 1), full_tables=False)
+
+
+if __name__ == "__main__":
+    main()

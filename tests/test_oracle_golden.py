@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/diral_oracle.c) to the reference.
+
+Every fixture under tests/golden/ was recorded from the real reference
+(tests/golden/gen_golden.py).  The oracle in its reference-faithful mode
+(sq_mode=SQ_POW) must reproduce every recorded output BIT FOR BIT: rewards,
+channel observations, state vectors, positions, velocities, neighbour-table
+planes, arrival stamps and the information-age histogram.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, SQ_IEEE, SQ_POW
+from tests.golden_util import Golden, golden_names, ulp_diff
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def replay(g, sq_mode, batch=1):
+    o = Oracle(g.cfg, batch=batch, sq_mode=sq_mode)
+    o.reset(g["x0"], g["y0"], g["v0"])
+    out = dict(rews=[], chobs=[], state=[], pos_x=[], vel=[], ia=[], exp=[])
+    for i, mode, acts, t, (ep, eps) in g.steps():
+        rews, chobs = o.step(mode, acts, t)
+        st = o.obtain_state(acts, chobs, rews, ep, eps)
+        out["rews"].append(rews)
+        out["chobs"].append(chobs)
+        out["state"].append(st)
+        out["ia"].append(o.info_age(t))
+        if i in g.vel_updates:
+            o.update_velocity(g.vel_updates[i])
+        e = o.export()
+        out["pos_x"].append(e["pos_x"])
+        out["vel"].append(e["vel"])
+        out["exp"].append(e)
+    return o, out
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_reproduces_reference_bit_exact(name):
+    g = Golden(name)
+    o, out = replay(g, SQ_POW)
+    assert o.S == int(g["state_space"])
+    ck = g.table_checkpoints()
+    for i in range(g.T):
+        for key in ("rews", "chobs", "state", "pos_x", "vel"):
+            got = out[key][i][0]
+            ref = g[key][i]
+            assert got.shape == ref.shape, (key, i)
+            assert np.array_equal(got.view(np.int64), ref.view(np.int64)) or \
+                np.array_equal(got, ref), "%s step %d differs (max ulp %d)" % (
+                    key, i, ulp_diff(got, ref))
+        assert np.array_equal(out["ia"][i][0], g["ia"][i]), ("ia", i)
+        e = out["exp"][i]
+        shas = [sha(e["seq"][0].astype(np.int64)), sha(e["age"][0].astype(np.int64)),
+                sha(e["x"][0]), sha(e["y"][0]), sha(e["la"][0])]
+        assert shas == list(g["table_sha"][i]), "table planes differ at step %d" % i
+        if i in ck:
+            j = ck[i]
+            assert np.array_equal(e["seq"][0], g["tab_seq"][j])
+            assert np.array_equal(e["age"][0], g["tab_age"][j])
+            assert np.array_equal(e["x"][0], g["tab_x"][j])
+            assert np.array_equal(e["y"][0], g["tab_y"][j])
+            assert np.array_equal(e["la"][0], g["tab_la"][j])
+
+
+@pytest.mark.parametrize("name", ["g4_c2_step", "g4_c2_ch", "g4_c2_vary_rd1", "g6_c5_vary",
+                                  "g5_c3_step", "g8_n70_a5", "g3_design6_rc100"])
+def test_ieee_square_mode_matches_on_indices(name):
+    """sq_mode=SQ_IEEE (x*x, what the GPU computes) vs the reference-faithful
+    pow(): every integer/index output identical, distances within 1 ulp."""
+    g = Golden(name)
+    _, a = replay(g, SQ_POW)
+    _, b = replay(g, SQ_IEEE)
+    for i in range(g.T):
+        assert np.array_equal(a["state"][i], b["state"][i]) or \
+            ulp_diff(a["state"][i], b["state"][i]) <= 1
+        # histogram sections / one-hot are index work: exactly equal
+        K = g.cfg.State.num_bins
+        if g.cfg.State.add_positional_dist_piggy and not g.cfg.State.add_reward:
+            assert np.array_equal(a["state"][i][..., -K:], b["state"][i][..., -K:])
+        assert ulp_diff(a["chobs"][i], b["chobs"][i]) <= 1
+        assert ulp_diff(a["rews"][i], b["rews"][i]) <= 1
+        assert np.array_equal(a["pos_x"][i], b["pos_x"][i])
+        ea, eb = a["exp"][i], b["exp"][i]
+        for k in ("seq", "age", "x", "y", "la"):
+            assert np.array_equal(ea[k], eb[k]), (k, i)
+
+
+def test_batch_envs_are_independent():
+    """B copies of the same env give B identical results (batch plumbing)."""
+    g = Golden("g8_n5_a9_ch")
+    _, one = replay(g, SQ_POW, batch=1)
+    _, many = replay(g, SQ_POW, batch=3)
+    for i in range(g.T):
+        for b in range(3):
+            assert np.array_equal(many["state"][i][b], one["state"][i][0])
+            assert np.array_equal(many["rews"][i][b], one["rews"][i][0])
+
+
+def test_histogram_edges_match_numpy():
+    from diral_amd.config import bench_config
+    for K in (1, 7, 10, 20, 33, 40, 64):
+        for rb in (500, 250, 123.456, 0.3):
+            cfg = bench_config(8, 4, 100.0, bin_range=rb, State=dict(num_bins=K))
+            e = Oracle(cfg).edges()
+            ref = np.linspace(-rb, rb, K + 1)
+            assert np.array_equal(e, ref), (K, rb)
+
+
+def test_histogram_bin_edges_sweep():
+    """G7: distances exactly on / 1 ulp around every bin edge, checked against
+    NumPy itself (np.histogram is the third-party routine the reference calls at
+    network.py:500)."""
+    from diral_amd.config import bench_config
+    for K, rb in ((10, 500), (20, 500), (40, 500), (20, 123.456), (7, 250.0)):
+        N = 6
+        cfg = bench_config(N, 4, 100000.0, bin_range=rb, State=dict(num_bins=K))
+        edges = np.linspace(-rb, rb, K + 1)
+        cand = []
+        for ed in edges:
+            cand += [ed, np.nextafter(ed, -np.inf), np.nextafter(ed, np.inf)]
+        cand = [c for c in cand if abs(c) < rb and c != 0.0]
+        own_x = 5000.0
+        for start in range(0, len(cand), N - 1):
+            chunk = cand[start:start + N - 1]
+            o = Oracle(cfg)
+            px = np.full(N, own_x)
+            o.reset(px, np.zeros(N), np.ones(N))
+            seq = np.zeros((1, N, N), np.int32)
+            age = np.full((1, N, N), 99, np.int32)
+            x = np.zeros((1, N, N))
+            for j, c in enumerate(chunk):
+                k = j + 1
+                seq[0, 0, k] = 1
+                age[0, 0, k] = 0
+                x[0, 0, k] = own_x + c          # exact: |c| << 2**52 ulp(own_x)? checked below
+            o.import_state(seq=seq, age=age, x=x, y=np.zeros((1, N, N)))
+            st = o.obtain_state(np.zeros(N, np.int32), np.zeros((1, N, 4)), np.zeros((1, N)))
+            hist = st[0, 0, -K:]
+            vals = []
+            for j, c in enumerate(chunk):
+                dx = (own_x + c) - own_x
+                d = np.sqrt(dx * dx)
+                if d < rb:
+                    vals.append(d * (1 if dx > 0 else -1))
+            ref = np.histogram(sorted(vals), K, range=(-rb, rb))[0] / float(len(vals)) \
+                if vals else np.zeros(K)
+            assert np.array_equal(hist, ref), (K, rb, chunk)
