@@ -1,0 +1,79 @@
+"""ctypes loader for libdiral_env.so (the C-ABI of include/diral_env.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, every
+product entry point raises.  (The CPU restatement under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .config import DiralCfg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdiral_env.so")
+
+# every symbol include/diral_env.h declares
+SYMBOLS = [
+    "diral_cfg_defaults", "diral_env_state_space", "diral_env_validate", "diral_env_strerror",
+    "diral_env_abi_version", "diral_env_create", "diral_env_destroy", "diral_env_hbm_bytes",
+    "diral_env_reset", "diral_env_step", "diral_env_observe", "diral_env_update_velocity",
+    "diral_env_sample", "diral_env_info_age", "diral_env_export_state", "diral_env_import_state",
+    "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error",
+]
+
+_lib = None
+
+
+class DiralLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DiralLibraryError(
+            "%s is missing - build it with `python -m diral_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 not present
+        raise DiralLibraryError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    P, I, I64, U64, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
+    CFG = ctypes.POINTER(DiralCfg)
+    sig = {
+        "diral_cfg_defaults": (None, [CFG]),
+        "diral_env_state_space": (I, [CFG]),
+        "diral_env_validate": (I, [CFG]),
+        "diral_env_strerror": (ctypes.c_char_p, [I]),
+        "diral_env_abi_version": (I, []),
+        "diral_env_create": (I, [CFG, I, I, ctypes.POINTER(P)]),
+        "diral_env_destroy": (I, [P]),
+        "diral_env_hbm_bytes": (I64, [P]),
+        "diral_env_reset": (I, [P, P, P, P, U64, P]),
+        "diral_env_step": (I, [P, I, P, I64, P, P, P, P, I, D, D, P]),
+        "diral_env_observe": (I, [P, P, P, P, P, I, D, D, P]),
+        "diral_env_update_velocity": (I, [P, P, U64, P]),
+        "diral_env_sample": (I, [P, P, U64, P]),
+        "diral_env_info_age": (I, [P, I64, P, P]),
+        "diral_env_export_state": (I, [P] + [P] * 8 + [P]),
+        "diral_env_import_state": (I, [P] + [P] * 7 + [P]),
+        "diral_env_metrics": (I, [P, P, I, P]),
+        "diral_env_check": (I, [P, P]),
+        "diral_env_last_hip_error": (ctypes.c_char_p, [P]),
+    }
+    for name in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise DiralLibraryError("libdiral_env.so lacks symbol %s" % name) from exc
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+def strerror(status: int) -> str:
+    return load().diral_env_strerror(status).decode()

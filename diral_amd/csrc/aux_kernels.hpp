@@ -1,0 +1,127 @@
+// aux_kernels.hpp - the small kernels around the step: topology reset, action
+// sampling, velocity update, state export/import, information-age histogram,
+// metric read-out.  All are elementwise / tiny; none is on the hot path.
+#pragma once
+#include "common.hpp"
+
+namespace diral {
+
+// counter-based generator (splitmix64 finaliser over seed/stream/index); the
+// reference uses unseeded global RNGs, so only the distribution matters.
+__device__ inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ inline uint64_t rng_u64(uint64_t seed, uint64_t stream, uint64_t idx) {
+  return mix64(mix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx);
+}
+__device__ inline double rng_unit(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+
+// Network.initialize_mobility_topology (network.py:92-119): x = randint(0, L)
+// (integer valued), y = randint(0, H/2) = 0, v = 1.7 if mobility_vary else
+// uniform(1.1, 2.7); any of x0/y0/v0 given => copied instead.
+__global__ void reset_kernel(int total, double L, int vary, uint64_t seed, const double* x0,
+                             const double* y0, const double* v0, double* pos_x, double* pos_y,
+                             double* vel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  double x, y, v;
+  if (x0) x = x0[i];
+  else {
+    const double Lf = floor(L);
+    x = floor(rng_unit(rng_u64(seed, 1, (uint64_t)i)) * Lf);
+    if (x >= Lf) x = Lf - 1.0;
+  }
+  y = y0 ? y0[i] : 0.0;
+  if (v0) v = v0[i];
+  else v = vary ? 1.7 : 1.1 + rng_unit(rng_u64(seed, 2, (uint64_t)i)) * (2.7 - 1.1);
+  pos_x[i] = x; pos_y[i] = y; vel[i] = v;
+}
+
+// TestEnv.sample (test_env.py:116-122)
+__global__ void sample_kernel(int total, int A, uint64_t seed, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  out[i] = (int32_t)(rng_u64(seed, 3, (uint64_t)i) % (uint64_t)A);
+}
+
+// Network.update_velocity (network.py:208-223)
+__global__ void velocity_kernel(int total, const uint8_t* draws, uint64_t seed, double* vel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int r = draws ? (int)draws[i] : 1 + (int)(rng_u64(seed, 4, (uint64_t)i) % 3ull);
+  double v = vel[i];
+  if (r == 1) { v += 0.55; if (v > 2.77) v = 2.77; }
+  else if (r == 2) { v -= 0.55; if (v < 1.1) v = 1.1; }
+  vel[i] = v;
+}
+
+// subject-major packed table -> reference-shaped [env][viewer][subject] planes
+__global__ void export_tables_kernel(int B, int N, int NV, const uint32_t* tkey, const double* tx,
+                                     const double* pos_y, int32_t* seq, int32_t* age, double* x,
+                                     double* y) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * N;
+  if (i >= total) return;
+  const int k = (int)(i % N);
+  const int u = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t src = ((size_t)b * N + k) * NV + u;
+  const uint32_t w = tkey[src];
+  if (seq) seq[i] = (int32_t)(w >> 8);
+  if (age) age[i] = (int32_t)(w & 255u);
+  if (x) x[i] = tx[src];
+  if (y) y[i] = (w >> 8) ? pos_y[(size_t)b * N + k] : 0.0;
+}
+
+__global__ void import_tables_kernel(int B, int N, int NV, const int32_t* seq, const int32_t* age,
+                                     const double* x, uint32_t* tkey, double* tx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * N;
+  if (i >= total) return;
+  const int k = (int)(i % N);
+  const int u = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t dst = ((size_t)b * N + k) * NV + u;
+  if (seq || age) {
+    uint32_t w = tkey[dst];
+    uint32_t s = seq ? (uint32_t)seq[i] : (w >> 8);
+    int a = age ? age[i] : (int)(w & 255u);
+    if (a > 255) a = 255;
+    if (a < 0) a = 0;
+    tkey[dst] = (s << 8) | (uint32_t)a;
+  }
+  if (x) tx[dst] = x[i];
+}
+
+// Network.get_information_age (network.py:560-574); one workgroup per env.
+// Python's negative list indexing (ia in [-100,-1]) is reproduced.
+__global__ void info_age_kernel(int N, long long t, const int32_t* la, int32_t* out) {
+  __shared__ int bins[100];
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < 100; j += blockDim.x) bins[j] = 0;
+  __syncthreads();
+  const int32_t* l = la + (size_t)b * N * N;
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    const int tx = i / N, rx = i - tx * N;
+    if (tx == rx) continue;
+    const int32_t v = l[i];
+    if (v != -1) {
+      long long ia = t - (long long)v;
+      if (ia < 100) { if (ia < 0) ia += 100; if (ia >= 0) atomicAdd(&bins[(int)ia], 1); }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 100; j += blockDim.x) out[(size_t)b * 100 + j] = bins[j];
+}
+
+__global__ void metrics_kernel(int total, double* metrics, double* out, int clear) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (out) out[i] = metrics[i];
+  if (clear) metrics[i] = 0.0;
+}
+
+}  // namespace diral

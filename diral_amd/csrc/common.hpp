@@ -1,0 +1,97 @@
+// common.hpp - shared host/device definitions for libdiral_env.so (gfx950 only).
+//
+// Data layout in HBM (one DiralEnv handle, B envs, N vehicles):
+//   pos_x,pos_y,vel  f64 [B][N]          Vehicle.pos_x/pos_y/velocity (vehicle.py:9-14)
+//   tkey             u32 [B][N][NV]      neighbour table, SUBJECT-major: tkey[b][k][u] is
+//                                        viewer u's entry about vehicle k, packed
+//                                        (seq_number << 8) | min(last_updated, 255)
+//   tx               f64 [B][N][NV]      the entry's xpos, same indexing
+//   (ypos is not stored: it is pos_y[k] once seq > 0, else 0 - SURVEY.md Q7)
+//   la               i32 [B][N][N]       last_arrival_time[tx][rx] (optional)
+//   pf               i32 [B][N]          pf_counter (optional)
+//   metrics          f64 [B][DIRAL_M_COLUMNS]
+// NV = N rounded up to 16 so every subject column starts 64-byte aligned.
+// The reference stores the table viewer-major (one dict per Vehicle); subject-
+// major makes "all viewers of one subject" contiguous, which is what a
+// wavefront (lane = viewer) loads with one coalesced instruction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diral_env.h"
+
+namespace diral {
+
+constexpr int kModeObserve = 3;  // internal: obtain_state only
+
+constexpr uint32_t kErrAction = 1u;
+constexpr uint32_t kErrSeq = 2u;
+
+struct StepParams {
+  // geometry
+  int B, N, A, K, S, NV;
+  uint32_t flags;
+  int mode;            // DiralStepMode or kModeObserve
+  int reward_design, state_type;
+  int age_limit, pf_threshold;
+  double pf_penalty;
+  double L, H, Rc, Rb, hist_denom;
+  long long t;
+  double episode, eps;
+  int out_f64;
+  int episode_interval;
+  // state-vector section offsets (test_env.py:527-583 order), -1 = absent
+  int off_act, off_chobs, off_posdist, off_hist, off_rew, off_idx, off_pos, off_vel, off_fp;
+  // persistent state
+  double* pos_x;
+  double* pos_y;
+  double* vel;
+  uint32_t* tkey;
+  double* tx;
+  int32_t* la;
+  int32_t* pf;
+  double* metrics;
+  uint32_t* err;
+  const double* edges;  // [K+1] np.linspace(-Rb, Rb, K+1), built on the host
+  // per-call I/O
+  const int32_t* actions;
+  void* state_out;
+  void* rew_out;
+  uint8_t* done_out;
+  void* chobs_out;
+  const double* chobs_in;
+  const double* rew_in;
+};
+
+// LDS carve of the fused step kernel; byte offsets, doubles first.
+struct LdsLayout {
+  uint32_t px, py, npx, vel, rv, rtx, rew, edges, red, mask, act, inr, hist, cnt, mtab, scratch, total;
+};
+
+__host__ __device__ inline uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+__host__ __device__ inline LdsLayout lds_layout(int npad, int A, int K, int vpl, int waves) {
+  LdsLayout l;
+  uint32_t o = 0;
+  l.px = o;    o += 8u * npad;
+  l.py = o;    o += 8u * npad;
+  l.npx = o;   o += 8u * npad;
+  l.vel = o;   o += 8u * npad;
+  l.rv = o;    o += 8u * A;
+  l.rtx = o;   o += 8u * npad;
+  l.rew = o;   o += 8u * npad;
+  l.edges = o; o += 8u * (K + 1);
+  l.red = o;   o += 8u * 8 * waves;
+  l.mask = o;  o += 8u * A * vpl;
+  l.act = o;   o += 4u * npad;
+  l.inr = o;   o += 4u * npad;
+  l.hist = o;  o += 4u * K * npad;
+  l.cnt = o;   o += 4u * npad;
+  l.mtab = o;  o += align_up((uint32_t)A * npad, 16);
+  l.scratch = o;
+  if (vpl > 1) o += 4096u * waves;  // CC columns x npad keys per wave
+  l.total = align_up(o, 16);
+  return l;
+}
+
+}  // namespace diral

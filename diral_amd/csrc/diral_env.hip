@@ -1,0 +1,422 @@
+// diral_env.hip - C-ABI implementation of include/diral_env.h for gfx950.
+// Host side: config validation, HBM allocation, kernel launches.  No torch
+// types anywhere; every data pointer in the ABI is a device pointer.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.hpp"
+#include "common.hpp"
+#include "step_kernel.hpp"
+
+using namespace diral;
+
+struct DiralEnv {
+  DiralCfg cfg;
+  int B = 0, N = 0, A = 0, K = 0, S = 0, NV = 0, vpl = 1;
+  int device = 0;
+  StepParams base;       // everything that does not change per call
+  uint32_t lds_bytes = 0;
+  double* pos_x = nullptr;
+  double* pos_y = nullptr;
+  double* vel = nullptr;
+  uint32_t* tkey = nullptr;
+  double* tx = nullptr;
+  int32_t* la = nullptr;
+  int32_t* pf = nullptr;
+  double* metrics = nullptr;
+  uint32_t* err = nullptr;
+  double* edges = nullptr;
+  int64_t hbm_bytes = 0;
+  std::string last_hip_error;
+};
+
+namespace {
+
+bool has(const DiralCfg* c, uint32_t f) { return (c->flags & f) != 0; }
+
+int note_hip(DiralEnv* e, hipError_t st, const char* what) {
+  if (st == hipSuccess) return DIRAL_OK;
+  if (e) e->last_hip_error = std::string(what) + ": " + hipGetErrorString(st);
+  return DIRAL_ERR_HIP;
+}
+
+#define HIP_TRY(env, call)                                   \
+  do {                                                       \
+    hipError_t st__ = (call);                                \
+    if (st__ != hipSuccess) return note_hip(env, st__, #call); \
+  } while (0)
+
+// np.linspace(start, stop, num), endpoint=True (numpy/_core/function_base.py):
+// y[i] = i*step + start with both roundings, last = stop.
+void np_linspace(double start, double stop, int num, std::vector<double>& out) {
+  out.assign(num, 0.0);
+  const int div = num - 1;
+  const double delta = stop - start;
+  if (div > 0) {
+    const double step = delta / (double)div;
+    for (int i = 0; i < num; ++i) {
+      volatile double y = (double)i;
+      if (step == 0.0) { y = y / (double)div; y = y * delta; }
+      else y = y * step;
+      volatile double r = y + start;
+      out[i] = r;
+    }
+    out[num - 1] = stop;
+  } else if (num == 1) {
+    out[0] = start;
+  }
+}
+
+struct Offsets { int act, chobs, posdist, hist, rew, idx, pos, vel, fp, S; };
+
+// section order of TestEnv.obtain_state (test_env.py:527-583)
+Offsets state_offsets(const DiralCfg* c) {
+  Offsets o{-1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
+  int p = 0;
+  if (has(c, DIRAL_F_ADD_ACTION)) { o.act = p; p += has(c, DIRAL_F_ACTION_REAL) ? 1 : c->num_channels; }
+  if (has(c, DIRAL_F_ADD_CHANNEL_OBS)) { o.chobs = p; p += c->num_channels; }
+  if (has(c, DIRAL_F_ADD_POSDIST)) { o.posdist = p; p += c->num_users - 1; }
+  if (has(c, DIRAL_F_ADD_POSDIST_PIGGY)) { o.hist = p; p += c->num_bins; }
+  if (has(c, DIRAL_F_ADD_REWARD)) { o.rew = p; p += 1; }
+  if (has(c, DIRAL_F_ADD_INDEX)) { o.idx = p; p += 1; }
+  if (has(c, DIRAL_F_ADD_POSITION)) { o.pos = p; p += 2; }
+  if (has(c, DIRAL_F_ADD_VELOCITY)) { o.vel = p; p += 1; }
+  if (has(c, DIRAL_F_FINGERPRINT)) { o.fp = p; p += 2; }
+  o.S = p;
+  return o;
+}
+
+int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
+
+template <int VPL>
+hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
+  hipLaunchKernelGGL(step_kernel<VPL>, dim3(p.B), dim3(Geo<VPL>::THREADS), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s) {
+  switch (vpl) {
+    case 1: return launch_step<1>(p, lds, s);
+    case 2: return launch_step<2>(p, lds, s);
+    default: return launch_step<4>(p, lds, s);
+  }
+}
+
+template <int VPL>
+hipError_t set_lds_attr(uint32_t lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
+
+}  // namespace
+
+extern "C" {
+
+int diral_env_abi_version(void) { return DIRAL_ABI_VERSION; }
+
+const char* diral_env_strerror(int status) {
+  switch (status) {
+    case DIRAL_OK: return "ok";
+    case DIRAL_ERR_BAD_ARG: return "bad argument";
+    case DIRAL_ERR_BAD_CONFIG: return "config rejected (the reference cannot run it either, or undefined behaviour there)";
+    case DIRAL_ERR_UNSUPPORTED: return "valid reference config outside this build's limits";
+    case DIRAL_ERR_HIP: return "HIP runtime error (see diral_env_last_hip_error)";
+    case DIRAL_ERR_NO_DEVICE: return "no usable HIP device";
+    case DIRAL_ERR_ACTION_RANGE: return "action outside [0, num_channels)";
+    case DIRAL_ERR_SEQ_OVERFLOW: return "more than DIRAL_MAX_SLOTS steps since reset";
+    default: return "unknown status";
+  }
+}
+
+void diral_cfg_defaults(DiralCfg* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->struct_bytes = sizeof(DiralCfg);
+  c->flags = 0;
+  c->num_users = 3;            // test_env.py:12
+  c->num_channels = 3;         // test_env.py:13
+  c->num_bins = 20;
+  c->reward_design = 1;        // test_env.py:20
+  c->state_type = 2;
+  c->posdist_type = 2;
+  c->episode_interval = 25;    // main_test.py:22
+  c->info_age_limit = 20;      // network.py:547
+  c->pf_threshold = 10;        // test_env.py:89
+  c->pf_penalty = -10.0;       // test_env.py:90
+  c->highway_length = 200;     // test_env.py:18
+  c->highway_height = 2;       // network.py:31
+  c->communication_range = 1;  // test_env.py:21
+  c->bin_range = 500;          // test_env.py:24
+}
+
+int diral_env_validate(const DiralCfg* c) {
+  if (!c || c->struct_bytes != sizeof(DiralCfg)) return DIRAL_ERR_BAD_ARG;
+  if (c->num_users < 1 || c->num_channels < 1) return DIRAL_ERR_BAD_CONFIG;
+  if (c->reward_design < 1 || c->reward_design > 5) return DIRAL_ERR_BAD_CONFIG;   // test_env.py:198-199
+  if (c->state_type != 1 && c->state_type != 2) return DIRAL_ERR_BAD_CONFIG;
+  if (!has(c, DIRAL_F_MOBILITY) && !has(c, DIRAL_F_DESIGN_TOPOLOGY)) return DIRAL_ERR_BAD_CONFIG;  // network.py:54-60
+  if (c->episode_interval < 1 || c->info_age_limit < 0 || c->info_age_limit > 255) return DIRAL_ERR_BAD_CONFIG;
+  if (!(c->highway_length > 0) || !(c->highway_height > 0)) return DIRAL_ERR_BAD_CONFIG;
+  if (has(c, DIRAL_F_ADD_POSDIST_PIGGY)) {
+    if (c->posdist_type != 1 && c->posdist_type != 2) return DIRAL_ERR_BAD_CONFIG;  // test_env.py:555-560
+    if (c->num_bins < 1 || !(c->bin_range > 0)) return DIRAL_ERR_BAD_CONFIG;
+    if (c->num_bins > DIRAL_MAX_BINS) return DIRAL_ERR_UNSUPPORTED;
+    if (c->posdist_type == 1) return DIRAL_ERR_UNSUPPORTED;   // a15: not built yet
+  }
+  if (has(c, DIRAL_F_ADD_POSDIST)) return DIRAL_ERR_UNSUPPORTED;  // a16: not built yet
+  if (c->num_users > DIRAL_MAX_USERS || c->num_channels > DIRAL_MAX_CHANNELS) return DIRAL_ERR_UNSUPPORTED;
+  const int vpl = vpl_for(c->num_users);
+  const LdsLayout l = lds_layout(64 * vpl, c->num_channels, c->num_bins > 0 ? c->num_bins : 1, vpl, 4 * vpl);
+  if (l.total > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
+  return DIRAL_OK;
+}
+
+int diral_env_state_space(const DiralCfg* c) {
+  if (!c || c->struct_bytes != sizeof(DiralCfg)) return DIRAL_ERR_BAD_ARG;
+  return state_offsets(c).S;
+}
+
+int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out) {
+  if (!out) return DIRAL_ERR_BAD_ARG;
+  *out = nullptr;
+  int st = diral_env_validate(cfg);
+  if (st != DIRAL_OK) return st;
+  if (batch < 1) return DIRAL_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DIRAL_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return DIRAL_ERR_NO_DEVICE;
+
+  DiralEnv* e = new DiralEnv();
+  e->cfg = *cfg;
+  e->B = batch; e->N = cfg->num_users; e->A = cfg->num_channels;
+  e->K = cfg->num_bins > 0 ? cfg->num_bins : 1;
+  e->NV = (int)align_up((uint32_t)e->N, 16);
+  e->vpl = vpl_for(e->N);
+  e->device = device;
+  const Offsets off = state_offsets(cfg);
+  e->S = off.S;
+
+  auto fail = [&](int code) { diral_env_destroy(e); return code; };
+  if (hipSetDevice(device) != hipSuccess) return fail(DIRAL_ERR_NO_DEVICE);
+
+  const size_t bn = (size_t)e->B * e->N;
+  const size_t tab = bn * e->NV;
+  auto alloc = [&](void** p, size_t bytes) {
+    hipError_t r = hipMalloc(p, bytes);
+    if (r == hipSuccess) e->hbm_bytes += (int64_t)bytes;
+    return r;
+  };
+#define CREATE_TRY(call) do { hipError_t r__ = (call); if (r__ != hipSuccess) { note_hip(e, r__, #call); \
+      std::fprintf(stderr, "diral_env_create: %s\n", e->last_hip_error.c_str()); return fail(DIRAL_ERR_HIP); } } while (0)
+  CREATE_TRY(alloc((void**)&e->pos_x, bn * 8));
+  CREATE_TRY(alloc((void**)&e->pos_y, bn * 8));
+  CREATE_TRY(alloc((void**)&e->vel, bn * 8));
+  CREATE_TRY(alloc((void**)&e->tkey, tab * 4));
+  CREATE_TRY(alloc((void**)&e->tx, tab * 8));
+  CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
+  CREATE_TRY(alloc((void**)&e->err, 4));
+  CREATE_TRY(alloc((void**)&e->edges, (size_t)(e->K + 1) * 8));
+  if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
+  if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
+
+  std::vector<double> edges;
+  np_linspace(-cfg->bin_range, cfg->bin_range, e->K + 1, edges);
+  CREATE_TRY(hipMemcpy(e->edges, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
+  CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
+  CREATE_TRY(hipMemset(e->vel, 0, bn * 8));
+  CREATE_TRY(hipMemset(e->tkey, 0, tab * 4));
+  CREATE_TRY(hipMemset(e->tx, 0, tab * 8));
+  CREATE_TRY(hipMemset(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8));
+  CREATE_TRY(hipMemset(e->err, 0, 4));
+  if (e->la) CREATE_TRY(hipMemset(e->la, 0xFF, bn * e->N * 4));
+  if (e->pf) CREATE_TRY(hipMemset(e->pf, 0, bn * 4));
+
+  const LdsLayout l = lds_layout(64 * e->vpl, e->A, e->K, e->vpl, 4 * e->vpl);
+  e->lds_bytes = l.total;
+  if (e->vpl == 1) CREATE_TRY(set_lds_attr<1>(l.total));
+  else if (e->vpl == 2) CREATE_TRY(set_lds_attr<2>(l.total));
+  else CREATE_TRY(set_lds_attr<4>(l.total));
+#undef CREATE_TRY
+
+  StepParams& p = e->base;
+  std::memset(&p, 0, sizeof(p));
+  p.B = e->B; p.N = e->N; p.A = e->A; p.K = e->K; p.S = e->S; p.NV = e->NV;
+  p.flags = cfg->flags;
+  p.reward_design = cfg->reward_design; p.state_type = cfg->state_type;
+  p.age_limit = cfg->info_age_limit; p.pf_threshold = cfg->pf_threshold; p.pf_penalty = cfg->pf_penalty;
+  p.L = cfg->highway_length; p.H = cfg->highway_height; p.Rc = cfg->communication_range;
+  p.Rb = cfg->bin_range;
+  { volatile double d = cfg->bin_range - (-cfg->bin_range); p.hist_denom = d; }
+  p.episode_interval = cfg->episode_interval;
+  p.off_act = off.act; p.off_chobs = off.chobs; p.off_posdist = off.posdist; p.off_hist = off.hist;
+  p.off_rew = off.rew; p.off_idx = off.idx; p.off_pos = off.pos; p.off_vel = off.vel; p.off_fp = off.fp;
+  p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel = e->vel; p.tkey = e->tkey; p.tx = e->tx;
+  p.la = e->la; p.pf = e->pf; p.metrics = e->metrics; p.err = e->err; p.edges = e->edges;
+  *out = e;
+  return DIRAL_OK;
+}
+
+int diral_env_destroy(DiralEnv* e) {
+  if (!e) return DIRAL_OK;
+  (void)hipSetDevice(e->device);
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  delete e;
+  return DIRAL_OK;
+}
+
+int64_t diral_env_hbm_bytes(const DiralEnv* e) { return e ? e->hbm_bytes : 0; }
+
+const char* diral_env_last_hip_error(const DiralEnv* e) { return e ? e->last_hip_error.c_str() : ""; }
+
+int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const double* v0, uint64_t seed,
+                    void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bn = (size_t)e->B * e->N;
+  const size_t tab = bn * e->NV;
+  HIP_TRY(e, hipMemsetAsync(e->tkey, 0, tab * 4, s));
+  HIP_TRY(e, hipMemsetAsync(e->tx, 0, tab * 8, s));
+  HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
+  if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));
+  if (e->pf) HIP_TRY(e, hipMemsetAsync(e->pf, 0, bn * 4, s));
+  hipLaunchKernelGGL(reset_kernel, dim3(blocks(bn, 256)), dim3(256), 0, s, (int)bn, e->cfg.highway_length,
+                     has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0, seed, x0, y0, v0, e->pos_x, e->pos_y, e->vel);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, void* state_out, void* rew_out,
+                   uint8_t* done_out, void* chobs_out, int out_dtype, double episode, double epsilon,
+                   void* stream) {
+  if (!e || !actions) return DIRAL_ERR_BAD_ARG;
+  if (mode != DIRAL_STEP_MY_STEP && mode != DIRAL_STEP_MY_STEP_CH && mode != DIRAL_STEP_DESIGN)
+    return DIRAL_ERR_BAD_ARG;
+  if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  // my_step_ch defines rewards only for reward_design 2,3,4 (test_env.py:413-429)
+  if (mode == DIRAL_STEP_MY_STEP_CH && (e->cfg.reward_design < 2 || e->cfg.reward_design > 4))
+    return DIRAL_ERR_BAD_CONFIG;
+  StepParams p = e->base;
+  p.mode = mode; p.t = t; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
+  p.actions = actions;
+  p.state_out = e->S > 0 ? state_out : nullptr;
+  p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
+  p.chobs_in = nullptr; p.rew_in = nullptr;
+  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream));
+  return DIRAL_OK;
+}
+
+int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_in, const double* rew_in,
+                      void* state_out, int out_dtype, double episode, double epsilon, void* stream) {
+  if (!e || !actions || !state_out) return DIRAL_ERR_BAD_ARG;
+  if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  if (e->S == 0) return DIRAL_OK;
+  StepParams p = e->base;
+  p.mode = kModeObserve; p.t = 0; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
+  p.actions = actions; p.state_out = state_out;
+  p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
+  p.chobs_in = chobs_in; p.rew_in = rew_in;
+  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream));
+  return DIRAL_OK;
+}
+
+int diral_env_update_velocity(DiralEnv* e, const uint8_t* draws, uint64_t seed, void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  if (!has(&e->cfg, DIRAL_F_MOBILITY_VARY)) return DIRAL_OK;   // test_env.py:503
+  const size_t bn = (size_t)e->B * e->N;
+  hipLaunchKernelGGL(velocity_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, draws,
+                     seed, e->vel);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_sample(DiralEnv* e, int32_t* actions_out, uint64_t seed, void* stream) {
+  if (!e || !actions_out) return DIRAL_ERR_BAD_ARG;
+  const size_t bn = (size_t)e->B * e->N;
+  hipLaunchKernelGGL(sample_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, e->A, seed,
+                     actions_out);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_info_age(DiralEnv* e, int64_t t, int32_t* out, void* stream) {
+  if (!e || !out) return DIRAL_ERR_BAD_ARG;
+  if (!e->la) return DIRAL_ERR_BAD_CONFIG;
+  hipLaunchKernelGGL(info_age_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, e->N, (long long)t, e->la, out);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* vel, int32_t* tab_seq,
+                           int32_t* tab_age, double* tab_x, double* tab_y, int32_t* last_arrival, void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bn = (size_t)e->B * e->N;
+  if (pos_x) HIP_TRY(e, hipMemcpyAsync(pos_x, e->pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (pos_y) HIP_TRY(e, hipMemcpyAsync(pos_y, e->pos_y, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (vel) HIP_TRY(e, hipMemcpyAsync(vel, e->vel, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (tab_seq || tab_age || tab_x || tab_y) {
+    const size_t total = bn * e->N;
+    hipLaunchKernelGGL(export_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->tkey,
+                       e->tx, e->pos_y, tab_seq, tab_age, tab_x, tab_y);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (last_arrival) {
+    if (!e->la) return DIRAL_ERR_BAD_CONFIG;
+    HIP_TRY(e, hipMemcpyAsync(last_arrival, e->la, bn * e->N * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return DIRAL_OK;
+}
+
+int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y, const double* vel,
+                           const int32_t* tab_seq, const int32_t* tab_age, const double* tab_x,
+                           const int32_t* last_arrival, void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bn = (size_t)e->B * e->N;
+  if (pos_x) HIP_TRY(e, hipMemcpyAsync(e->pos_x, pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (pos_y) HIP_TRY(e, hipMemcpyAsync(e->pos_y, pos_y, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (vel) HIP_TRY(e, hipMemcpyAsync(e->vel, vel, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (tab_seq || tab_age || tab_x) {
+    const size_t total = bn * e->N;
+    hipLaunchKernelGGL(import_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, tab_seq,
+                       tab_age, tab_x, e->tkey, e->tx);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (last_arrival) {
+    if (!e->la) return DIRAL_ERR_BAD_CONFIG;
+    HIP_TRY(e, hipMemcpyAsync(e->la, last_arrival, bn * e->N * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return DIRAL_OK;
+}
+
+int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  const int total = e->B * DIRAL_M_COLUMNS;
+  hipLaunchKernelGGL(metrics_kernel, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total, e->metrics,
+                     out, clear);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_check(DiralEnv* e, void* stream) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  uint32_t flags = 0;
+  HIP_TRY(e, hipMemcpyAsync(&flags, e->err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+  if (flags) HIP_TRY(e, hipMemsetAsync(e->err, 0, 4, (hipStream_t)stream));
+  if (flags & kErrAction) return DIRAL_ERR_ACTION_RANGE;
+  if (flags & kErrSeq) return DIRAL_ERR_SEQ_OVERFLOW;
+  return DIRAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,590 @@
+// step_kernel.hpp - the fused env-step kernel (one workgroup = one env).
+//
+// Replaces, for one env per workgroup and one time-slot per launch:
+//   TestEnv.my_step / my_step_ch / my_step_design  (test_env.py:124-266/351-443/269-349)
+//   + TestEnv.obtain_state                          (test_env.py:527-583)
+// i.e. Network.periodic_update, find_closest_tx, received_update,
+// calculate_reward_weights, update_positions, get_positional_dist_2_piggy.
+//
+// Mapping to CDNA4 (no MFMA: there is no dense contraction on this path):
+//   lane  = viewer vehicle u (VPL viewers per lane when N > 64)
+//   wave  = 16 subject columns of the neighbour table
+//   * per-resource transmitter sets are 64-bit wave ballots; collision counts
+//     and the PRR in-range/received counts are popcounts of ballots
+//   * the gossip merge Vehicle.received_update is a per-COLUMN problem: for a
+//     fixed subject k the entry is fully determined by its sequence number, so
+//     "rx copies tx's row where tx is fresher" == key[u] = max(key[u], key[m_i(u)])
+//     with key = (seq << 8) | source-viewer, applied for resources i = 0..A-1 in
+//     order.  Columns are independent, so a wave walks all A
+//     resources for its 16 columns with NO workgroup barrier:
+//       N <= 64 : the gather is one ds_bpermute per column per resource,
+//       N  > 64 : the column lives in a wave-private LDS scratch (in-order LDS
+//                 queue of a wave orders its own writes and reads).
+//     xpos follows afterwards with ONE gather from the recorded source viewer.
+//   * HBM traffic per env-slot: each table word read once, written once,
+//     coalesced along the viewer axis (subject-major layout, common.hpp).
+//
+// float64 everywhere the reference uses Python floats; build with
+// -ffp-contract=off so a*b+c is never fused (bin edges, distances).
+#pragma once
+#include "common.hpp"
+
+namespace diral {
+
+template <int VPL>
+struct Geo {
+  static constexpr int NPAD = 64 * VPL;      // padded viewer count
+  static constexpr int WAVES = 4 * VPL;      // 16 subject columns per wave
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int CC = 16 / VPL;        // columns per register chunk (16 key regs)
+  static constexpr int NCH = VPL;            // chunks per wave
+};
+
+__device__ inline bool flag(const StepParams& p, uint32_t f) { return (p.flags & f) != 0; }
+
+// Network.dist (network.py:318-332) with correctly rounded v*v (see DESIGN.md
+// on the reference's pow()).
+__device__ inline double dist2d(double x1, double y1, double x2, double y2) {
+  const double dx = x2 - x1, dy = y2 - y1;
+  return __builtin_sqrt(dx * dx + dy * dy);
+}
+
+// Python float `%` for the position wrap (network.py:203): fast exact path when
+// 0 <= s < 2L (Sterbenz), generic fmod + sign fix-up otherwise.
+__device__ inline double py_mod_pos(double s, double L) {
+  if (s >= 0.0 && s < L) return s;
+  if (s >= L && s <= 2.0 * L) {
+    const double r = s - L;            // exact
+    return (r >= L) ? r - L : r;       // s == 2L -> 0
+  }
+  double m = fmod(s, L);
+  if (m != 0.0) { if ((L < 0) != (m < 0)) m += L; } else { m = copysign(0.0, L); }
+  return m;
+}
+
+// np.histogram uniform-bin index (numpy/lib/_histograms_impl.py fast path)
+__device__ inline int hist_bin(double v, double first, double denom, int K, const double* edges) {
+  const double f = ((v - first) / denom) * (double)K;
+  int idx = (int)f;
+  if (idx == K) idx -= 1;
+  if (v < edges[idx]) idx -= 1;
+  if (v >= edges[idx + 1] && idx != K - 1) idx += 1;
+  return idx;
+}
+
+__device__ inline void store_out(void* base, size_t idx, double v, int f64) {
+  if (f64) reinterpret_cast<double*>(base)[idx] = v;
+  else reinterpret_cast<float*>(base)[idx] = (float)v;
+}
+
+// wave-uniform 64-bit LDS value -> SGPR pair, so branches on it are scalar
+__device__ inline unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline int popc_masks(const unsigned long long* m, int vpl) {
+  int c = 0;
+  for (int j = 0; j < vpl; ++j) c += __popcll(m[j]);
+  return c;
+}
+
+// Network.calculate_reward_weights (network.py:273-300) for the tx set `mk`,
+// evaluated wave-uniformly (every lane computes the same value).
+template <int VPL>
+__device__ inline int reward_weight(const StepParams& p, const unsigned long long (&mk)[VPL],
+                                    const double* s_px, const double* s_py) {
+  // calculate_avg_distance (network.py:307-316): combinations order, serial sum
+  double s = 0.0;
+  int cnt = 0;
+  for (int ja = 0; ja < VPL; ++ja) {
+    unsigned long long ma = mk[ja];
+    while (ma) {
+      const int a = ja * 64 + __builtin_ctzll(ma);
+      ma &= ma - 1;
+      for (int jb = ja; jb < VPL; ++jb) {
+        unsigned long long mb = (jb == ja) ? ma : mk[jb];
+        while (mb) {
+          const int b = jb * 64 + __builtin_ctzll(mb);
+          mb &= mb - 1;
+          s = s + dist2d(s_px[a], s_py[a], s_px[b], s_py[b]);
+          ++cnt;
+        }
+      }
+    }
+  }
+  const double m = s / (double)cnt;
+  if (p.flags & DIRAL_F_TOY_WEIGHTS) {
+    // calculate_norm (network.py:225-246)
+    double x_min = p.L + 1, x_max = -p.L - 1;
+    int umin = 0, umax = 0;
+    for (int u = 0; u < p.N; ++u) {
+      const double x = s_px[u];
+      if (x < x_min) { x_min = x; umin = u; }
+      if (x > x_max) { x_max = x; umax = u; }
+    }
+    const double norm = dist2d(s_px[umin], s_py[umin], s_px[umax], s_py[umax]);
+    return m == norm;
+  }
+  return m > p.Rc;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParams p) {
+  using G = Geo<VPL>;
+  constexpr int NPAD = G::NPAD, WAVES = G::WAVES, CC = G::CC, NCH = G::NCH;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const LdsLayout lay = lds_layout(NPAD, p.A, p.K, VPL, WAVES);
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);
+  double* s_py = reinterpret_cast<double*>(smem + lay.py);
+  double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
+  double* s_vel = reinterpret_cast<double*>(smem + lay.vel);
+  double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
+  double* s_rtx = reinterpret_cast<double*>(smem + lay.rtx);
+  double* s_rew = reinterpret_cast<double*>(smem + lay.rew);
+  double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
+  double* s_red = reinterpret_cast<double*>(smem + lay.red);
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
+  int* s_act = reinterpret_cast<int*>(smem + lay.act);
+  int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
+  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
+  unsigned char* s_mtab = smem + lay.mtab;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int N = p.N, A = p.A, K = p.K, NV = p.NV;
+  const bool do_step = p.mode != kModeObserve;
+  const bool piggy = flag(p, DIRAL_F_ADD_POSDIST_PIGGY);
+  const bool want_hist = piggy && p.state_out != nullptr && p.off_hist >= 0;
+  const bool track_la = flag(p, DIRAL_F_TRACK_ARRIVAL) && p.la != nullptr;
+  const bool want_prr = do_step && (p.mode == DIRAL_STEP_MY_STEP_CH ||
+                                    (p.mode == DIRAL_STEP_MY_STEP && flag(p, DIRAL_F_TRACK_PRR)));
+  const size_t bN = (size_t)b * N;
+
+  // ---- P0: stage per-vehicle state, compute the post-move position --------
+  for (int u = tid; u < NPAD; u += G::THREADS) {
+    int a = -1;
+    double x = 0.0, y = 0.0, v = 0.0, nx = 0.0;
+    if (u < N) {
+      a = p.actions[bN + u];
+      if (a < 0 || a >= A) { atomicOr(p.err, kErrAction); a = -1; }
+      x = p.pos_x[bN + u];
+      y = p.pos_y[bN + u];
+      v = p.vel[bN + u];
+      nx = x;
+      if (do_step && flag(p, DIRAL_F_MOBILITY)) nx = py_mod_pos(x + v + p.L, p.L);  // network.py:203
+    }
+    s_act[u] = a; s_px[u] = x; s_py[u] = y; s_vel[u] = v; s_npx[u] = nx;
+    s_cnt[u] = 0u; s_rtx[u] = 1.0; s_rew[u] = 0.0; s_inr[u] = 0;
+  }
+  for (int j = tid; j < K * NPAD; j += G::THREADS) s_hist[j] = 0u;
+  for (int j = tid; j <= K; j += G::THREADS) s_edges[j] = p.edges[j];
+  __syncthreads();
+
+  // per-lane copies of this lane's viewers
+  int myact[VPL];
+  double mypx[VPL], mypy[VPL], mynpx[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int u = lane + 64 * j;
+    myact[j] = s_act[u]; mypx[j] = s_px[u]; mypy[j] = s_py[u]; mynpx[j] = s_npx[u];
+  }
+
+  // ---- P1: per resource: tx set, closest in-range tx per viewer, rewards ----
+  if (do_step) {
+    for (int i = wave; i < A; i += WAVES) {
+      unsigned long long mk[VPL];
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) { mk[j] = __ballot(myact[j] == i); c += __popcll(mk[j]); }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) s_mask[i * VPL + j] = mk[j];
+      }
+      double best[VPL];
+      int bid[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) { best[j] = 100000.0; bid[j] = -1; }   // network.py:385-386
+      if (c > 0) {
+        // Network.find_closest_tx (network.py:378-398), ascending tx id, strict <
+#pragma unroll
+        for (int jt = 0; jt < VPL; ++jt) {
+          unsigned long long m = mk[jt];
+          while (m) {
+            const int w = jt * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            const double xw = s_px[w], yw = s_py[w];
+            int n_in = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const int u = lane + 64 * j;
+              const double d = dist2d(xw, yw, mypx[j], mypy[j]);
+              const bool inr = d < p.Rc;
+              if (inr && d < best[j]) { best[j] = d; bid[j] = w; }
+              const bool rx = (u < N) && (myact[j] != i);
+              if (track_la && rx && !inr) p.la[(bN + w) * N + u] = -1;        // network.py:394
+              if (want_prr && c > 1) n_in += __popcll(__ballot(rx && inr));   // test_env.py:395-397
+            }
+            if (want_prr && c > 1 && lane == 0) s_inr[w] = n_in;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;
+        const bool is_tx = (myact[j] == i);
+        const bool got = (!is_tx) && (bid[j] >= 0) && (u < N) && (c > 0);
+        s_mtab[i * NPAD + u] = (unsigned char)(got ? bid[j] : u);
+        if (u < N) {
+          // channel observation of the reference step (`obs[user][i]`)
+          double ob = 0.0;
+          if (!is_tx && c > 0) {
+            if (p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ob = best[j];  // test_env.py:240
+            else ob = 1.0;                                                    // :228, :306, :432
+          }
+          if (p.chobs_out) store_out(p.chobs_out, (bN + u) * A + i, ob, p.out_f64);
+          if (p.state_out && p.off_chobs >= 0)
+            store_out(p.state_out, (bN + u) * p.S + p.off_chobs + i, ob, p.out_f64);
+          if (track_la && p.mode == DIRAL_STEP_MY_STEP_CH && got)
+            p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;                       // test_env.py:436
+        }
+      }
+      if (want_prr && c > 1) {
+        // received[tx] = #rx whose nearest tx is tx (test_env.py:398-400)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int jt = 0; jt < VPL; ++jt) {
+          unsigned long long m = mk[jt];
+          while (m) {
+            const int w = jt * 64 + __builtin_ctzll(m);
+            m &= m - 1;
+            int n_rec = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const int u = lane + 64 * j;
+              const bool rx = (u < N) && (myact[j] != i);
+              n_rec += __popcll(__ballot(rx && bid[j] == w));
+            }
+            if (lane == 0) {
+              const int n_in = s_inr[w];
+              s_rtx[w] = n_in > 0 ? (double)n_rec / (double)n_in : 1.0;       // test_env.py:402-405
+            }
+          }
+        }
+      }
+      if (p.mode == DIRAL_STEP_MY_STEP && c > 1) {
+        // test_env.py:163-199, one value per resource
+        double rw = 0.0;
+        const int rd = p.reward_design;
+        if (rd == 1) {
+          const int w = reward_weight<VPL>(p, mk, s_px, s_py);
+          const double R = (double)w / (double)c;
+          rw = -1.0 * (1.0 - R);
+        } else if (rd == 2) {
+          if (c == 2) rw = 2.0 * (double)reward_weight<VPL>(p, mk, s_px, s_py) - (double)c;
+          else rw = 0.0 - (double)c;
+        } else if (rd == 3) {
+          const double R = 1.0 / (double)c;
+          rw = -1.0 * exp(1.0 - R);
+        } else if (rd == 4) {
+          rw = 1.0 / (double)c;
+        } else {
+          if (c == 2) rw = (reward_weight<VPL>(p, mk, s_px, s_py) == 1) ? 0.0 : -1.0;
+          else rw = -1.0;
+        }
+        if (lane == 0) s_rv[i] = rw;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: reward per transmitter -----------------------------------------
+  if (do_step) {
+    for (int u = tid; u < NPAD; u += G::THREADS) {
+      double r = 0.0, prr = 0.0;
+      int sole = 0, coll = 0;
+      const int a = s_act[u];
+      if (u < N && a >= 0) {
+        const int c = popc_masks(s_mask + a * VPL, VPL);
+        if (p.mode == DIRAL_STEP_MY_STEP) {                                   // test_env.py:211-222
+          if (c > 1) {
+            r = s_rv[a];
+            if (flag(p, DIRAL_F_PROPORTIONAL_FAIR)) {
+              const int pc = p.pf[bN + u];
+              if (pc > p.pf_threshold) r = p.pf_penalty;
+              p.pf[bN + u] = pc + 1;
+            }
+            coll = 1; prr = s_rtx[u];
+          } else {
+            r = 1.0;
+            if (flag(p, DIRAL_F_PROPORTIONAL_FAIR)) p.pf[bN + u] = 0;
+            sole = 1; prr = 1.0;
+          }
+        } else if (p.mode == DIRAL_STEP_MY_STEP_CH) {                         // test_env.py:411-429
+          const int rd = p.reward_design;
+          if (c > 1) {
+            const double R = s_rtx[u];
+            if (rd == 3) r = 1.0 - exp(1.0 - R);
+            else if (rd == 4) r = -1.0 * exp(1.0 - R);
+            else if (rd == 2) r = -1.0 * (1.0 - R);
+            coll = 1; prr = R;
+          } else {
+            if (rd == 3) r = 1.0;
+            else if (rd == 4) r = exp(1.0);
+            else if (rd == 2) r = 1.0;
+            sole = 1; prr = 1.0;
+          }
+        } else {                                                              // test_env.py:297-301, 319-349
+          if (c == 1) { r = 1.0; sole = 1; }
+          else {
+            int n = 1;
+            double dlast = 0.0;
+            for (int jt = 0; jt < VPL; ++jt) {
+              unsigned long long m = s_mask[a * VPL + jt];
+              while (m) {
+                const int o = jt * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                if (o == u) continue;
+                const double d = dist2d(s_px[u], s_py[u], s_px[o], s_py[o]);
+                if (d < 2.0 * p.Rc) { if (n == 1) dlast = d; ++n; }           // network.py:122-133
+              }
+            }
+            if (n == 1) r = 1.0;
+            else if (n == 2) r = ((dlast / 1.0) > p.Rc * 2.0) ? 0.0 : -2.0;    // network.py:135-157
+            else r = -(double)n;
+            coll = 1;
+          }
+        }
+        s_rew[u] = r;
+        if (p.rew_out) store_out(p.rew_out, bN + u, r, p.out_f64);
+      }
+      // deterministic per-wave reductions for the metric accumulators
+      double vr = r, vp = want_prr ? prr : 0.0;
+      int vs = sole, vc = coll;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        vr += __shfl_down(vr, off);
+        vp += __shfl_down(vp, off);
+        vs += __shfl_down(vs, off);
+        vc += __shfl_down(vc, off);
+      }
+      if (lane == 0) {
+        const int slot = (u >> 6);
+        s_red[slot * 4 + 0] = vr; s_red[slot * 4 + 1] = vp;
+        s_red[slot * 4 + 2] = (double)vs; s_red[slot * 4 + 3] = (double)vc;
+      }
+    }
+  } else {
+    for (int u = tid; u < N; u += G::THREADS) s_rew[u] = p.rew_in ? p.rew_in[bN + u] : 0.0;
+  }
+
+  // ---- P3: neighbour-table stamp + gossip merge + observation histogram ----
+  if (piggy && (do_step || want_hist)) {
+    unsigned int* scratch = reinterpret_cast<unsigned int*>(smem + lay.scratch) + wave * 1024;
+    unsigned int mycnt[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
+
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int kbase = wave * 16 + ch * CC;
+      if (kbase >= N) break;
+      unsigned int w1[CC * VPL];   // post-stamp (seq << 8) | age
+      unsigned int key[CC * VPL];  // (seq << 8) | source viewer
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const int k = kbase + c;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          unsigned int w = 0u;
+          if (k < N && u < N) w = p.tkey[(bN + k) * NV + u];
+          if (do_step) {
+            // Vehicle.periodic_update (vehicle.py:56-70)
+            unsigned int seq = w >> 8, age = w & 255u;
+            if (u == k) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
+            else age = (age < 255u) ? age + 1u : 255u;
+            w = (seq << 8) | age;
+          }
+          w1[c * VPL + j] = w;
+          key[c * VPL + j] = (w & ~255u) | (unsigned int)u;
+        }
+      }
+      if (do_step) {
+        // Vehicle.received_update for every (resource, rx) in reference order
+        if constexpr (VPL == 1) {
+          for (int i = 0; i < A; ++i) {
+            if (uniform_u64(s_mask[i]) == 0ull) continue;
+            const int m4 = (int)s_mtab[i * NPAD + lane] << 2;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+              const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
+              key[c] = max(key[c], v);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) scratch[c * NPAD + lane + 64 * j] = key[c * VPL + j];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          for (int i = 0; i < A; ++i) {
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
+            if (uniform_u64(any) == 0ull) continue;
+            int m[VPL];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
+            unsigned int v[CC * VPL];
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+#pragma unroll
+              for (int j = 0; j < VPL; ++j) v[c * VPL + j] = scratch[c * NPAD + m[j]];
+            // tx entries are not written in resource i (a tx never merges on its
+            // own resource), so all gathers of step i may precede all writes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+#pragma unroll
+              for (int j = 0; j < VPL; ++j) {
+                const unsigned int nk = max(key[c * VPL + j], v[c * VPL + j]);
+                if (nk != key[c * VPL + j]) scratch[c * NPAD + lane + 64 * j] = nk;
+                key[c * VPL + j] = nk;
+              }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          }
+        }
+      }
+      // finalize: xpos follows the winning sequence number; age reset on change
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const int k = kbase + c;
+        if (k >= N) continue;
+        const double pxk = s_px[k], pyk = s_py[k];
+        double xn[VPL];
+        unsigned int wn[VPL];
+        bool changed[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          const unsigned int kf = key[c * VPL + j], w = w1[c * VPL + j];
+          const unsigned int seqf = kf >> 8, src = kf & 255u;
+          const bool upd = (seqf != (w >> 8));
+          double xo = 0.0;
+          if (u < N) xo = p.tx[(bN + k) * NV + u];
+          if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
+          double xg = xo;
+          if constexpr (VPL == 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2loint(xo));
+            const int hi = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2hiint(xo));
+            if (upd) xg = __hiloint2double(hi, lo);
+          } else {
+            if (upd) xg = ((int)src == k) ? pxk : p.tx[(bN + k) * NV + src];
+          }
+          xn[j] = xg;
+          wn[j] = upd ? (seqf << 8) : w;
+          changed[j] = upd;
+        }
+        if (do_step) {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            if (u < N) {
+              p.tkey[(bN + k) * NV + u] = wn[j];
+              if (changed[j] || u == k) p.tx[(bN + k) * NV + u] = xn[j];
+            }
+          }
+        }
+        if (want_hist) {
+          // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            const int age = (int)(wn[j] & 255u);
+            if (u < N && u != k && age < p.age_limit) {
+              const double x1 = xn[j];
+              const double y1 = ((wn[j] >> 8) > 0u) ? pyk : 0.0;
+              const double x2 = mynpx[j], y2 = mypy[j];
+              const double d = dist2d(x1, y1, x2, y2);
+              if (d < p.Rb) {
+                const double v = (x1 - x2 > 0.0) ? d : -d;
+                const int bin = hist_bin(v, -p.Rb, p.hist_denom, K, s_edges);
+                atomicAdd(&s_hist[bin * NPAD + u], 1u);
+                mycnt[j] += 1u;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (want_hist) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j)
+        if (mycnt[j]) atomicAdd(&s_cnt[lane + 64 * j], mycnt[j]);
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: write-back: positions, state vectors, done flag, metrics --------
+  if (do_step) {
+    for (int u = tid; u < N; u += G::THREADS) p.pos_x[bN + u] = s_npx[u];
+    if (tid == 0) {
+      if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+      double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
+      for (int w = 0; w < VPL; ++w) {
+        sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3];
+      }
+      double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+      mt[DIRAL_M_SLOTS] += 1.0;
+      mt[DIRAL_M_SUM_REWARD] += sr;
+      mt[DIRAL_M_TX_SOLE] += ss;
+      mt[DIRAL_M_TX_COLLIDED] += sc;
+      if (want_prr) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
+    }
+  }
+  if (p.state_out) {
+    const int S = p.S;
+    const int total = N * S;
+    int e = tid;
+    int u = e / S, s = e - u * S;
+    const int du = G::THREADS / S, ds = G::THREADS - du * S;
+    while (e < total) {
+      double val = 0.0;
+      bool write = true;
+      if (p.off_act >= 0 && s >= p.off_act && s < p.off_act + ((p.flags & DIRAL_F_ACTION_REAL) ? 1 : A)) {
+        val = (p.flags & DIRAL_F_ACTION_REAL) ? (double)s_act[u]
+                                               : ((s_act[u] == s - p.off_act) ? 1.0 : 0.0);   // test_env.py:585-595
+      } else if (p.off_chobs >= 0 && s >= p.off_chobs && s < p.off_chobs + A) {
+        if (do_step) write = false;   // written in P1
+        else val = p.chobs_in ? p.chobs_in[(bN + u) * A + (s - p.off_chobs)] : 0.0;
+      } else if (p.off_hist >= 0 && s >= p.off_hist && s < p.off_hist + K) {
+        const unsigned int n = s_cnt[u];
+        const unsigned int h = s_hist[(s - p.off_hist) * NPAD + u];
+        val = n ? (double)h / (double)n : 0.0;                                   // network.py:501
+      } else if (s == p.off_rew) {
+        val = s_rew[u];
+      } else if (s == p.off_idx) {
+        val = (double)(u + 1);
+      } else if (p.off_pos >= 0 && s == p.off_pos) {
+        val = s_npx[u] / p.L;                                                    // network.py:403-407
+      } else if (p.off_pos >= 0 && s == p.off_pos + 1) {
+        val = s_py[u] / p.H;
+      } else if (s == p.off_vel) {
+        val = s_vel[u];
+      } else if (p.off_fp >= 0 && s == p.off_fp) {
+        val = p.episode;
+      } else if (p.off_fp >= 0 && s == p.off_fp + 1) {
+        val = p.eps;
+      }
+      if (write) store_out(p.state_out, (size_t)bN * S + e, val, p.out_f64);
+      e += G::THREADS; u += du; s += ds;
+      if (s >= S) { s -= S; u += 1; }
+    }
+  }
+}
+
+}  // namespace diral

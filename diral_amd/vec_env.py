@@ -1,0 +1,321 @@
+"""VecV2VEnv - B parallel DIRAL environments behind the reference's env surface.
+
+The reference env (envs/test_env.py:6 ``TestEnv``) is one Python object per
+process.  This class keeps its method names and argument meaning, batched over
+B independent envs that live on one MI355X and advance in ONE fused HIP launch
+per time-slot (csrc/step_kernel.hpp) through the C-ABI of include/diral_env.h.
+
+PyTorch is plumbing only: it owns device memory for the I/O tensors and supplies
+the current HIP stream.  All arithmetic happens inside libdiral_env.so; there
+is no eager/torch fallback - a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Dict, Mapping, Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from .config import (DT_F32, DT_F64, ERR_HIP, M_COLUMNS, OK, STEP_DESIGN, STEP_MY_STEP,
+                     STEP_MY_STEP_CH, ConfigError, EnvConfig)
+
+_MODES = {"my_step": STEP_MY_STEP, "my_step_ch": STEP_MY_STEP_CH, "my_step_design": STEP_DESIGN,
+          STEP_MY_STEP: STEP_MY_STEP, STEP_MY_STEP_CH: STEP_MY_STEP_CH, STEP_DESIGN: STEP_DESIGN}
+
+
+class DiralError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = "%s: %s (status %d)" % (where, _lib.strerror(status), status)
+        if detail:
+            msg += " - " + detail
+        super().__init__(msg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class VecV2VEnv:
+    """B independent V2V resource-allocation envs on one GPU.
+
+    Parameters
+    ----------
+    cfg : EnvConfig | dict
+        the reference's ``EnvironmentTest`` block (dict accepted verbatim).
+    batch : int
+        number of parallel envs B.
+    device : torch.device | str | int
+        a CUDA(HIP) device; CPU is rejected.
+    out_dtype : torch.float32 | torch.float64
+        element type of obs / reward / channel-obs outputs.  Arithmetic is
+        always float64 (like the reference); float32 is a final cast.
+    step_mode : "my_step" | "my_step_ch" | "my_step_design"
+        which reference step function ``step()`` stands for.
+    """
+
+    def __init__(self, cfg: Union[EnvConfig, Mapping[str, Any]], batch: int = 1,
+                 device: Union[str, int, torch.device] = "cuda:0",
+                 out_dtype: torch.dtype = torch.float32, step_mode: Union[str, int] = "my_step"):
+        if not isinstance(cfg, EnvConfig):
+            cfg = EnvConfig.from_dict(cfg)
+        cfg.validate()
+        if out_dtype not in (torch.float32, torch.float64):
+            raise ValueError("out_dtype must be float32 or float64")
+        if step_mode not in _MODES:
+            raise ValueError("unknown step_mode %r" % (step_mode,))
+        self.cfg = cfg
+        self.device = torch.device(device if not isinstance(device, int) else "cuda:%d" % device)
+        if self.device.type != "cuda":
+            raise DiralError(-5, "VecV2VEnv", "a HIP device is required; there is no CPU path")
+        if not torch.cuda.is_available():
+            raise DiralError(-5, "VecV2VEnv", "torch sees no GPU")
+        self.lib = _lib.load()
+        self.B = int(batch)
+        self.N = cfg.num_users
+        self.A = cfg.num_channels
+        self.S = cfg.state_space
+        self.out_dtype = out_dtype
+        self._dt = DT_F64 if out_dtype == torch.float64 else DT_F32
+        self.step_mode = _MODES[step_mode]
+        self._ccfg = cfg.to_c()
+        st = self.lib.diral_env_validate(ctypes.byref(self._ccfg))
+        if st != OK:
+            raise DiralError(st, "diral_env_validate")
+        self._h = ctypes.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        st = self.lib.diral_env_create(ctypes.byref(self._ccfg), self.B, dev_index, ctypes.byref(self._h))
+        if st != OK:
+            self._h = None
+            raise DiralError(st, "diral_env_create")
+        assert self.lib.diral_env_state_space(ctypes.byref(self._ccfg)) == self.S
+        # I/O tensors are allocated once; step() never allocates
+        with torch.cuda.device(self.device):
+            self._obs = torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device)
+            self._rew = torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device)
+            self._done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
+            self._chobs: Optional[torch.Tensor] = None
+        self.t = 0
+
+    # ---- lifetime -------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.diral_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers --------------------------------------------------------------
+    def _stream(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ok(self, st: int, where: str) -> None:
+        if st != OK:
+            detail = ""
+            if st == ERR_HIP:
+                detail = self.lib.diral_env_last_hip_error(self._h).decode()
+            raise DiralError(st, where, detail)
+
+    def _f64(self, a, shape) -> Optional[torch.Tensor]:
+        if a is None:
+            return None
+        t = torch.as_tensor(a, dtype=torch.float64, device=self.device)
+        return t.expand(shape).contiguous()
+
+    def _actions(self, actions) -> torch.Tensor:
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.int32:
+            a = a.to(torch.int32)
+        if a.dim() == 1:
+            a = a.unsqueeze(0).expand(self.B, self.N)
+        if tuple(a.shape) != (self.B, self.N):
+            raise ValueError("actions must have shape [B=%d, N=%d], got %s" % (self.B, self.N, tuple(a.shape)))
+        return a.contiguous()
+
+    def hbm_bytes(self) -> int:
+        return int(self.lib.diral_env_hbm_bytes(self._h))
+
+    # ---- reference getters (test_env.py:486-496) ----------------------------
+    def get_total_users(self) -> int:
+        return self.N
+
+    def get_num_ch(self) -> int:
+        return self.A
+
+    def get_state_space(self) -> int:
+        return self.S
+
+    def get_action_space(self) -> int:
+        return self.A
+
+    # ---- topology ---------------------------------------------------------------
+    def reset_topology(self, x0=None, y0=None, v0=None, seed: int = 0) -> None:
+        """New vehicles with zeroed tables: what constructing ``TestEnv`` does
+        (network.py:92-119) or ``reset_mobility_env`` (test_env.py:479-484)
+        when x0/y0/v0 are given."""
+        shape = (self.B, self.N)
+        x0, y0, v0 = self._f64(x0, shape), self._f64(y0, shape), self._f64(v0, shape)
+        self._keep = (x0, y0, v0)
+        self._ok(self.lib.diral_env_reset(self._h, _ptr(x0), _ptr(y0), _ptr(v0), int(seed) & (2**64 - 1),
+                                          self._stream()), "diral_env_reset")
+        self.t = 0
+
+    def reset(self, x0=None, y0=None, v0=None, seed: int = 0, actions=None) -> torch.Tensor:
+        """``reset() -> obs``.  The reference has no reset(); its driver
+        bootstraps with ``action = env.sample(); obs, rews = env.my_step(action, 0);
+        state = env.obtain_state(obs, action, rews)`` (main_test.py:89-94).
+        This does exactly that on a fresh topology and returns the state."""
+        self.reset_topology(x0, y0, v0, seed)
+        a = self.sample(seed=seed + 0x5EED) if actions is None else self._actions(actions)
+        obs, _, _ = self._step(STEP_MY_STEP, a, 0)
+        self.t = 0
+        return obs
+
+    def reset_mobility_env(self) -> None:
+        """test_env.py:479-484 -> network.py:81-90: the fixed 4-UE toy topology."""
+        if self.N != 4:
+            raise ConfigError("reset_mobility_env builds the fixed 4-UE topology (network.py:81-90)")
+        self.reset_topology([3., 5., 3., 5.], [1., 1., 2., 2.], [0.5, 1.0, 1.25, 1.5])
+
+    def reset_design_topology(self) -> None:
+        """network.py:69-79: six vehicles 195 m apart, v = 1.0."""
+        if self.N != 6:
+            raise ConfigError("the design topology has 6 vehicles (network.py:69-79)")
+        self.reset_topology([0., 195., 390., 585., 780., 975.], [1., 1., 2., 2., 2., 2.], [1.0] * 6)
+
+    # ---- stepping ---------------------------------------------------------------
+    def sample(self, seed: Optional[int] = None) -> torch.Tensor:
+        """test_env.py:116-122: uniform random actions, [B, N] int32."""
+        out = torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        self._ok(self.lib.diral_env_sample(self._h, _ptr(out), int(seed) & (2**64 - 1), self._stream()),
+                 "diral_env_sample")
+        return out
+
+    def _step(self, mode: int, actions: torch.Tensor, t: int, episode: float = 0.0, eps: float = 1.0,
+              want_chobs: bool = False, want_obs: bool = True):
+        if want_chobs and self._chobs is None:
+            self._chobs = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+        st = self.lib.diral_env_step(self._h, mode, _ptr(actions), int(t),
+                                     _ptr(self._obs) if (want_obs and self.S > 0) else None,
+                                     _ptr(self._rew), _ptr(self._done),
+                                     _ptr(self._chobs) if want_chobs else None,
+                                     self._dt, float(episode), float(eps), self._stream())
+        self._ok(st, "diral_env_step")
+        return self._obs, self._rew, self._done
+
+    def step(self, actions, t: Optional[int] = None, episode: float = 0.0, epsilon: float = 1.0
+             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """``step(actions[B,N]) -> (obs[B,N,S], reward[B,N], done[B])``.
+
+        One fused launch = the reference's per-slot pair
+        ``obs, reward = env.my_step(action, t)`` +
+        ``env.obtain_state(obs, action, reward, episode, eps)``
+        (main_test.py:144-164).  ``done`` is the driver's episode boundary
+        ``t % episode_interval == episode_interval-1`` (main_test.py:226); state is
+        kept across it (continuing task).  The returned tensors are owned by the
+        env and overwritten by the next call; enqueue-only, no host sync."""
+        a = self._actions(actions)
+        if t is None:
+            t = self.t
+        out = self._step(self.step_mode, a, t, episode, epsilon)
+        self.t = int(t) + 1
+        return out
+
+    # reference-named batched variants: return (chobs[B,N,A], rews[B,N]) like
+    # `obs, rews = env.my_step(actions, timestep)` and leave the state vector
+    # to obtain_state(), so a main_test-style loop reads the same.
+    def my_step(self, actions, timestep: int = 0):
+        a = self._actions(actions)
+        self._last_actions = a
+        self._step(STEP_MY_STEP, a, timestep, want_chobs=True, want_obs=False)
+        return self._chobs, self._rew
+
+    def my_step_ch(self, actions, time_step: int = 0):
+        a = self._actions(actions)
+        self._last_actions = a
+        self._step(STEP_MY_STEP_CH, a, time_step, want_chobs=True, want_obs=False)
+        return self._chobs, self._rew
+
+    def my_step_design(self, actions, timestep: int = 0):
+        a = self._actions(actions)
+        self._last_actions = a
+        self._step(STEP_DESIGN, a, timestep, want_chobs=True, want_obs=False)
+        return self._chobs, self._rew
+
+    def obtain_state(self, obs, acts, rewards, episode_number: float = 0, epsilon: float = 1) -> torch.Tensor:
+        """test_env.py:527-583 on the current tables/positions; [B, N, S]."""
+        a = self._actions(acts)
+        chobs = None if obs is None else self._f64(obs, (self.B, self.N, self.A))
+        rew = None if rewards is None else self._f64(rewards, (self.B, self.N))
+        st = self.lib.diral_env_observe(self._h, _ptr(a), _ptr(chobs), _ptr(rew), _ptr(self._obs), self._dt,
+                                        float(episode_number), float(epsilon), self._stream())
+        self._ok(st, "diral_env_observe")
+        return self._obs
+
+    def update_velocity(self, draws=None, seed: Optional[int] = None) -> None:
+        """test_env.py:498-504 -> network.py:208-223 (no-op unless mobility_vary)."""
+        d = None
+        if draws is not None:
+            d = torch.as_tensor(draws, dtype=torch.uint8, device=self.device).expand(self.B, self.N).contiguous()
+        if seed is None:
+            seed = self.t * 2654435761 + 12345
+        self._ok(self.lib.diral_env_update_velocity(self._h, _ptr(d), int(seed) & (2**64 - 1), self._stream()),
+                 "diral_env_update_velocity")
+
+    # ---- state access ---------------------------------------------------------
+    def get_x_pos(self) -> torch.Tensor:
+        """test_env.py:471-476, [B, N] float64."""
+        return self.export_state(tables=False)["pos_x"]
+
+    def export_state(self, tables: bool = True) -> Dict[str, torch.Tensor]:
+        B, N = self.B, self.N
+        f = dict(dtype=torch.float64, device=self.device)
+        i = dict(dtype=torch.int32, device=self.device)
+        out = dict(pos_x=torch.empty((B, N), **f), pos_y=torch.empty((B, N), **f), vel=torch.empty((B, N), **f))
+        seq = age = x = y = la = None
+        if tables:
+            seq, age = torch.empty((B, N, N), **i), torch.empty((B, N, N), **i)
+            x, y = torch.empty((B, N, N), **f), torch.empty((B, N, N), **f)
+            out.update(seq=seq, age=age, x=x, y=y)
+            if self.cfg.track_arrival:
+                la = torch.empty((B, N, N), **i)
+                out["la"] = la
+        self._ok(self.lib.diral_env_export_state(self._h, _ptr(out["pos_x"]), _ptr(out["pos_y"]), _ptr(out["vel"]),
+                                                 _ptr(seq), _ptr(age), _ptr(x), _ptr(y), _ptr(la), self._stream()),
+                 "diral_env_export_state")
+        return out
+
+    def import_state(self, pos_x=None, pos_y=None, vel=None, seq=None, age=None, x=None, la=None) -> None:
+        B, N = self.B, self.N
+        def ti(a):
+            return None if a is None else torch.as_tensor(a, dtype=torch.int32, device=self.device).expand(B, N, N).contiguous()
+        px, py, v = self._f64(pos_x, (B, N)), self._f64(pos_y, (B, N)), self._f64(vel, (B, N))
+        s, a, xx, l = ti(seq), ti(age), self._f64(x, (B, N, N)), ti(la)
+        self._ok(self.lib.diral_env_import_state(self._h, _ptr(px), _ptr(py), _ptr(v), _ptr(s), _ptr(a), _ptr(xx),
+                                                 _ptr(l), self._stream()), "diral_env_import_state")
+        torch.cuda.current_stream(self.device).synchronize()   # inputs may be temporaries
+
+    def info_age(self, t: int) -> torch.Tensor:
+        """network.py:560-574 (`env.network.get_information_age(t)`), [B, 100] int32."""
+        out = torch.empty((self.B, 100), dtype=torch.int32, device=self.device)
+        self._ok(self.lib.diral_env_info_age(self._h, int(t), _ptr(out), self._stream()), "diral_env_info_age")
+        return out
+
+    def metrics(self, clear: bool = False) -> torch.Tensor:
+        """[B, 6] float64: slots, sum reward, sole tx, collided tx, PRR sum, PRR count."""
+        out = torch.empty((self.B, M_COLUMNS), dtype=torch.float64, device=self.device)
+        self._ok(self.lib.diral_env_metrics(self._h, _ptr(out), int(clear), self._stream()), "diral_env_metrics")
+        return out
+
+    def check(self) -> None:
+        """Raise if a kernel flagged an out-of-range action or a sequence
+        overflow since the last check (synchronises the stream)."""
+        self._ok(self.lib.diral_env_check(self._h, self._stream()), "diral_env_check")

@@ -1,0 +1,351 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the reference goldens and
+vs the CPU oracle, on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact for collision / indexing work
+(collision counts, rewards of the integer-valued designs, one-hot, histogram
+bins, sequence numbers, ages, arrival stamps, information-age histogram) and for
+positions; distances within 1 ulp of the reference (the reference's `**2` is
+libm pow(), the kernel uses the correctly rounded x*x - DESIGN.md), exp()-based
+rewards within 2e-15 absolute (1-2 ulp of exp itself).  Against the oracle in its IEEE-square mode everything
+except exp() is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from diral_amd.config import (EnvConfig, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, bench_config,
+                              c2_config)
+from tests.golden_util import Golden, golden_names, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+EXP_ATOL = 2e-15   # device exp() vs glibc exp(): <= 1-2 ulp of exp(x) <= e; the rewards built
+                   # from it (1-exp(1-R), test_env.py:414) cancel, so the bound is absolute
+DIST_ULP = 1       # sqrt(x*x+y*y) vs sqrt(pow(x,2)+pow(y,2))
+
+UNBUILT = {"g1_posdist_full", "g1_posdist_type1"}   # secondary obs modes, SURVEY a15/a16 (next rows)
+
+
+def make_env(cfg, B, mode=STEP_MY_STEP, dtype=torch.float64):
+    from diral_amd.vec_env import VecV2VEnv
+    return VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=dtype, step_mode=mode)
+
+
+def gpu_step(env, mode, acts, t, ep=0.0, eps=1.0):
+    a = env._actions(np.asarray(acts))
+    obs, rew, done = env._step(mode, a, t, ep, eps, want_chobs=True)
+    torch.cuda.synchronize()
+    return obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), env._chobs.cpu().numpy().copy(), \
+        done.cpu().numpy().copy()
+
+
+def uses_exp(cfg, mode):
+    return cfg.reward_design in (3, 4)
+
+
+def exp_close(a, b):
+    return bool(np.all(np.abs(np.asarray(a) - np.asarray(b)) <= EXP_ATOL))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n not in UNBUILT])
+def test_golden_replay_on_gpu(name):
+    """Every reference fixture replayed through libdiral_env.so (B=3 replicas)."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    g = Golden(name)
+    B = 3
+    env = make_env(g.cfg, B)
+    env.reset_topology(g["x0"], g["y0"], g["v0"])
+    orc = Oracle(g.cfg, batch=1, sq_mode=SQ_IEEE)
+    orc.reset(g["x0"], g["y0"], g["v0"])
+    ck = g.table_checkpoints()
+    S = env.S
+    cfg = g.cfg
+    for i, mode, acts, t, (ep, eps) in g.steps():
+        obs, rew, chobs, done = gpu_step(env, mode, acts, t, ep, eps)
+        o_rew, o_chobs = orc.step(mode, acts, t)
+        o_state = orc.obtain_state(acts, o_chobs, o_rew, ep, eps)
+        for b in range(B):
+            # --- vs the oracle (IEEE squares): bit-exact except exp() rewards
+            if uses_exp(cfg, mode):
+                assert exp_close(rew[b], o_rew[0]), (name, i)
+            else:
+                assert np.array_equal(rew[b], o_rew[0]), (name, i, rew[b], o_rew[0])
+            assert np.array_equal(chobs[b], o_chobs[0]), (name, i)
+            if cfg.State.add_reward and uses_exp(cfg, mode):
+                assert exp_close(obs[b], o_state[0])
+            else:
+                assert np.array_equal(obs[b], o_state[0]), (name, i, np.argwhere(obs[b] != o_state[0])[:5])
+            # --- vs the reference fixture
+            ref_rew, ref_chobs, ref_state = g["rews"][i], g["chobs"][i], g["state"][i]
+            assert exp_close(rew[b], ref_rew) if uses_exp(cfg, mode) else np.array_equal(rew[b], ref_rew), (name, i)
+            assert ulp_diff(chobs[b], ref_chobs) <= DIST_ULP, (name, i)
+            assert ulp_diff(obs[b], ref_state) <= DIST_ULP or (cfg.State.add_reward and exp_close(obs[b], ref_state)), (name, i)
+            if cfg.State.add_positional_dist_piggy:
+                K = cfg.State.num_bins
+                off = (cfg.num_channels if cfg.State.action_index == "binary" else 1) if cfg.State.add_action else 0
+                off += cfg.num_channels if cfg.State.add_channel_obs else 0
+                assert np.array_equal(obs[b][:, off:off + K], ref_state[:, off:off + K]), "histogram bins"
+            assert done[b] == ((t % cfg.episode_interval) == cfg.episode_interval - 1)
+        if i in g.vel_updates:
+            env.update_velocity(g.vel_updates[i])
+            orc.update_velocity(g.vel_updates[i])
+        ia = env.info_age(t).cpu().numpy()
+        st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        oe = orc.export()
+        for b in range(B):
+            assert np.array_equal(st["pos_x"][b], g["pos_x"][i]), (name, i)
+            assert np.array_equal(st["vel"][b], g["vel"][i]), (name, i)
+            assert np.array_equal(ia[b], g["ia"][i]), (name, i)
+            assert np.array_equal(st["seq"][b], oe["seq"][0]), (name, i)
+            assert np.array_equal(st["age"][b], np.minimum(oe["age"][0], 255)), (name, i)
+            assert np.array_equal(st["x"][b], oe["x"][0]), (name, i)
+            assert np.array_equal(st["y"][b], oe["y"][0]), (name, i)
+            assert np.array_equal(st["la"][b].astype(np.int64), oe["la"][0]), (name, i)
+            if i in ck:
+                j = ck[i]
+                assert np.array_equal(st["seq"][b], g["tab_seq"][j])
+                assert np.array_equal(st["age"][b], np.minimum(g["tab_age"][j], 255))
+                assert np.array_equal(st["x"][b], g["tab_x"][j])
+                assert np.array_equal(st["y"][b], g["tab_y"][j])
+                assert np.array_equal(st["la"][b], g["tab_la"][j])
+    env.check()
+
+
+def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8):
+    """GPU vs oracle (IEEE squares) on B different random envs, T slots; returns
+    the number of compared slots.  Everything must match bit for bit (exp()
+    rewards within EXP_ATOL)."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    rng = np.random.default_rng(seed)
+    N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
+    cfg = cfg.replace(track_arrival=True, track_prr=True)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    y0 = np.zeros((B, N))
+    v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
+    env = make_env(cfg, B)
+    env.reset_topology(x0, y0, v0)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=threads)
+    orc.reset(x0, y0, v0)
+    acts = rng.integers(0, A, size=(B, N))
+    for t in range(T):
+        new = rng.integers(0, A, size=(B, N))
+        acts = np.where(rng.random((B, N)) < sticky, acts, new).astype(np.int32)
+        obs, rew, chobs, _ = gpu_step(env, mode, acts, t)
+        o_rew, o_chobs = orc.step(mode, acts, t)
+        o_state = orc.obtain_state(acts, o_chobs, o_rew)
+        if uses_exp(cfg, mode):
+            assert exp_close(rew, o_rew)
+        else:
+            assert np.array_equal(rew, o_rew), t
+        assert np.array_equal(chobs, o_chobs), t
+        assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
+        if vel_every and t % vel_every == vel_every - 1:
+            draws = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
+            env.update_velocity(draws)
+            orc.update_velocity(draws)
+    st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    oe = orc.export()
+    assert np.array_equal(st["pos_x"], oe["pos_x"])
+    assert np.array_equal(st["vel"], oe["vel"])
+    assert np.array_equal(st["seq"], oe["seq"])
+    assert np.array_equal(st["age"], np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"], oe["x"])
+    assert np.array_equal(st["y"], oe["y"])
+    assert np.array_equal(st["la"].astype(np.int64), oe["la"])
+    assert np.array_equal(env.info_age(T - 1).cpu().numpy(), orc.info_age(T - 1))
+    m, om = env.metrics().cpu().numpy(), orc.metrics()
+    assert np.array_equal(m[:, [0, 2, 3, 5]], om[:, [0, 2, 3, 5]])          # counts: exact
+    assert np.allclose(m[:, [1, 4]], om[:, [1, 4]], rtol=1e-12, atol=1e-9)  # float sums: order differs
+    # PRR parity (north_star: within 1e-6)
+    prr = m[:, 4] / np.maximum(m[:, 5], 1)
+    oprr = om[:, 4] / np.maximum(om[:, 5], 1)
+    assert np.max(np.abs(prr - oprr)) < 1e-6
+    env.check()
+    return T
+
+
+def test_c2_random_vs_oracle():
+    random_rollout(c2_config(), B=96, T=70, seed=1)
+
+
+def test_c2_ch_mode_vs_oracle():
+    random_rollout(c2_config(reward_design=3), B=48, T=40, seed=2, mode=STEP_MY_STEP_CH, sticky=0.6)
+
+
+def test_c2_design_mode_vs_oracle():
+    random_rollout(c2_config(), B=32, T=30, seed=3, mode=STEP_DESIGN)
+
+
+def test_c2_channel_obs_and_flags_vs_oracle():
+    cfg = c2_config(reward_design=1, enable_fingerprint=False,
+                    State=dict(add_channel_obs=True, add_reward=True, add_index=True, add_velocity=True,
+                               add_position=True))
+    random_rollout(cfg, B=24, T=30, seed=4, sticky=0.8)
+
+
+def test_c3_congested_vs_oracle():
+    random_rollout(bench_config(256, 64, 4000.0), B=6, T=26, seed=5)
+
+
+def test_c5_dynamic_density_vs_oracle():
+    random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True), B=10, T=55, seed=6, vel_every=25)
+
+
+@pytest.mark.parametrize("N,A,L", [(1, 1, 50.0), (2, 5, 100.0), (63, 7, 900.0), (65, 3, 900.0),
+                                   (129, 40, 3000.0), (200, 13, 3000.0), (256, 128, 5000.0)])
+def test_ragged_sizes_vs_oracle(N, A, L):
+    random_rollout(bench_config(N, A, L, communication_range=180.0), B=4, T=24, seed=100 + N)
+
+
+def test_rd5_and_proportional_fair_vs_oracle():
+    random_rollout(c2_config(reward_design=5, proportional_fair=True), B=16, T=40, seed=7, sticky=0.95)
+
+
+def test_f32_output_is_cast_of_f64():
+    cfg = c2_config(State=dict(add_channel_obs=True))
+    rng = np.random.default_rng(9)
+    B = 8
+    x0 = rng.integers(0, 2000, size=(B, 64)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, 64))
+    e64, e32 = make_env(cfg, B, dtype=torch.float64), make_env(cfg, B, dtype=torch.float32)
+    e64.reset_topology(x0, 0.0, v0)
+    e32.reset_topology(x0, 0.0, v0)
+    for t in range(25):
+        a = rng.integers(0, 32, size=(B, 64)).astype(np.int32)
+        o64, r64, _ = e64.step(a, t)
+        o32, r32, _ = e32.step(a, t)
+        torch.cuda.synchronize()
+        assert torch.equal(o64.to(torch.float32), o32)
+        assert torch.equal(r64.to(torch.float32), r32)
+
+
+def test_observe_equals_fused_step_observation():
+    cfg = c2_config(State=dict(add_channel_obs=True, add_reward=True))
+    rng = np.random.default_rng(10)
+    B = 5
+    env = make_env(cfg, B)
+    env.reset_topology(rng.integers(0, 2000, size=(B, 64)).astype(np.float64), 0.0,
+                       rng.uniform(1.1, 2.7, size=(B, 64)))
+    for t in range(30):
+        a = rng.integers(0, 32, size=(B, 64)).astype(np.int32)
+        obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, a, t)
+        again = env.obtain_state(chobs, a, rew).cpu().numpy()
+        assert np.array_equal(obs, again)
+
+
+def test_reference_named_two_call_sequence():
+    """`obs, rews = env.my_step(a, t); state = env.obtain_state(obs, a, rews)`
+    (main_test.py:144-164) gives the same state as the fused step()."""
+    cfg = c2_config()
+    rng = np.random.default_rng(11)
+    B = 4
+    x0 = rng.integers(0, 2000, size=(B, 64)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, 64))
+    fused, split = make_env(cfg, B), make_env(cfg, B)
+    fused.reset_topology(x0, 0.0, v0)
+    split.reset_topology(x0, 0.0, v0)
+    for t in range(22):
+        a = rng.integers(0, 32, size=(B, 64)).astype(np.int32)
+        o1, r1, _ = fused.step(a, t)
+        chobs, rews = split.my_step(a, t)
+        o2 = split.obtain_state(chobs, a, rews)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2)
+        assert torch.equal(r1, rews)
+
+
+def test_bad_action_is_flagged():
+    from diral_amd.vec_env import DiralError
+    env = make_env(c2_config(), 2)
+    env.reset_topology(seed=3)
+    a = np.zeros((2, 64), np.int32)
+    a[1, 5] = 32
+    env.step(a, 0)
+    with pytest.raises(DiralError) as ei:
+        env.check()
+    assert ei.value.status == -6
+    env.step(np.zeros((2, 64), np.int32), 1)
+    env.check()
+
+
+def test_device_topology_draws_follow_reference_distribution():
+    """network.py:103-110: x integer in [0,L), y = 0, v in [1.1,2.7) (1.7 if vary)."""
+    env = make_env(c2_config(), 512)
+    env.reset_topology(seed=42)
+    st = env.export_state(tables=False)
+    x, y, v = st["pos_x"], st["pos_y"], st["vel"]
+    assert torch.all(x == torch.floor(x)) and x.min() >= 0 and x.max() < 2000
+    assert torch.all(y == 0)
+    assert v.min() >= 1.1 and v.max() < 2.7 and abs(v.mean().item() - 1.9) < 0.02
+    assert abs(x.mean().item() - 999.5) < 15
+    a = env.sample(seed=1)
+    assert a.min() >= 0 and a.max() < 32
+    cnt = torch.bincount(a.flatten().long(), minlength=32).double()
+    assert (cnt / cnt.sum() - 1 / 32).abs().max() < 0.01
+    env2 = make_env(c2_config(mobility_vary=True), 4)
+    env2.reset_topology(seed=1)
+    assert torch.all(env2.export_state(tables=False)["vel"] == 1.7)
+
+
+def test_full_size_c2_properties_and_sampled_oracle():
+    """BASELINE configs[1] at full size: B=4096 x 64 UE x 32 res.  Size-
+    independent properties on every env + bit-exact oracle check on a sample."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = c2_config()
+    B, N, A, K = 4096, 64, 32, 20
+    rng = np.random.default_rng(77)
+    x0 = rng.integers(0, 2000, size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    env = make_env(cfg, B)
+    env.reset_topology(x0, 0.0, v0)
+    sample = np.sort(rng.choice(B, size=48, replace=False))
+    orc = Oracle(cfg, batch=len(sample), sq_mode=SQ_IEEE, threads=8)
+    orc.reset(x0[sample], np.zeros((len(sample), N)), v0[sample])
+    T = 30
+    for t in range(T):
+        acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, done = env.step(acts, t)
+        torch.cuda.synchronize()
+        a_t = torch.as_tensor(acts, device="cuda").long()
+        # (1) one-hot section == actions
+        assert torch.equal(obs[..., :A].argmax(-1), a_t) and torch.all(obs[..., :A].sum(-1) == 1)
+        # (2) histogram rows sum to 1 (or are all zero)
+        hs = obs[..., A:].sum(-1)
+        assert torch.all(((hs - 1).abs() < 1e-12) | (hs == 0))
+        # (3) rewards against collision counts recomputed in torch (reward_design 2)
+        cnt = torch.zeros((B, A), dtype=torch.long, device="cuda").scatter_add_(1, a_t, torch.ones_like(a_t))
+        c = cnt.gather(1, a_t)
+        assert torch.all(rew[c == 1] == 1)
+        assert torch.all(rew[c > 2] == -c[c > 2].double())
+        assert torch.all((rew[c == 2] == 0) | (rew[c == 2] == -2))
+        # (4) sampled envs bit-exact vs the oracle
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, acts[sample], t)
+        o_state = orc.obtain_state(acts[sample], o_chobs, o_rew)
+        assert np.array_equal(obs[sample].cpu().numpy(), o_state), t
+        assert np.array_equal(rew[sample].cpu().numpy(), o_rew), t
+    # (5) positions stay in [0, L) and sequence numbers equal the slot count on the diagonal
+    st = env.export_state()
+    assert st["pos_x"].min() >= 0 and st["pos_x"].max() < 2000
+    diag = torch.diagonal(st["seq"], dim1=1, dim2=2)
+    assert torch.all(diag == T)
+    assert torch.all(st["seq"] <= T)
+    env.check()
+
+
+def test_replica_envs_are_identical_at_scale():
+    """Idempotence across the batch: 2048 copies of one env stay identical."""
+    cfg = bench_config(128, 64, 4000.0)
+    B, N, A = 2048, 128, 64
+    rng = np.random.default_rng(5)
+    x0 = rng.integers(0, 4000, size=N).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=N)
+    env = make_env(cfg, B, dtype=torch.float32)
+    env.reset_topology(x0, 0.0, v0)
+    for t in range(12):
+        a = rng.integers(0, A, size=N).astype(np.int32)
+        obs, rew, _ = env.step(a, t)
+    torch.cuda.synchronize()
+    assert torch.all(obs == obs[0:1]) and torch.all(rew == rew[0:1])
+    st = env.export_state()
+    for k in ("seq", "age", "x"):
+        assert torch.all(st[k] == st[k][0:1])
