@@ -12,7 +12,7 @@ import os
 from .config import DiralCfg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdiral_env.so")
+LIB_PATH = os.environ.get("DIRAL_LIB") or os.path.join(HERE, "libdiral_env.so")   # DIRAL_LIB: tuning variants
 
 # every symbol include/diral_env.h declares
 SYMBOLS = [
@@ -34,6 +34,11 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE
+    # libdiral_env.so is dlopen'ed so both bind to the SAME HIP runtime (same
+    # SONAME -> the loader reuses it).  Loading ours first would pull in
+    # /opt/rocm's copy and torch's device pointers would belong to another runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DiralLibraryError(
             "%s is missing - build it with `python -m diral_amd.build` (hipcc, gfx950). "

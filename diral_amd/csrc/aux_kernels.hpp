@@ -117,6 +117,11 @@ __global__ void info_age_kernel(int N, long long t, const int32_t* la, int32_t* 
   for (int j = threadIdx.x; j < 100; j += blockDim.x) out[(size_t)b * 100 + j] = bins[j];
 }
 
+__global__ void any_nonzero_kernel(int total, const double* v, uint32_t* flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total && v[i] != 0.0) atomicOr(flag, 1u);
+}
+
 __global__ void metrics_kernel(int total, double* metrics, double* out, int clear) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;

@@ -35,7 +35,7 @@ struct StepParams {
   int reward_design, state_type;
   int age_limit, pf_threshold;
   double pf_penalty;
-  double L, H, Rc, Rb, hist_denom;
+  double L, H, Rc, Rb, hist_inv_width;   // K / (Rb - (-Rb)): bin-index estimate only
   long long t;
   double episode, eps;
   int out_f64;
@@ -61,6 +61,7 @@ struct StepParams {
   void* chobs_out;
   const double* chobs_in;
   const double* rew_in;
+  unsigned long long* dbg;   // phase timestamps (DIRAL_TIMING builds only)
 };
 
 // LDS carve of the fused step kernel; byte offsets, doubles first.
@@ -85,7 +86,7 @@ __host__ __device__ inline LdsLayout lds_layout(int npad, int A, int K, int vpl,
   l.mask = o;  o += 8u * A * vpl;
   l.act = o;   o += 4u * npad;
   l.inr = o;   o += 4u * npad;
-  l.hist = o;  o += 4u * K * npad;
+  l.hist = o;  o += 4u * (K | 1) * npad;   // [viewer][K|1]: odd row stride
   l.cnt = o;   o += 4u * npad;
   l.mtab = o;  o += align_up((uint32_t)A * npad, 16);
   l.scratch = o;

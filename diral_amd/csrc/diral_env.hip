@@ -13,6 +13,7 @@
 #include "aux_kernels.hpp"
 #include "common.hpp"
 #include "step_kernel.hpp"
+#include "step_fast64.hpp"
 
 using namespace diral;
 
@@ -33,6 +34,9 @@ struct DiralEnv {
   uint32_t* err = nullptr;
   double* edges = nullptr;
   int64_t hbm_bytes = 0;
+  bool flat_y = true;      // every pos_y == 0 (random topologies, network.py:104): |dx| distance path
+  uint32_t* yflag = nullptr;
+  unsigned long long* dbg = nullptr;   // DIRAL_TIMING builds: [B][waves][8] timestamps
   std::string last_hip_error;
 };
 
@@ -94,27 +98,67 @@ Offsets state_offsets(const DiralCfg* c) {
 
 int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
 
-template <int VPL>
+template <int VPL, bool FAST>
 hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
-  hipLaunchKernelGGL(step_kernel<VPL>, dim3(p.B), dim3(Geo<VPL>::THREADS), lds, s, p);
+  hipLaunchKernelGGL((step_kernel<VPL, FAST>), dim3(p.B), dim3(Geo<VPL>::THREADS), lds, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s) {
+// FAST instantiation = the metric's configuration (see step_kernel.hpp): the
+// toy YAML's State flags, my_step, f32 outputs, no optional side outputs.
+bool is_fast(const StepParams& p) {
+  const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
+  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
+  return (p.flags & ~ignore) == want && p.mode == DIRAL_STEP_MY_STEP && !p.out_f64 &&
+         p.state_out != nullptr && p.chobs_out == nullptr;
+}
+
+hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
+  const bool fast = is_fast(p);
+  if (fast && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64")) {
+    FastParams f;
+    f.N = p.N; f.A = p.A; f.K = p.K; f.NV = p.NV; f.flags = p.flags;
+    f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
+    f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
+    f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
+    f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
+    f.state_out = reinterpret_cast<float*>(p.state_out); f.rew_out = reinterpret_cast<float*>(p.rew_out);
+    f.done_out = p.done_out; f.dbg = p.dbg;
+    const uint32_t fl = fast_lds_layout(p.K).total;
+    if (flat_y) hipLaunchKernelGGL(step_fast64_kernel<true>, dim3(p.B), dim3(256), fl, s, f);
+    else hipLaunchKernelGGL(step_fast64_kernel<false>, dim3(p.B), dim3(256), fl, s, f);
+    return hipGetLastError();
+  }
   switch (vpl) {
-    case 1: return launch_step<1>(p, lds, s);
-    case 2: return launch_step<2>(p, lds, s);
-    default: return launch_step<4>(p, lds, s);
+    case 1: return fast ? launch_step<1, true>(p, lds, s) : launch_step<1, false>(p, lds, s);
+    case 2: return fast ? launch_step<2, true>(p, lds, s) : launch_step<2, false>(p, lds, s);
+    default: return fast ? launch_step<4, true>(p, lds, s) : launch_step<4, false>(p, lds, s);
   }
 }
 
 template <int VPL>
 hipError_t set_lds_attr(uint32_t lds) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL>),
+  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (r != hipSuccess) return r;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
+
+// Recompute DiralEnv::flat_y (all pos_y == 0) after pos_y was written by the
+// caller.  Synchronises the stream; only reset/import call it, never step.
+int refresh_flat_y(DiralEnv* e, hipStream_t s) {
+  const size_t bn = (size_t)e->B * e->N;
+  if (hipMemsetAsync(e->yflag, 0, 4, s) != hipSuccess) return DIRAL_ERR_HIP;
+  hipLaunchKernelGGL(any_nonzero_kernel, dim3(blocks(bn, 256)), dim3(256), 0, s, (int)bn, e->pos_y, e->yflag);
+  uint32_t f = 1;
+  if (hipMemcpyAsync(&f, e->yflag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return DIRAL_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) return DIRAL_ERR_HIP;
+  e->flat_y = (f == 0);
+  return DIRAL_OK;
+}
 
 }  // namespace
 
@@ -198,7 +242,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   e->cfg = *cfg;
   e->B = batch; e->N = cfg->num_users; e->A = cfg->num_channels;
   e->K = cfg->num_bins > 0 ? cfg->num_bins : 1;
-  e->NV = (int)align_up((uint32_t)e->N, 16);
+  e->NV = e->N <= 64 ? 64 : (int)align_up((uint32_t)e->N, 16);   // one wave lane per viewer, no lane predicate
   e->vpl = vpl_for(e->N);
   e->device = device;
   const Offsets off = state_offsets(cfg);
@@ -223,12 +267,15 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->tx, tab * 8));
   CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(alloc((void**)&e->err, 4));
+  CREATE_TRY(alloc((void**)&e->yflag, 4));
   CREATE_TRY(alloc((void**)&e->edges, (size_t)(e->K + 1) * 8));
   if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
   if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
 
   std::vector<double> edges;
   np_linspace(-cfg->bin_range, cfg->bin_range, e->K + 1, edges);
+  for (int i = 0; i < e->K; ++i)   // np.histogram: "Too many bins for data range"
+    if (!(edges[i] < edges[i + 1])) return fail(DIRAL_ERR_BAD_CONFIG);
   CREATE_TRY(hipMemcpy(e->edges, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
@@ -255,11 +302,15 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   p.age_limit = cfg->info_age_limit; p.pf_threshold = cfg->pf_threshold; p.pf_penalty = cfg->pf_penalty;
   p.L = cfg->highway_length; p.H = cfg->highway_height; p.Rc = cfg->communication_range;
   p.Rb = cfg->bin_range;
-  { volatile double d = cfg->bin_range - (-cfg->bin_range); p.hist_denom = d; }
+  p.hist_inv_width = (double)e->K / (cfg->bin_range - (-cfg->bin_range));
   p.episode_interval = cfg->episode_interval;
   p.off_act = off.act; p.off_chobs = off.chobs; p.off_posdist = off.posdist; p.off_hist = off.hist;
   p.off_rew = off.rew; p.off_idx = off.idx; p.off_pos = off.pos; p.off_vel = off.vel; p.off_fp = off.fp;
   p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel = e->vel; p.tkey = e->tkey; p.tx = e->tx;
+#ifdef DIRAL_TIMING
+  if (hipMalloc((void**)&e->dbg, (size_t)e->B * 16 * 8 * 8) == hipSuccess) (void)hipMemset(e->dbg, 0, (size_t)e->B * 16 * 8 * 8);
+#endif
+  p.dbg = e->dbg;
   p.la = e->la; p.pf = e->pf; p.metrics = e->metrics; p.err = e->err; p.edges = e->edges;
   *out = e;
   return DIRAL_OK;
@@ -268,7 +319,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   (void)hipSetDevice(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges};
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->yflag,
+                  e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
   return DIRAL_OK;
@@ -292,6 +344,8 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   hipLaunchKernelGGL(reset_kernel, dim3(blocks(bn, 256)), dim3(256), 0, s, (int)bn, e->cfg.highway_length,
                      has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0, seed, x0, y0, v0, e->pos_x, e->pos_y, e->vel);
   HIP_TRY(e, hipGetLastError());
+  if (y0) { if (refresh_flat_y(e, s) != DIRAL_OK) return DIRAL_ERR_HIP; }
+  else e->flat_y = true;
   return DIRAL_OK;
 }
 
@@ -311,7 +365,7 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   p.state_out = e->S > 0 ? state_out : nullptr;
   p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
   p.chobs_in = nullptr; p.rew_in = nullptr;
-  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream));
+  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
   return DIRAL_OK;
 }
 
@@ -325,7 +379,7 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   p.actions = actions; p.state_out = state_out;
   p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
   p.chobs_in = chobs_in; p.rew_in = rew_in;
-  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream));
+  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
   return DIRAL_OK;
 }
 
@@ -384,7 +438,10 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   if (pos_x) HIP_TRY(e, hipMemcpyAsync(e->pos_x, pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
-  if (pos_y) HIP_TRY(e, hipMemcpyAsync(e->pos_y, pos_y, bn * 8, hipMemcpyDeviceToDevice, s));
+  if (pos_y) {
+    HIP_TRY(e, hipMemcpyAsync(e->pos_y, pos_y, bn * 8, hipMemcpyDeviceToDevice, s));
+    if (refresh_flat_y(e, s) != DIRAL_OK) return DIRAL_ERR_HIP;
+  }
   if (vel) HIP_TRY(e, hipMemcpyAsync(e->vel, vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x) {
     const size_t total = bn * e->N;
@@ -405,6 +462,15 @@ int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
   hipLaunchKernelGGL(metrics_kernel, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total, e->metrics,
                      out, clear);
   HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+// DIRAL_TIMING builds only (not part of the ABI header): copy the phase
+// timestamps [B][waves][8] to a host buffer.
+int diral_env_debug_timing(DiralEnv* e, unsigned long long* host_out, int waves) {
+  if (!e || !e->dbg || !host_out) return DIRAL_ERR_BAD_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return DIRAL_ERR_HIP;
+  if (hipMemcpy(host_out, e->dbg, (size_t)e->B * waves * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return DIRAL_ERR_HIP;
   return DIRAL_OK;
 }
 

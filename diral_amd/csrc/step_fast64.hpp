@@ -1,0 +1,404 @@
+// step_fast64.hpp - the fused env-step kernel specialised for the headline
+// configuration: N <= 64 vehicles (one wavefront lane per vehicle), A <= 32
+// resources, the toy YAML's State flags (one-hot action + type-2 piggybacked
+// positional histogram), my_step + obtain_state, float32 outputs.
+//
+// Same semantics as step_kernel.hpp (which stays the general path and is what
+// the parity tests compare this kernel against, bit for bit); what changes is
+// the schedule.  Profiling on MI355X (profiles/) showed the general kernel
+//   - LATENCY-bound on LDS round trips (63 % of wave cycles waiting),
+//   - then instruction-ISSUE-bound (~7000 instructions per wave, 16 waves per
+//     SIMD per launch), with ~90 KB of inlined rare-path code (sqrt/exp/fmod),
+//   - with the gossip merge sitting on the CU-shared LDS pipe (a
+//     ds_bpermute_b32 costs ~5.5 LDS cycles; one env-slot needs ~1800).
+// So here:
+//   * closest-transmitter search without LDS: lane = vehicle, a transmitter's
+//     position is broadcast with v_readlane; each wave owns the resources
+//     i == wave (mod 4) and walks their transmitters in ascending id with a
+//     strict '<' (the reference's lowest-id tie-break, network.py:387-392);
+//   * gossip merge key[u] = max(key[u], key[m_i(u)]): one ds_bpermute + v_max
+//     per (resource, column); optionally (DIRAL_MERGE_BPERM < 16) part of the
+//     columns go through v_readlane + masked v_max on the VALU instead;
+//   * a compact parameter block (no SGPR spills), 32-bit table offsets, padded
+//     viewer stride (NV = 64) so table loads/stores need no lane predicate;
+//   * when every vehicle has y == 0 (any random topology, network.py:104) the
+//     distance is |dx| exactly and the dy logic is compiled out (FLAT);
+//   * branch-free histogram bin search; rare paths out of line.
+#pragma once
+#include "common.hpp"
+#include "step_kernel.hpp"
+
+namespace diral {
+
+#ifndef DIRAL_FAST_MINWAVES
+#define DIRAL_FAST_MINWAVES 1
+#endif
+#ifndef DIRAL_MERGE_BPERM
+#define DIRAL_MERGE_BPERM 16           // columns (of 16) merged through ds_bpermute
+#endif
+
+constexpr int kFastMaxA = 32;
+
+struct FastParams {
+  int N, A, K, NV;
+  uint32_t flags;
+  int reward_design, age_limit, episode_interval;
+  double L, Rc, Rb, inv_w;
+  long long t;
+  const int32_t* actions;
+  double* pos_x;
+  const double* pos_y;
+  const double* vel;
+  uint32_t* tkey;
+  double* tx;
+  double* metrics;
+  uint32_t* err;
+  const double* edges;
+  float* state_out;
+  float* rew_out;
+  uint8_t* done_out;
+  unsigned long long* dbg;
+};
+
+struct FastLds {
+  uint32_t rv, edges, mask, rx, act, hist, cnt, mtab, total;
+};
+__host__ __device__ inline FastLds fast_lds_layout(int K) {
+  FastLds l;
+  uint32_t o = 0;
+  l.rv = o;    o += 8u * kFastMaxA;
+  l.edges = o; o += 8u * (K + 2);
+  l.mask = o;  o += 8u * kFastMaxA;
+  l.rx = o;    o += 8u * 64;                // receiver set of each transmitter
+  l.act = o;   o += 4u * 64;
+  l.hist = o;  o += 4u * (K | 1) * 64;
+  l.cnt = o;   o += 4u * 64;
+  l.mtab = o;  o += 64u * kFastMaxA;        // [vehicle][32] gather-source bytes
+  l.total = align_up(o, 16);
+  return l;
+}
+
+__device__ inline double readlane_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int srclane) {
+  const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)v, srclane);
+  const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(v >> 32), srclane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Network.dist for the fast kernel.  FLAT (all y == 0): sqrt(fl(dx*dx)) == |dx|
+// exactly when 2^-500 <= |dx| <= 2^500; the exponent test is two integer ops.
+template <bool FLAT>
+__device__ inline double fast_dist(double x1, double y1, double x2, double y2) {
+  const double dx = x2 - x1;
+  const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
+  const bool in_range = (hi - 0x20b00000u) <= (0x5f300000u - 0x20b00000u);
+  if (FLAT) {
+    if (in_range) return __hiloint2double((int)hi, __double2loint(dx));
+    return dist_general(dx, 0.0);
+  } else {
+    const double dy = y2 - y1;
+    if (in_range && dy == 0.0) return __hiloint2double((int)hi, __double2loint(dx));
+    return dist_general(dx, dy);
+  }
+}
+
+// Reward of a colliding resource (test_env.py:163-199) incl.
+// Network.calculate_reward_weights (network.py:273-300); wave-uniform, positions
+// broadcast from lanes.  Out of line: runs ~once per colliding resource.
+__device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
+                                                                  unsigned long long mk, int c, double mypx,
+                                                                  double mypy) {
+  int wgt = 0;
+  if (rd == 1 || ((rd == 2 || rd == 5) && c == 2)) {
+    double s = 0.0;                    // calculate_avg_distance (network.py:307-316)
+    int cnt = 0;
+    unsigned long long ma = mk;
+    while (ma) {
+      const int a = __builtin_ctzll(ma);
+      ma &= ma - 1;
+      const double xa = readlane_f64(mypx, a), ya = readlane_f64(mypy, a);
+      unsigned long long mb = ma;
+      while (mb) {
+        const int b = __builtin_ctzll(mb);
+        mb &= mb - 1;
+        s = s + dist2d(xa, ya, readlane_f64(mypx, b), readlane_f64(mypy, b));
+        ++cnt;
+      }
+    }
+    const double m = (cnt == 1) ? s : s / (double)cnt;       // s/1 == s exactly
+    if (flags & DIRAL_F_TOY_WEIGHTS) {
+      double x_min = L + 1, x_max = -L - 1;      // calculate_norm (network.py:225-246)
+      int umin = 0, umax = 0;
+      for (int u = 0; u < N; ++u) {
+        const double x = readlane_f64(mypx, u);
+        if (x < x_min) { x_min = x; umin = u; }
+        if (x > x_max) { x_max = x; umax = u; }
+      }
+      wgt = (m == dist2d(readlane_f64(mypx, umin), readlane_f64(mypy, umin), readlane_f64(mypx, umax),
+                         readlane_f64(mypy, umax)));
+    } else {
+      wgt = (m > Rc);
+    }
+  }
+  if (rd == 1) { const double R = (double)wgt / (double)c; return -1.0 * (1.0 - R); }
+  if (rd == 2) return (c == 2) ? 2.0 * (double)wgt - (double)c : 0.0 - (double)c;
+  if (rd == 3) { const double R = 1.0 / (double)c; return -1.0 * exp(1.0 - R); }
+  if (rd == 4) return 1.0 / (double)c;
+  return (c == 2 && wgt == 1) ? 0.0 : -1.0;
+}
+
+#ifdef DIRAL_TIMING
+#define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DIRAL_FSTAMP(i) do {} while (0)
+#endif
+
+template <bool FLAT>
+__global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const FastLds lay = fast_lds_layout(p.K);
+  double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
+  double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
+  unsigned long long* s_rx = reinterpret_cast<unsigned long long*>(smem + lay.rx);
+  int* s_act = reinterpret_cast<int*>(smem + lay.act);
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
+  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
+  unsigned char* s_mtab = smem + lay.mtab;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, A = p.A, K = p.K;
+  const int KP = K | 1;
+  const size_t bN = (size_t)b * N;
+  const bool live = lane < N;
+  constexpr int XB = DIRAL_MERGE_BPERM;
+  constexpr int NV = 64;                       // padded viewer stride (host guarantees p.NV == 64)
+  DIRAL_FSTAMP(0);
+
+  // ---- P0: per-vehicle state straight into registers (every wave, lane = vehicle)
+  int myact = -1;
+  double mypx = 0.0, mypy = 0.0, myvel = 0.0;
+  if (live) {
+    myact = p.actions[bN + lane];
+    mypx = p.pos_x[bN + lane];
+    if (!FLAT) mypy = p.pos_y[bN + lane];
+    myvel = p.vel[bN + lane];
+  }
+  // this wave's 16 subject columns; issued AFTER the small loads (in-order vmcnt)
+  unsigned int* const tk = p.tkey + bN * NV;
+  double* const txp = p.tx + bN * NV;
+  const int ncol = min(16, N - wave * 16);     // uniform; <= 0 for idle waves of a small env
+  unsigned int w1[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    w1[c] = 0u;
+    if (c < ncol) w1[c] = tk[(wave * 16 + c) * NV + lane];
+  }
+  if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
+  const double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;       // network.py:203
+  if (wave == 0) { s_act[lane] = myact; s_cnt[lane] = 0u; }
+  for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
+  for (int j = tid; j <= K + 1; j += 256) s_edges[j] = p.edges[j < K ? j : K];
+  DIRAL_FSTAMP(1);
+
+  // ---- P1: per owned resource i = wave + 4*s: transmitter set, closest in-range
+  // transmitter per vehicle, gather sources, collision reward ----------------------
+#pragma unroll 1
+  for (int i = wave; i < A; i += 4) {
+    const unsigned long long mk = __ballot(myact == i);     // tx set (test_env.py:153-157)
+    const int c = __popcll(mk);
+    if (lane == 0) s_mask[i] = mk;
+    // Network.find_closest_tx (network.py:378-398): ascending id, strict '<'
+    double best = 100000.0;
+    int bid = -1;
+    unsigned long long m = mk;
+    while (m) {
+      const int w = __builtin_ctzll(m);
+      m &= m - 1;
+      const double d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
+      const bool bt = (d < p.Rc) && (d < best);
+      best = bt ? d : best;
+      bid = bt ? w : bid;
+    }
+    const bool got = live && (myact != i) && (bid >= 0);
+    s_mtab[lane * kFastMaxA + i] = (unsigned char)(got ? bid : lane);
+    if constexpr (XB < 16) {
+      m = mk;
+      while (m) {                                             // receiver set of each transmitter
+        const int w = __builtin_ctzll(m);
+        m &= m - 1;
+        const unsigned long long rx = __ballot(got && bid == w);
+        if (lane == 0) s_rx[w] = rx;
+      }
+    }
+    if (c > 1) {                                              // test_env.py:159-199
+      const double rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
+      if (lane == 0) s_rv[i] = rw;
+    }
+  }
+  DIRAL_FSTAMP(2);
+  __syncthreads();
+  DIRAL_FSTAMP(3);
+
+  // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
+  if (wave == 0) {
+    double r = 0.0;
+    int sole = 0, coll = 0;
+    if (live && myact >= 0) {
+      const int c = __popcll(s_mask[myact]);
+      if (c > 1) { r = s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222
+      if (p.rew_out) p.rew_out[bN + lane] = (float)r;
+    }
+    double vr = r;
+    int vs = sole, vc = coll;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      vr += __shfl_down(vr, off);
+      vs += __shfl_down(vs, off);
+      vc += __shfl_down(vc, off);
+    }
+    if (lane == 0) {
+      double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+      mt[DIRAL_M_SLOTS] += 1.0;
+      mt[DIRAL_M_SUM_REWARD] += vr;
+      mt[DIRAL_M_TX_SOLE] += (double)vs;
+      mt[DIRAL_M_TX_COLLIDED] += (double)vc;
+      if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+    }
+    if (live) p.pos_x[bN + lane] = mynpx;
+  }
+  DIRAL_FSTAMP(4);
+
+  // ---- P3a: stamp + gossip merge over this wave's 16 subject columns -------------
+  unsigned int key[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int k = wave * 16 + c;
+    unsigned int w = w1[c];
+    unsigned int seq = w >> 8, age = w & 255u;                 // Vehicle.periodic_update (vehicle.py:56-70)
+    if (lane == k) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
+    else age = (age < 255u) ? age + 1u : 255u;
+    w = (seq << 8) | age;
+    w1[c] = w;
+    key[c] = (w & ~255u) | (unsigned int)lane;
+  }
+  // Vehicle.received_update for every (resource, rx), resources ascending.
+  unsigned long long myrx = 0ull;                              // lane w: receiver set of transmitter w
+  if constexpr (XB < 16) myrx = s_rx[lane];
+  int m_next = s_mtab[lane * kFastMaxA];
+#pragma unroll 1
+  for (int i = 0; i < A; ++i) {
+    const int m_cur = m_next;
+    m_next = s_mtab[lane * kFastMaxA + ((i + 1 < A) ? i + 1 : i)];
+    unsigned long long mk = __ballot(myact == i);
+    if (mk == 0ull) continue;
+    if constexpr (XB > 0) {
+      const int m4 = m_cur << 2;
+#pragma unroll
+      for (int c = 0; c < XB; ++c) {
+        const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
+        key[c] = max(key[c], v);
+      }
+    }
+    if constexpr (XB < 16) {
+      while (mk) {
+        const int w = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const unsigned long long rx = readlane_u64(myrx, w);
+        if (rx == 0ull) continue;
+        unsigned int sv[XB < 16 ? 16 - XB : 1];
+#pragma unroll
+        for (int c = XB; c < 16; ++c) sv[c - XB] = (unsigned int)__builtin_amdgcn_readlane((int)key[c], w);
+        if (__builtin_amdgcn_inverse_ballot_w64(rx)) {
+#pragma unroll
+          for (int c = XB; c < 16; ++c) key[c] = max(key[c], sv[c - XB]);
+        }
+      }
+    }
+  }
+  DIRAL_FSTAMP(5);
+
+  // ---- P3b: xpos follows the winning sequence number; histogram ------------------
+  unsigned int mycnt = 0u;
+  const double inv_w = p.inv_w;
+  unsigned int* const hrow = s_hist + lane * KP;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c >= ncol) break;
+    const int k = wave * 16 + c;
+    const int off = k * NV + lane;
+    const unsigned int kf = key[c], w = w1[c];
+    const bool upd = ((kf ^ w) >> 8) != 0u;
+    double xo = txp[off];
+    if (lane == k) xo = mypx;                                   // own stamp (vehicle.py:63)
+    const int src4 = (int)(kf & 255u) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xo));
+    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xo));
+    const double xg = upd ? __hiloint2double(hi, lo) : xo;
+    const unsigned int wn = upd ? (kf & ~255u) : w;
+    tk[off] = wn;
+    if (upd || lane == k) txp[off] = xg;
+    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
+    double y1 = 0.0;
+    if (!FLAT) { const double pyk = readlane_f64(mypy, k); y1 = (wn >> 8) ? pyk : 0.0; }
+    const double d = fast_dist<FLAT>(xg, y1, mynpx, mypy);
+    const bool ok = live && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    if (ok) {
+      const double v = (xg - mynpx > 0.0) ? d : -d;
+      int est = (int)((v + p.Rb) * inv_w);
+      est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
+      const double e0 = s_edges[est], e1 = s_edges[est + 1];
+      const int bin = est + ((v >= e1 && est < K - 1) ? 1 : 0) - ((v < e0 && est > 0) ? 1 : 0);
+      atomicAdd(&hrow[bin], 1u);
+      mycnt += 1u;
+    }
+  }
+  if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
+  DIRAL_FSTAMP(6);
+  __syncthreads();
+  DIRAL_FSTAMP(7);
+
+  // ---- P4: state = [one-hot(action) (A) | histogram (K)], float32 ----------------
+  const int S = A + K;
+  float* out = p.state_out + bN * S;
+  if (((A | K) & 3) == 0) {
+    const int q_per_row = S >> 2, total = N * q_per_row;
+    for (int q = tid; q < total; q += 256) {
+      const int u = q / q_per_row, s0 = (q - u * q_per_row) << 2;
+      float4 v;
+      if (s0 < A) {
+        const int a = s_act[u] - s0;
+        v = make_float4(a == 0 ? 1.f : 0.f, a == 1 ? 1.f : 0.f, a == 2 ? 1.f : 0.f, a == 3 ? 1.f : 0.f);
+      } else {
+        const unsigned int n = s_cnt[u];
+        const unsigned int* h = s_hist + u * KP + (s0 - A);
+        // exact w.r.t. (float)((double)h/(double)n): see step_kernel.hpp
+        const float fn = (float)n;
+        v = n ? make_float4(__fdiv_rn((float)h[0], fn), __fdiv_rn((float)h[1], fn),
+                            __fdiv_rn((float)h[2], fn), __fdiv_rn((float)h[3], fn))
+              : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      reinterpret_cast<float4*>(out)[q] = v;
+    }
+  } else {
+    for (int e = tid; e < N * S; e += 256) {
+      const int u = e / S, s = e - u * S;
+      float val;
+      if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
+      else {
+        const unsigned int n = s_cnt[u];
+        val = n ? __fdiv_rn((float)s_hist[u * KP + (s - A)], (float)n) : 0.f;
+      }
+      out[e] = val;
+    }
+  }
+}
+
+}  // namespace diral

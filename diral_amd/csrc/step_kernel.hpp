@@ -22,7 +22,9 @@
 //                 queue of a wave orders its own writes and reads).
 //     xpos follows afterwards with ONE gather from the recorded source viewer.
 //   * HBM traffic per env-slot: each table word read once, written once,
-//     coalesced along the viewer axis (subject-major layout, common.hpp).
+//     coalesced along the viewer axis (subject-major layout, common.hpp); for
+//     N <= 64 the whole table read is issued before any compute so its latency
+//     hides behind the closest-transmitter phase.
 //
 // float64 everywhere the reference uses Python floats; build with
 // -ffp-contract=off so a*b+c is never fused (bin edges, distances).
@@ -30,6 +32,18 @@
 #include "common.hpp"
 
 namespace diral {
+
+#ifdef DIRAL_TIMING
+#define DIRAL_STAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DIRAL_STAMP(i) do {} while (0)
+#endif
+#ifndef DIRAL_MINWAVES
+#define DIRAL_MINWAVES 1
+#endif
+#ifndef DIRAL_PREFETCH
+#define DIRAL_PREFETCH 1
+#endif
 
 template <int VPL>
 struct Geo {
@@ -40,35 +54,50 @@ struct Geo {
   static constexpr int NCH = VPL;            // chunks per wave
 };
 
-__device__ inline bool flag(const StepParams& p, uint32_t f) { return (p.flags & f) != 0; }
-
-// Network.dist (network.py:318-332) with correctly rounded v*v (see DESIGN.md
-// on the reference's pow()).
+// Network.dist (network.py:318-332): sqrt(dx^2 + dy^2) with correctly rounded
+// squares (DESIGN.md on the reference's pow()).  When dy == 0 - every pair in a
+// random topology, where all y are 0 - sqrt(fl(dx*dx)) == |dx| exactly in IEEE
+// binary64 (no over/underflow for 2^-500 <= |dx| <= 2^500), so the sqrt is skipped.
+// rare general paths are kept out of line so the hot code stays compact
+// (the fused kernels were instruction-fetch bound when these were inlined)
+__device__ __attribute__((noinline)) double dist_general(double dx, double dy) {
+  return __builtin_sqrt(dx * dx + dy * dy);
+}
 __device__ inline double dist2d(double x1, double y1, double x2, double y2) {
   const double dx = x2 - x1, dy = y2 - y1;
-  return __builtin_sqrt(dx * dx + dy * dy);
+  const double ax = __builtin_fabs(dx);
+  if (dy == 0.0 && ax >= 0x1p-500 && ax <= 0x1p500) return ax;
+  return dist_general(dx, dy);
 }
 
 // Python float `%` for the position wrap (network.py:203): fast exact path when
-// 0 <= s < 2L (Sterbenz), generic fmod + sign fix-up otherwise.
+// 0 <= s <= 2L (Sterbenz), generic fmod + sign fix-up otherwise.
+__device__ __attribute__((noinline)) double py_mod_general(double s, double L) {
+  double m = fmod(s, L);
+  if (m != 0.0) { if ((L < 0) != (m < 0)) m += L; } else { m = copysign(0.0, L); }
+  return m;
+}
 __device__ inline double py_mod_pos(double s, double L) {
   if (s >= 0.0 && s < L) return s;
   if (s >= L && s <= 2.0 * L) {
     const double r = s - L;            // exact
     return (r >= L) ? r - L : r;       // s == 2L -> 0
   }
-  double m = fmod(s, L);
-  if (m != 0.0) { if ((L < 0) != (m < 0)) m += L; } else { m = copysign(0.0, L); }
-  return m;
+  return py_mod_general(s, L);
 }
 
-// np.histogram uniform-bin index (numpy/lib/_histograms_impl.py fast path)
-__device__ inline int hist_bin(double v, double first, double denom, int K, const double* edges) {
-  const double f = ((v - first) / denom) * (double)K;
-  int idx = (int)f;
-  if (idx == K) idx -= 1;
-  if (v < edges[idx]) idx -= 1;
-  if (v >= edges[idx + 1] && idx != K - 1) idx += 1;
+// np.histogram uniform-bin index (numpy/lib/_histograms_impl.py fast path).
+// NumPy estimates the index with a division and then corrects it against the
+// actual edges ("not guaranteed to give exactly consistent results within ~1
+// ULP of the bin edges"), so its result is THE bin with edges[i] <= v <
+// edges[i+1].  Any estimate followed by the same edge correction lands in the
+// same bin; a reciprocal multiply replaces the f64 division.  `edges` are the
+// exact np.linspace values (strictly increasing, checked at create).
+__device__ inline int hist_bin(double v, double first, double inv_width, int K, const double* edges) {
+  int idx = (int)((v - first) * inv_width);
+  idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+  while (idx > 0 && v < edges[idx]) --idx;
+  while (idx < K - 1 && v >= edges[idx + 1]) ++idx;
   return idx;
 }
 
@@ -77,7 +106,7 @@ __device__ inline void store_out(void* base, size_t idx, double v, int f64) {
   else reinterpret_cast<float*>(base)[idx] = (float)v;
 }
 
-// wave-uniform 64-bit LDS value -> SGPR pair, so branches on it are scalar
+// wave-uniform 64-bit value -> SGPR pair, so branches on it are scalar
 __device__ inline unsigned long long uniform_u64(unsigned long long v) {
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
   const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
@@ -130,8 +159,13 @@ __device__ inline int reward_weight(const StepParams& p, const unsigned long lon
   return m > p.Rc;
 }
 
-template <int VPL>
-__global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParams p) {
+// FAST = the configuration BASELINE.json's metric is quoted on (the toy YAML's
+// State flags: one-hot action + type-2 piggybacked histogram, my_step, f32
+// outputs, no channel-obs / arrival / PRR / PF side outputs).  It is the same
+// code with the optional branches removed at compile time; every other config
+// runs FAST=false.
+template <int VPL, bool FAST>
+__global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1)) void step_kernel(const StepParams p) {
   using G = Geo<VPL>;
   constexpr int NPAD = G::NPAD, WAVES = G::WAVES, CC = G::CC, NCH = G::NCH;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -157,13 +191,37 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int N = p.N, A = p.A, K = p.K, NV = p.NV;
-  const bool do_step = p.mode != kModeObserve;
-  const bool piggy = flag(p, DIRAL_F_ADD_POSDIST_PIGGY);
-  const bool want_hist = piggy && p.state_out != nullptr && p.off_hist >= 0;
-  const bool track_la = flag(p, DIRAL_F_TRACK_ARRIVAL) && p.la != nullptr;
-  const bool want_prr = do_step && (p.mode == DIRAL_STEP_MY_STEP_CH ||
-                                    (p.mode == DIRAL_STEP_MY_STEP && flag(p, DIRAL_F_TRACK_PRR)));
+  const int KP = K | 1;                       // odd histogram row stride: conflict-free LDS
+  const int mode = FAST ? (int)DIRAL_STEP_MY_STEP : p.mode;
+  const bool do_step = FAST || mode != kModeObserve;
+  const bool piggy = FAST || (p.flags & DIRAL_F_ADD_POSDIST_PIGGY);
+  const bool want_hist = FAST || (piggy && p.state_out != nullptr && p.off_hist >= 0);
+  const bool track_la = !FAST && (p.flags & DIRAL_F_TRACK_ARRIVAL) && p.la != nullptr;
+  const bool want_prr = !FAST && do_step && (mode == DIRAL_STEP_MY_STEP_CH ||
+                                              (mode == DIRAL_STEP_MY_STEP && (p.flags & DIRAL_F_TRACK_PRR)));
+  const bool mobile = FAST || (p.flags & DIRAL_F_MOBILITY);
+  const bool use_pf = !FAST && (p.flags & DIRAL_F_PROPORTIONAL_FAIR);
+  const int out_f64 = FAST ? 0 : p.out_f64;
   const size_t bN = (size_t)b * N;
+
+  DIRAL_STAMP(0);
+  // ---- prefetch (N <= 64): this wave's 16 table columns, before any compute --
+  unsigned int pre_w[VPL == 1 ? 16 : 1];
+  double pre_x[VPL == 1 ? 16 : 1];
+  if constexpr (VPL == 1 && DIRAL_PREFETCH) {
+    if (piggy) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int k = wave * 16 + c;
+        const bool ok = (k < N) && (lane < N);
+        const size_t idx = (bN + (ok ? k : 0)) * NV + (ok ? lane : 0);
+        const unsigned int w = p.tkey[idx];
+        const double x = p.tx[idx];
+        pre_w[c] = ok ? w : 0u;
+        pre_x[c] = ok ? x : 0.0;
+      }
+    }
+  }
 
   // ---- P0: stage per-vehicle state, compute the post-move position --------
   for (int u = tid; u < NPAD; u += G::THREADS) {
@@ -176,14 +234,15 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
       y = p.pos_y[bN + u];
       v = p.vel[bN + u];
       nx = x;
-      if (do_step && flag(p, DIRAL_F_MOBILITY)) nx = py_mod_pos(x + v + p.L, p.L);  // network.py:203
+      if (do_step && mobile) nx = py_mod_pos(x + v + p.L, p.L);  // network.py:203
     }
     s_act[u] = a; s_px[u] = x; s_py[u] = y; s_vel[u] = v; s_npx[u] = nx;
     s_cnt[u] = 0u; s_rtx[u] = 1.0; s_rew[u] = 0.0; s_inr[u] = 0;
   }
-  for (int j = tid; j < K * NPAD; j += G::THREADS) s_hist[j] = 0u;
+  for (int j = tid; j < KP * NPAD; j += G::THREADS) s_hist[j] = 0u;
   for (int j = tid; j <= K; j += G::THREADS) s_edges[j] = p.edges[j];
   __syncthreads();
+  DIRAL_STAMP(1);
 
   // per-lane copies of this lane's viewers
   int myact[VPL];
@@ -225,11 +284,13 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
               const double d = dist2d(xw, yw, mypx[j], mypy[j]);
               const bool inr = d < p.Rc;
               if (inr && d < best[j]) { best[j] = d; bid[j] = w; }
-              const bool rx = (u < N) && (myact[j] != i);
-              if (track_la && rx && !inr) p.la[(bN + w) * N + u] = -1;        // network.py:394
-              if (want_prr && c > 1) n_in += __popcll(__ballot(rx && inr));   // test_env.py:395-397
+              if (!FAST) {
+                const bool rx = (u < N) && (myact[j] != i);
+                if (track_la && rx && !inr) p.la[(bN + w) * N + u] = -1;        // network.py:394
+                if (want_prr && c > 1) n_in += __popcll(__ballot(rx && inr));   // test_env.py:395-397
+              }
             }
-            if (want_prr && c > 1 && lane == 0) s_inr[w] = n_in;
+            if (!FAST && want_prr && c > 1 && lane == 0) s_inr[w] = n_in;
           }
         }
       }
@@ -239,21 +300,21 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
         const bool is_tx = (myact[j] == i);
         const bool got = (!is_tx) && (bid[j] >= 0) && (u < N) && (c > 0);
         s_mtab[i * NPAD + u] = (unsigned char)(got ? bid[j] : u);
-        if (u < N) {
+        if (!FAST && u < N) {
           // channel observation of the reference step (`obs[user][i]`)
           double ob = 0.0;
           if (!is_tx && c > 0) {
-            if (p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ob = best[j];  // test_env.py:240
-            else ob = 1.0;                                                    // :228, :306, :432
+            if (mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ob = best[j];    // test_env.py:240
+            else ob = 1.0;                                                      // :228, :306, :432
           }
-          if (p.chobs_out) store_out(p.chobs_out, (bN + u) * A + i, ob, p.out_f64);
+          if (p.chobs_out) store_out(p.chobs_out, (bN + u) * A + i, ob, out_f64);
           if (p.state_out && p.off_chobs >= 0)
-            store_out(p.state_out, (bN + u) * p.S + p.off_chobs + i, ob, p.out_f64);
-          if (track_la && p.mode == DIRAL_STEP_MY_STEP_CH && got)
-            p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;                       // test_env.py:436
+            store_out(p.state_out, (bN + u) * p.S + p.off_chobs + i, ob, out_f64);
+          if (track_la && mode == DIRAL_STEP_MY_STEP_CH && got)
+            p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;                         // test_env.py:436
         }
       }
-      if (want_prr && c > 1) {
+      if (!FAST && want_prr && c > 1) {
         // received[tx] = #rx whose nearest tx is tx (test_env.py:398-400)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -271,12 +332,12 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
             }
             if (lane == 0) {
               const int n_in = s_inr[w];
-              s_rtx[w] = n_in > 0 ? (double)n_rec / (double)n_in : 1.0;       // test_env.py:402-405
+              s_rtx[w] = n_in > 0 ? (double)n_rec / (double)n_in : 1.0;         // test_env.py:402-405
             }
           }
         }
       }
-      if (p.mode == DIRAL_STEP_MY_STEP && c > 1) {
+      if (mode == DIRAL_STEP_MY_STEP && c > 1) {
         // test_env.py:163-199, one value per resource
         double rw = 0.0;
         const int rd = p.reward_design;
@@ -300,7 +361,9 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
       }
     }
   }
+  DIRAL_STAMP(2);
   __syncthreads();
+  DIRAL_STAMP(3);
 
   // ---- P2: reward per transmitter -----------------------------------------
   if (do_step) {
@@ -310,10 +373,10 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
       const int a = s_act[u];
       if (u < N && a >= 0) {
         const int c = popc_masks(s_mask + a * VPL, VPL);
-        if (p.mode == DIRAL_STEP_MY_STEP) {                                   // test_env.py:211-222
+        if (mode == DIRAL_STEP_MY_STEP) {                                     // test_env.py:211-222
           if (c > 1) {
             r = s_rv[a];
-            if (flag(p, DIRAL_F_PROPORTIONAL_FAIR)) {
+            if (use_pf) {
               const int pc = p.pf[bN + u];
               if (pc > p.pf_threshold) r = p.pf_penalty;
               p.pf[bN + u] = pc + 1;
@@ -321,10 +384,10 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
             coll = 1; prr = s_rtx[u];
           } else {
             r = 1.0;
-            if (flag(p, DIRAL_F_PROPORTIONAL_FAIR)) p.pf[bN + u] = 0;
+            if (use_pf) p.pf[bN + u] = 0;
             sole = 1; prr = 1.0;
           }
-        } else if (p.mode == DIRAL_STEP_MY_STEP_CH) {                         // test_env.py:411-429
+        } else if (mode == DIRAL_STEP_MY_STEP_CH) {                           // test_env.py:411-429
           const int rd = p.reward_design;
           if (c > 1) {
             const double R = s_rtx[u];
@@ -360,7 +423,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
           }
         }
         s_rew[u] = r;
-        if (p.rew_out) store_out(p.rew_out, bN + u, r, p.out_f64);
+        if (p.rew_out) store_out(p.rew_out, bN + u, r, out_f64);
       }
       // deterministic per-wave reductions for the metric accumulators
       double vr = r, vp = want_prr ? prr : 0.0;
@@ -368,7 +431,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         vr += __shfl_down(vr, off);
-        vp += __shfl_down(vp, off);
+        if (!FAST) vp += __shfl_down(vp, off);
         vs += __shfl_down(vs, off);
         vc += __shfl_down(vc, off);
       }
@@ -382,12 +445,14 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
     for (int u = tid; u < N; u += G::THREADS) s_rew[u] = p.rew_in ? p.rew_in[bN + u] : 0.0;
   }
 
+  DIRAL_STAMP(4);
   // ---- P3: neighbour-table stamp + gossip merge + observation histogram ----
   if (piggy && (do_step || want_hist)) {
     unsigned int* scratch = reinterpret_cast<unsigned int*>(smem + lay.scratch) + wave * 1024;
     unsigned int mycnt[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
+    const double inv_w = p.hist_inv_width;
 
     for (int ch = 0; ch < NCH; ++ch) {
       const int kbase = wave * 16 + ch * CC;
@@ -401,7 +466,8 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
           unsigned int w = 0u;
-          if (k < N && u < N) w = p.tkey[(bN + k) * NV + u];
+          if constexpr (VPL == 1 && DIRAL_PREFETCH) w = pre_w[c];
+          else if (k < N && u < N) w = p.tkey[(bN + k) * NV + u];
           if (do_step) {
             // Vehicle.periodic_update (vehicle.py:56-70)
             unsigned int seq = w >> 8, age = w & 255u;
@@ -459,6 +525,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
           }
         }
       }
+      DIRAL_STAMP(5);
       // finalize: xpos follows the winning sequence number; age reset on change
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
@@ -472,10 +539,11 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
           const unsigned int kf = key[c * VPL + j], w = w1[c * VPL + j];
-          const unsigned int seqf = kf >> 8, src = kf & 255u;
-          const bool upd = (seqf != (w >> 8));
+          const unsigned int src = kf & 255u;
+          const bool upd = ((kf ^ w) >> 8) != 0u;
           double xo = 0.0;
-          if (u < N) xo = p.tx[(bN + k) * NV + u];
+          if constexpr (VPL == 1 && DIRAL_PREFETCH) xo = pre_x[c];
+          else if (u < N) xo = p.tx[(bN + k) * NV + u];
           if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
           double xg = xo;
           if constexpr (VPL == 1) {
@@ -486,7 +554,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
             if (upd) xg = ((int)src == k) ? pxk : p.tx[(bN + k) * NV + src];
           }
           xn[j] = xg;
-          wn[j] = upd ? (seqf << 8) : w;
+          wn[j] = upd ? (kf & ~255u) : w;
           changed[j] = upd;
         }
         if (do_step) {
@@ -512,8 +580,8 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
               const double d = dist2d(x1, y1, x2, y2);
               if (d < p.Rb) {
                 const double v = (x1 - x2 > 0.0) ? d : -d;
-                const int bin = hist_bin(v, -p.Rb, p.hist_denom, K, s_edges);
-                atomicAdd(&s_hist[bin * NPAD + u], 1u);
+                const int bin = hist_bin(v, -p.Rb, inv_w, K, s_edges);
+                atomicAdd(&s_hist[u * KP + bin], 1u);
                 mycnt[j] += 1u;
               }
             }
@@ -527,7 +595,9 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
         if (mycnt[j]) atomicAdd(&s_cnt[lane + 64 * j], mycnt[j]);
     }
   }
+  DIRAL_STAMP(6);
   __syncthreads();
+  DIRAL_STAMP(7);
 
   // ---- P4: write-back: positions, state vectors, done flag, metrics --------
   if (do_step) {
@@ -546,7 +616,45 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
       if (want_prr) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
     }
   }
-  if (p.state_out) {
+  if (FAST) {
+    // state = [one-hot(action) (A) | histogram (K)], float32, S = A + K
+    const int S = A + K;
+    float* out = reinterpret_cast<float*>(p.state_out) + bN * S;
+    if (((A | K) & 3) == 0) {
+      // 16-byte stores: rows are S*4 bytes, S % 4 == 0
+      const int q_per_row = S >> 2, total = N * q_per_row;
+      for (int q = tid; q < total; q += G::THREADS) {
+        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 2;
+        float4 v;
+        if (s0 < A) {
+          const int a = s_act[u] - s0;
+          v = make_float4(a == 0 ? 1.f : 0.f, a == 1 ? 1.f : 0.f, a == 2 ? 1.f : 0.f, a == 3 ? 1.f : 0.f);
+        } else {
+          const unsigned int n = s_cnt[u];
+          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          // (float)((double)h/(double)n) == correctly rounded float division for
+          // integers h <= n <= 255 (the quotient is never within 2^-53 of a
+          // float midpoint), so the f32 division is exact w.r.t. network.py:501
+          const float fn = (float)n;
+          v = n ? make_float4(__fdiv_rn((float)h[0], fn), __fdiv_rn((float)h[1], fn),
+                              __fdiv_rn((float)h[2], fn), __fdiv_rn((float)h[3], fn))
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        reinterpret_cast<float4*>(out)[q] = v;
+      }
+    } else {
+      for (int e = tid; e < N * S; e += G::THREADS) {
+        const int u = e / S, s = e - u * S;
+        float val;
+        if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
+        else {
+          const unsigned int n = s_cnt[u];
+          val = n ? __fdiv_rn((float)s_hist[u * KP + (s - A)], (float)n) : 0.f;
+        }
+        out[e] = val;
+      }
+    }
+  } else if (p.state_out) {
     const int S = p.S;
     const int total = N * S;
     int e = tid;
@@ -563,7 +671,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
         else val = p.chobs_in ? p.chobs_in[(bN + u) * A + (s - p.off_chobs)] : 0.0;
       } else if (p.off_hist >= 0 && s >= p.off_hist && s < p.off_hist + K) {
         const unsigned int n = s_cnt[u];
-        const unsigned int h = s_hist[(s - p.off_hist) * NPAD + u];
+        const unsigned int h = s_hist[u * KP + (s - p.off_hist)];
         val = n ? (double)h / (double)n : 0.0;                                   // network.py:501
       } else if (s == p.off_rew) {
         val = s_rew[u];
@@ -580,7 +688,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS) void step_kernel(const StepParam
       } else if (p.off_fp >= 0 && s == p.off_fp + 1) {
         val = p.eps;
       }
-      if (write) store_out(p.state_out, (size_t)bN * S + e, val, p.out_f64);
+      if (write) store_out(p.state_out, (size_t)bN * S + e, val, out_f64);
       e += G::THREADS; u += du; s += ds;
       if (s >= S) { s -= S; u += 1; }
     }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock timing of the fused step kernel (DIRAL_TIMING build).
+
+  DIRAL_LIB=diral_amd/variants/timing.so python profiles/phase_timing.py
+
+Stamps (s_memtime, per wave): 0 start, 1 after P0 barrier, 2 end P1, 3 after
+barrier, 4 end P2, 5 end merge, 6 end finalize/hist, 7 after barrier.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diral_amd.config import c2_config  # noqa: E402
+from diral_amd.vec_env import VecV2VEnv  # noqa: E402
+
+B = int(os.environ.get("B", 4096))
+env = VecV2VEnv(c2_config(), batch=B, out_dtype=torch.float32)
+env.reset_topology(seed=1)
+acts = [env.sample(seed=i) for i in range(8)]
+for t in range(60):
+    env.step(acts[t % 8], t)
+torch.cuda.synchronize()
+fn = env.lib.diral_env_debug_timing
+fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros((B, 4, 8), np.uint64)
+assert fn(env._h, buf.ctypes.data_as(ctypes.c_void_p), 4) == 0
+t = buf.astype(np.int64)
+names = ["P0 load+barrier", "P1 closest-tx", "wait barrier", "P2 rewards", "P3 merge", "P3 finalize+hist", "wait barrier"]
+d = np.diff(t, axis=2)
+print("B=%d; mean cycles per wave per phase (s_memtime ticks), by wave:" % B)
+for i, n in enumerate(names):
+    print("  %-18s %s   all=%.0f" % (n, " ".join("%7.0f" % d[:, w, i].mean() for w in range(4)), d[:, :, i].mean()))
+life = (t[:, :, 7] - t[:, :, 0])
+print("  wave lifetime to last barrier: mean %.0f  p50 %.0f  p99 %.0f" % (life.mean(), np.median(life), np.percentile(life, 99)))
+span = t[:, :, 7].max() - t[:, :, 0].min()
+print("  kernel span %d ticks" % span)
+start = t[:, 0, 0] - t[:, 0, 0].min()
+print("  WG start time percentiles (ticks):", [int(np.percentile(start, q)) for q in (0, 25, 50, 75, 100)])

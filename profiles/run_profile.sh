@@ -1,0 +1,28 @@
+#!/bin/bash
+# Profiling recipe (run on the GPU box through gpurun, from the repo root):
+#   bash profiles/run_profile.sh <tag> [bench args...]
+# Writes gpurun_out/prof_<tag>/ : kernel-trace stats + separate PMC passes.
+# Counters are collected in their OWN runs (never with sys/hip traces).
+set -u
+TAG=${1:-r01}; shift || true
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+pmc() { # name counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- \
+    python $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline ${EXTRA:-} > $OUT/$name.log 2>&1
+}
+EXTRA="$*"
+pmc pmc_sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
+pmc pmc_sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+pmc pmc_fetch FETCH_SIZE
+pmc pmc_write WRITE_SIZE
+pmc pmc_grbm GRBM_GUI_ACTIVE
+cd $R
+python profiles/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt

@@ -349,3 +349,54 @@ def test_replica_envs_are_identical_at_scale():
     st = env.export_state()
     for k in ("seq", "age", "x"):
         assert torch.all(st[k] == st[k][0:1])
+
+
+@pytest.mark.parametrize("N,A,K,rd,toy", [(64, 32, 20, 2, False), (64, 32, 20, 1, False), (64, 32, 40, 5, False),
+                                           (64, 32, 20, 3, False), (64, 32, 20, 4, False),
+                                           (4, 3, 20, 2, True), (4, 3, 10, 1, True), (63, 31, 10, 2, False),
+                                           (33, 7, 20, 2, False), (64, 5, 8, 2, False), (1, 1, 4, 2, False),
+                                           (17, 32, 64, 2, False)])
+def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
+    """The headline-config kernel (csrc/step_fast64.hpp: f32 outputs, default
+    State flags) against the general kernel (f64 outputs) and the oracle: states
+    equal after the f32 cast, rewards, positions and every table plane identical."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    L = 100.0 if toy else 30.0 * N + 100
+    cfg = bench_config(N, A, L, reward_design=rd, congestion_test=toy, State=dict(num_bins=K),
+                       communication_range=250.0 if N > 8 else 40.0)
+    rng = np.random.default_rng(1000 + N + A + K + rd)
+    B = 40
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    y0 = rng.integers(0, 2, size=(B, N)).astype(np.float64) if toy else np.zeros((B, N))
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    fast, gen = make_env(cfg, B, dtype=torch.float32), make_env(cfg, B, dtype=torch.float64)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (fast, gen):
+        e.reset_topology(x0, y0, v0)
+    orc.reset(x0, y0, v0)
+    for t in range(45):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        of, rf, df = fast.step(a, t)
+        og, rg, dg = gen.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert torch.equal(of, og.to(torch.float32)), t
+        assert torch.equal(df, dg)
+        assert np.array_equal(of.cpu().numpy(), o_state.astype(np.float32)), t
+        if rd in (3, 4):
+            assert torch.allclose(rf.double(), rg, rtol=0, atol=1e-6)
+        else:
+            assert torch.equal(rf, rg.to(torch.float32)), t
+            assert np.array_equal(rf.cpu().numpy(), o_rew.astype(np.float32)), t
+    sf, sg, oe = fast.export_state(), gen.export_state(), orc.export()
+    for k in ("pos_x", "vel", "seq", "age", "x", "y"):
+        assert torch.equal(sf[k], sg[k]), k
+    assert np.array_equal(sf["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(sf["x"].cpu().numpy(), oe["x"])
+    assert np.array_equal(sf["pos_x"].cpu().numpy(), oe["pos_x"])
+    mf, mg = fast.metrics().cpu().numpy(), gen.metrics().cpu().numpy()
+    assert np.array_equal(mf[:, [0, 2, 3]], mg[:, [0, 2, 3]])
+    assert np.allclose(mf[:, 1], mg[:, 1], rtol=1e-12, atol=1e-9)
+    fast.check()
+    gen.check()
