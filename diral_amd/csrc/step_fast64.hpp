@@ -73,7 +73,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int K) {
   l.act = o;   o += 4u * 64;
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;
-  l.mtab = o;  o += 64u * kFastMaxA;        // [vehicle][32] gather-source bytes
+  l.mtab = o;  o += 4u * 64 * kFastMaxA;    // [resource][vehicle] gather source lane * 4 (bpermute address)
   l.total = align_up(o, 16);
   return l;
 }
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   int* s_act = reinterpret_cast<int*>(smem + lay.act);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
-  unsigned char* s_mtab = smem + lay.mtab;
+  int* s_mtab = reinterpret_cast<int*>(smem + lay.mtab);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       bid = bt ? w : bid;
     }
     const bool got = live && (myact != i) && (bid >= 0);
-    s_mtab[lane * kFastMaxA + i] = (unsigned char)(got ? bid : lane);
+    s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
     if constexpr (XB < 16) {
       m = mk;
       while (m) {                                             // receiver set of each transmitter
@@ -292,15 +292,15 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // Vehicle.received_update for every (resource, rx), resources ascending.
   unsigned long long myrx = 0ull;                              // lane w: receiver set of transmitter w
   if constexpr (XB < 16) myrx = s_rx[lane];
-  int m_next = s_mtab[lane * kFastMaxA];
+  int m_next = s_mtab[lane];
 #pragma unroll 1
   for (int i = 0; i < A; ++i) {
     const int m_cur = m_next;
-    m_next = s_mtab[lane * kFastMaxA + ((i + 1 < A) ? i + 1 : i)];
+    m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
     unsigned long long mk = __ballot(myact == i);
     if (mk == 0ull) continue;
     if constexpr (XB > 0) {
-      const int m4 = m_cur << 2;
+      const int m4 = m_cur;
 #pragma unroll
       for (int c = 0; c < XB; ++c) {
         const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);

@@ -20,6 +20,8 @@ pmc() { # name counters...
 EXTRA="$*"
 pmc pmc_sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 pmc pmc_sq2 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+pmc pmc_sq3 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_IFETCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_INSTS_LDS_ATOMIC SQ_ACTIVE_INST_MISC
+pmc pmc_sq4 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 pmc pmc_grbm GRBM_GUI_ACTIVE

@@ -27,7 +27,7 @@ for f in find("*counter_collection.csv"):
     acc = defaultdict(list)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "step_kernel" not in row.get("Kernel_Name", ""):
+            if "step_" not in row.get("Kernel_Name", ""):
                 continue
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):

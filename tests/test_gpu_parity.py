@@ -400,3 +400,24 @@ def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
     assert np.allclose(mf[:, 1], mg[:, 1], rtol=1e-12, atol=1e-9)
     fast.check()
     gen.check()
+
+
+@pytest.mark.parametrize("name", ["g1_step_rd2", "g1_ch_rd2", "g1_design", "g1_flags_all"])
+def test_testenv_shim_on_gpu_reads_like_the_reference(name):
+    """`from diral_amd import TestEnv` driven with the reference's own call
+    sequence (main_test.py:89-164) returns the reference's Python shapes and the
+    recorded values."""
+    from diral_amd import TestEnv
+    g = Golden(name)
+    env = TestEnv(**g.cfg_dict)
+    env.reset_mobility_env()
+    step = {STEP_MY_STEP: env.my_step, STEP_MY_STEP_CH: env.my_step_ch, STEP_DESIGN: env.my_step_design}
+    for i, mode, acts, t, (ep, eps) in g.steps():
+        obs, rews = step[mode](acts, t)
+        state = env.obtain_state(obs, acts, list(rews), ep, eps)
+        assert isinstance(obs, dict) and isinstance(state, list) and len(state) == 4
+        assert np.array_equal(rews, g["rews"][i])
+        assert ulp_diff(np.array([obs[u] for u in range(4)]), g["chobs"][i]) <= DIST_ULP
+        assert ulp_diff(np.array(state), g["state"][i]) <= DIST_ULP
+        assert env.get_x_pos() == list(g["pos_x"][i])
+        assert env.network.get_information_age(t) == list(g["ia"][i])
