@@ -59,7 +59,7 @@ __global__ void velocity_kernel(int total, const uint8_t* draws, uint64_t seed, 
 }
 
 // subject-major packed table -> reference-shaped [env][viewer][subject] planes
-__global__ void export_tables_kernel(int B, int N, int NV, const uint32_t* tkey, const double* tx,
+__global__ void export_tables_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* tx,
                                      const double* pos_y, int32_t* seq, int32_t* age, double* x,
                                      double* y) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,7 +68,7 @@ __global__ void export_tables_kernel(int B, int N, int NV, const uint32_t* tkey,
   const int k = (int)(i % N);
   const int u = (int)((i / N) % N);
   const int b = (int)(i / ((size_t)N * N));
-  const size_t src = ((size_t)b * N + k) * NV + u;
+  const size_t src = ((size_t)b * NR + k) * NV + u;
   const uint32_t w = tkey[src];
   if (seq) seq[i] = (int32_t)(w >> 8);
   if (age) age[i] = (int32_t)(w & 255u);
@@ -76,7 +76,7 @@ __global__ void export_tables_kernel(int B, int N, int NV, const uint32_t* tkey,
   if (y) y[i] = (w >> 8) ? pos_y[(size_t)b * N + k] : 0.0;
 }
 
-__global__ void import_tables_kernel(int B, int N, int NV, const int32_t* seq, const int32_t* age,
+__global__ void import_tables_kernel(int B, int N, int NV, int NR, const int32_t* seq, const int32_t* age,
                                      const double* x, uint32_t* tkey, double* tx) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * N * N;
@@ -84,7 +84,7 @@ __global__ void import_tables_kernel(int B, int N, int NV, const int32_t* seq, c
   const int k = (int)(i % N);
   const int u = (int)((i / N) % N);
   const int b = (int)(i / ((size_t)N * N));
-  const size_t dst = ((size_t)b * N + k) * NV + u;
+  const size_t dst = ((size_t)b * NR + k) * NV + u;
   if (seq || age) {
     uint32_t w = tkey[dst];
     uint32_t s = seq ? (uint32_t)seq[i] : (w >> 8);

@@ -2,15 +2,16 @@
 //
 // Data layout in HBM (one DiralEnv handle, B envs, N vehicles):
 //   pos_x,pos_y,vel  f64 [B][N]          Vehicle.pos_x/pos_y/velocity (vehicle.py:9-14)
-//   tkey             u32 [B][N][NV]      neighbour table, SUBJECT-major: tkey[b][k][u] is
+//   tkey             u32 [B][NR][NV]      neighbour table, SUBJECT-major: tkey[b][k][u] is
 //                                        viewer u's entry about vehicle k, packed
 //                                        (seq_number << 8) | min(last_updated, 255)
-//   tx               f64 [B][N][NV]      the entry's xpos, same indexing
+//   tx               f64 [B][NR][NV]      the entry's xpos, same indexing
 //   (ypos is not stored: it is pos_y[k] once seq > 0, else 0 - SURVEY.md Q7)
 //   la               i32 [B][N][N]       last_arrival_time[tx][rx] (optional)
 //   pf               i32 [B][N]          pf_counter (optional)
 //   metrics          f64 [B][DIRAL_M_COLUMNS]
-// NV = N rounded up to 16 so every subject column starts 64-byte aligned.
+// NV = 64 for N <= 64 (else N rounded up to 16); NR = N rounded up to 16, so every wave
+// owns 16 existing subject rows and table loads/stores need no predicate.
 // The reference stores the table viewer-major (one dict per Vehicle); subject-
 // major makes "all viewers of one subject" contiguous, which is what a
 // wavefront (lane = viewer) loads with one coalesced instruction.
@@ -29,7 +30,7 @@ constexpr uint32_t kErrSeq = 2u;
 
 struct StepParams {
   // geometry
-  int B, N, A, K, S, NV;
+  int B, N, A, K, S, NV, NR;   // NV: padded viewer stride, NR: padded subject rows per env
   uint32_t flags;
   int mode;            // DiralStepMode or kModeObserve
   int reward_design, state_type;

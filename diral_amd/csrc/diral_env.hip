@@ -19,7 +19,7 @@ using namespace diral;
 
 struct DiralEnv {
   DiralCfg cfg;
-  int B = 0, N = 0, A = 0, K = 0, S = 0, NV = 0, vpl = 1;
+  int B = 0, N = 0, A = 0, K = 0, S = 0, NV = 0, NR = 0, vpl = 1;
   int device = 0;
   StepParams base;       // everything that does not change per call
   uint32_t lds_bytes = 0;
@@ -117,7 +117,7 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
   const bool fast = is_fast(p);
   if (fast && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64")) {
     FastParams f;
-    f.N = p.N; f.A = p.A; f.K = p.K; f.NV = p.NV; f.flags = p.flags;
+    f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
@@ -243,6 +243,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   e->B = batch; e->N = cfg->num_users; e->A = cfg->num_channels;
   e->K = cfg->num_bins > 0 ? cfg->num_bins : 1;
   e->NV = e->N <= 64 ? 64 : (int)align_up((uint32_t)e->N, 16);   // one wave lane per viewer, no lane predicate
+  e->NR = (int)align_up((uint32_t)e->N, 16);   // every wave owns 16 existing subject rows
   e->vpl = vpl_for(e->N);
   e->device = device;
   const Offsets off = state_offsets(cfg);
@@ -252,7 +253,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if (hipSetDevice(device) != hipSuccess) return fail(DIRAL_ERR_NO_DEVICE);
 
   const size_t bn = (size_t)e->B * e->N;
-  const size_t tab = bn * e->NV;
+  const size_t tab = (size_t)e->B * e->NR * e->NV;
   auto alloc = [&](void** p, size_t bytes) {
     hipError_t r = hipMalloc(p, bytes);
     if (r == hipSuccess) e->hbm_bytes += (int64_t)bytes;
@@ -296,7 +297,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 
   StepParams& p = e->base;
   std::memset(&p, 0, sizeof(p));
-  p.B = e->B; p.N = e->N; p.A = e->A; p.K = e->K; p.S = e->S; p.NV = e->NV;
+  p.B = e->B; p.N = e->N; p.A = e->A; p.K = e->K; p.S = e->S; p.NV = e->NV; p.NR = e->NR;
   p.flags = cfg->flags;
   p.reward_design = cfg->reward_design; p.state_type = cfg->state_type;
   p.age_limit = cfg->info_age_limit; p.pf_threshold = cfg->pf_threshold; p.pf_penalty = cfg->pf_penalty;
@@ -335,7 +336,7 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   if (!e) return DIRAL_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
-  const size_t tab = bn * e->NV;
+  const size_t tab = (size_t)e->B * e->NR * e->NV;
   HIP_TRY(e, hipMemsetAsync(e->tkey, 0, tab * 4, s));
   HIP_TRY(e, hipMemsetAsync(e->tx, 0, tab * 8, s));
   HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
@@ -420,7 +421,7 @@ int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* ve
   if (vel) HIP_TRY(e, hipMemcpyAsync(vel, e->vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x || tab_y) {
     const size_t total = bn * e->N;
-    hipLaunchKernelGGL(export_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->tkey,
+    hipLaunchKernelGGL(export_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                        e->tx, e->pos_y, tab_seq, tab_age, tab_x, tab_y);
     HIP_TRY(e, hipGetLastError());
   }
@@ -445,7 +446,7 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
   if (vel) HIP_TRY(e, hipMemcpyAsync(e->vel, vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x) {
     const size_t total = bn * e->N;
-    hipLaunchKernelGGL(import_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, tab_seq,
+    hipLaunchKernelGGL(import_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, tab_seq,
                        tab_age, tab_x, e->tkey, e->tx);
     HIP_TRY(e, hipGetLastError());
   }

@@ -16,9 +16,9 @@
 //     position is broadcast with v_readlane; each wave owns the resources
 //     i == wave (mod 4) and walks their transmitters in ascending id with a
 //     strict '<' (the reference's lowest-id tie-break, network.py:387-392);
-//   * gossip merge key[u] = max(key[u], key[m_i(u)]): one ds_bpermute + v_max
-//     per (resource, column); optionally (DIRAL_MERGE_BPERM < 16) part of the
-//     columns go through v_readlane + masked v_max on the VALU instead;
+//   * gossip merge key[u] = max(key[u], key[m_i(u)]): one ds_bpermute + max per
+//     (resource, column PAIR): two columns travel as 16-bit (rank, source) keys in
+//     one register (exactness argument and fallback at the merge loop);
 //   * a compact parameter block (no SGPR spills), 32-bit table offsets, padded
 //     viewer stride (NV = 64) so table loads/stores need no lane predicate;
 //   * when every vehicle has y == 0 (any random topology, network.py:104) the
@@ -31,16 +31,16 @@
 namespace diral {
 
 #ifndef DIRAL_FAST_MINWAVES
-#define DIRAL_FAST_MINWAVES 1
+#define DIRAL_FAST_MINWAVES 8           // <= 64 VGPRs: 8 waves/SIMD (the phases are latency-bound; occupancy pays)
 #endif
-#ifndef DIRAL_MERGE_BPERM
-#define DIRAL_MERGE_BPERM 16           // columns (of 16) merged through ds_bpermute
+#ifndef DIRAL_PACKED_MERGE
+#define DIRAL_PACKED_MERGE 1           // 16-bit packed gossip merge (exact; falls back per wave)
 #endif
 
 constexpr int kFastMaxA = 32;
 
 struct FastParams {
-  int N, A, K, NV;
+  int N, A, K, NR;               // NR: padded subject rows (multiple of 16); viewer stride is 64
   uint32_t flags;
   int reward_design, age_limit, episode_interval;
   double L, Rc, Rb, inv_w;
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
-  unsigned long long* s_rx = reinterpret_cast<unsigned long long*>(smem + lay.rx);
   int* s_act = reinterpret_cast<int*>(smem + lay.act);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
@@ -178,34 +177,38 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   const int KP = K | 1;
   const size_t bN = (size_t)b * N;
   const bool live = lane < N;
-  constexpr int XB = DIRAL_MERGE_BPERM;
   constexpr int NV = 64;                       // padded viewer stride (host guarantees p.NV == 64)
   DIRAL_FSTAMP(0);
 
   // ---- P0: per-vehicle state straight into registers (every wave, lane = vehicle)
-  int myact = -1;
-  double mypx = 0.0, mypy = 0.0, myvel = 0.0;
-  if (live) {
-    myact = p.actions[bN + lane];
-    mypx = p.pos_x[bN + lane];
-    if (!FLAT) mypy = p.pos_y[bN + lane];
-    myvel = p.vel[bN + lane];
-  }
-  // this wave's 16 subject columns; issued AFTER the small loads (in-order vmcnt)
-  unsigned int* const tk = p.tkey + bN * NV;
-  double* const txp = p.tx + bN * NV;
-  const int ncol = min(16, N - wave * 16);     // uniform; <= 0 for idle waves of a small env
+  // (unconditional, index-clamped loads pinned ahead of the table loads: vmcnt
+  // retires in order, so P1 must not sit behind the 16 table words)
+  const size_t vi = bN + (live ? lane : 0);
+  const double my_edge = p.edges[tid < K ? tid : K];        // oldest load: must not sit behind the table
+  int myact = p.actions[vi];
+  double mypx = p.pos_x[vi];
+  double mypy = FLAT ? 0.0 : p.pos_y[vi];
+  double myvel = p.vel[vi];
+  __builtin_amdgcn_sched_barrier(0);
+  if (!live) { myact = -1; mypx = 0.0; mypy = 0.0; myvel = 0.0; }
+  // this wave's 16 subject columns (rows are padded to a multiple of 16, viewers
+  // to 64: no predicate), issued AFTER the small loads (vmcnt retires in order)
+  unsigned int* const tk = p.tkey + ((size_t)b * p.NR + wave * 16) * NV + lane;
+  double* const txp = p.tx + ((size_t)b * p.NR + wave * 16) * NV + lane;
+  const bool has_cols = wave * 16 < p.NR;      // uniform: idle waves of a small env
+  // (unconditional: a branch around the loads would make the compiler wait for
+  // ALL of them at the first use of the per-vehicle values - the waitcnt pass
+  // merges both paths conservatively; idle waves of a small env re-read row 0)
+  const unsigned int* const tk_ld = has_cols ? tk : p.tkey + (size_t)b * p.NR * NV + lane;
   unsigned int w1[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    w1[c] = 0u;
-    if (c < ncol) w1[c] = tk[(wave * 16 + c) * NV + lane];
-  }
+  for (int c = 0; c < 16; ++c) w1[c] = tk_ld[c * NV];
+  __builtin_amdgcn_sched_barrier(0);
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
   const double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;       // network.py:203
   if (wave == 0) { s_act[lane] = myact; s_cnt[lane] = 0u; }
   for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
-  for (int j = tid; j <= K + 1; j += 256) s_edges[j] = p.edges[j < K ? j : K];
+  if (tid <= K + 1) s_edges[tid] = my_edge;                 // K <= 64 < 256 threads
   DIRAL_FSTAMP(1);
 
   // ---- P1: per owned resource i = wave + 4*s: transmitter set, closest in-range
@@ -229,23 +232,27 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
-    if constexpr (XB < 16) {
-      m = mk;
-      while (m) {                                             // receiver set of each transmitter
-        const int w = __builtin_ctzll(m);
-        m &= m - 1;
-        const unsigned long long rx = __ballot(got && bid == w);
-        if (lane == 0) s_rx[w] = rx;
-      }
-    }
     if (c > 1) {                                              // test_env.py:159-199
-      const double rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
+      double rw;
+      if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
+        // inlined common case (reward_design 2, network.py:291-295 weight): a pair
+        // is rewarded 2*[dist > Rc] - 2, more than two transmitters -c
+        if (c == 2) {
+          const int a = __builtin_ctzll(mk);
+          const int bb = __builtin_ctzll(mk & (mk - 1));
+          const double dab = fast_dist<true>(readlane_f64(mypx, a), 0.0, readlane_f64(mypx, bb), 0.0);
+          rw = 2.0 * (double)(dab > p.Rc) - (double)c;       // (0 + d) / 1 == d exactly
+        } else {
+          rw = 0.0 - (double)c;
+        }
+      } else {
+        rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
+      }
       if (lane == 0) s_rv[i] = rw;
     }
   }
   DIRAL_FSTAMP(2);
   __syncthreads();
-  DIRAL_FSTAMP(3);
 
   // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
   if (wave == 0) {
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     if (live) p.pos_x[bN + lane] = mynpx;
   }
-  DIRAL_FSTAMP(4);
+  DIRAL_FSTAMP(3);
 
   // ---- P3a: stamp + gossip merge over this wave's 16 subject columns -------------
   unsigned int key[16];
@@ -283,65 +290,111 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const int k = wave * 16 + c;
     unsigned int w = w1[c];
     unsigned int seq = w >> 8, age = w & 255u;                 // Vehicle.periodic_update (vehicle.py:56-70)
-    if (lane == k) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
+    if (lane == k && live) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
     else age = (age < 255u) ? age + 1u : 255u;
     w = (seq << 8) | age;
     w1[c] = w;
-    key[c] = (w & ~255u) | (unsigned int)lane;
   }
-  // Vehicle.received_update for every (resource, rx), resources ascending.
-  unsigned long long myrx = 0ull;                              // lane w: receiver set of transmitter w
-  if constexpr (XB < 16) myrx = s_rx[lane];
-  int m_next = s_mtab[lane];
-#pragma unroll 1
-  for (int i = 0; i < A; ++i) {
-    const int m_cur = m_next;
-    m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
-    unsigned long long mk = __ballot(myact == i);
-    if (mk == 0ull) continue;
-    if constexpr (XB > 0) {
-      const int m4 = m_cur;
+  // Vehicle.received_update for every (resource, rx), resources ascending:
+  // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
+  //
+  // PACKED path (DIRAL_PACKED_MERGE): two columns share one register as 16-bit keys
+  // (rank << 6) | source, rank = 1023 - lag, lag = t_k - seq (t_k = the subject's own
+  // fresh sequence number), merged with v_pk_max_u16 - half the LDS and VALU work.
+  // rank is order-preserving and injective for lag < 1023, and an update can only
+  // raise an entry to a rank > 0, so the result is exact iff no entry of the wave
+  // has lag >= 1023 with seq != 0 (never-heard entries, seq == 0, all share rank 0).
+  // Otherwise (imported or very stale tables) the wave takes the 32-bit path.
+  bool packed_ok = false;
+#if DIRAL_PACKED_MERGE
+  unsigned int kp[8];
+  {
+    bool bad = false;
 #pragma unroll
-      for (int c = 0; c < XB; ++c) {
+    for (int j = 0; j < 8; ++j) {
+      unsigned int k16[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 2 * j + h;
+        const unsigned int seq = w1[c] >> 8;
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)seq, (wave * 16 + c) & 63);
+        const unsigned int lag = tk_own - seq;
+        bad = bad || (lag >= 1023u && seq != 0u);
+        const unsigned int rank = lag < 1023u ? 1023u - lag : 0u;
+        k16[h] = (rank << 6) | (unsigned int)lane;
+      }
+      kp[j] = k16[0] | (k16[1] << 16);
+    }
+    packed_ok = (__ballot(bad) == 0ull);
+  }
+  if (packed_ok) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    int m_next = s_mtab[lane];
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+      const int m4 = m_next;
+      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
+      if (__ballot(myact == i) == 0ull) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kp[j]);
+        const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, kp[j]), __builtin_bit_cast(u16x2, v));
+        kp[j] = __builtin_bit_cast(unsigned int, r);
+      }
+    }
+    // back to (seq << 8) | source: seq = t_k - (1023 - rank); rank 0 never results
+    // from an update, so such an entry keeps its own word
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const unsigned int k16 = (kp[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+      const unsigned int rank = k16 >> 6, src = k16 & 63u;
+      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)(w1[c] >> 8), (wave * 16 + c) & 63);
+      const unsigned int seqf = tk_own - 1023u + rank;
+      key[c] = rank ? ((seqf << 8) | src) : ((w1[c] & ~255u) | (unsigned int)lane);
+    }
+  }
+#endif
+  if (!packed_ok) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) key[c] = (w1[c] & ~255u) | (unsigned int)lane;
+    int m_next = s_mtab[lane];
+#pragma unroll 1
+    for (int i = 0; i < A; ++i) {
+      const int m4 = m_next;
+      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
+      if (__ballot(myact == i) == 0ull) continue;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
         const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
         key[c] = max(key[c], v);
       }
     }
-    if constexpr (XB < 16) {
-      while (mk) {
-        const int w = __builtin_ctzll(mk);
-        mk &= mk - 1;
-        const unsigned long long rx = readlane_u64(myrx, w);
-        if (rx == 0ull) continue;
-        unsigned int sv[XB < 16 ? 16 - XB : 1];
-#pragma unroll
-        for (int c = XB; c < 16; ++c) sv[c - XB] = (unsigned int)__builtin_amdgcn_readlane((int)key[c], w);
-        if (__builtin_amdgcn_inverse_ballot_w64(rx)) {
-#pragma unroll
-          for (int c = XB; c < 16; ++c) key[c] = max(key[c], sv[c - XB]);
-        }
-      }
-    }
   }
-  DIRAL_FSTAMP(5);
+  DIRAL_FSTAMP(4);
 
   // ---- P3b: xpos follows the winning sequence number; histogram ------------------
   unsigned int mycnt = 0u;
   const double inv_w = p.inv_w;
   unsigned int* const hrow = s_hist + lane * KP;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    if (c >= ncol) break;
+  // (a rolled loop with uniform register indexing: measured faster than the
+  // unrolled form, which costs 27 VGPRs = 3 waves/SIMD of occupancy; the next
+  // column's xpos load is issued one iteration ahead)
+  const int ncol = has_cols ? 16 : 0;
+  double x_next = has_cols ? txp[0] : 0.0;
+#pragma unroll 1
+  for (int c = 0; c < ncol; ++c) {
+    {
     const int k = wave * 16 + c;
-    const int off = k * NV + lane;
+    const int off = c * NV;
     const unsigned int kf = key[c], w = w1[c];
     const bool upd = ((kf ^ w) >> 8) != 0u;
-    double xo = txp[off];
-    if (lane == k) xo = mypx;                                   // own stamp (vehicle.py:63)
+    const double x_cur = x_next;
+    if (c + 1 < ncol) x_next = txp[off + NV];
+    const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
     const int src4 = (int)(kf & 255u) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xo));
-    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xo));
-    const double xg = upd ? __hiloint2double(hi, lo) : xo;
+    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
+    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
+    const double xg = upd ? __hiloint2double(hi, lo) : xs;
     const unsigned int wn = upd ? (kf & ~255u) : w;
     tk[off] = wn;
     if (upd || lane == k) txp[off] = xg;
@@ -349,7 +402,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     double y1 = 0.0;
     if (!FLAT) { const double pyk = readlane_f64(mypy, k); y1 = (wn >> 8) ? pyk : 0.0; }
     const double d = fast_dist<FLAT>(xg, y1, mynpx, mypy);
-    const bool ok = live && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    const bool ok = live && (k < N) && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
     if (ok) {
       const double v = (xg - mynpx > 0.0) ? d : -d;
       int est = (int)((v + p.Rb) * inv_w);
@@ -359,11 +412,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       atomicAdd(&hrow[bin], 1u);
       mycnt += 1u;
     }
+    }
   }
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
-  DIRAL_FSTAMP(6);
+  DIRAL_FSTAMP(5);
   __syncthreads();
-  DIRAL_FSTAMP(7);
+  DIRAL_FSTAMP(6);
 
   // ---- P4: state = [one-hot(action) (A) | histogram (K)], float32 ----------------
   const int S = A + K;
@@ -399,6 +453,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       out[e] = val;
     }
   }
+  DIRAL_FSTAMP(7);
 }
 
 }  // namespace diral

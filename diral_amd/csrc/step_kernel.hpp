@@ -203,6 +203,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
   const bool use_pf = !FAST && (p.flags & DIRAL_F_PROPORTIONAL_FAIR);
   const int out_f64 = FAST ? 0 : p.out_f64;
   const size_t bN = (size_t)b * N;
+  const size_t bR = (size_t)b * p.NR;   // table row base (padded rows)
 
   DIRAL_STAMP(0);
   // ---- prefetch (N <= 64): this wave's 16 table columns, before any compute --
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
       for (int c = 0; c < 16; ++c) {
         const int k = wave * 16 + c;
         const bool ok = (k < N) && (lane < N);
-        const size_t idx = (bN + (ok ? k : 0)) * NV + (ok ? lane : 0);
+        const size_t idx = (bR + (ok ? k : 0)) * NV + (ok ? lane : 0);
         const unsigned int w = p.tkey[idx];
         const double x = p.tx[idx];
         pre_w[c] = ok ? w : 0u;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
           const int u = lane + 64 * j;
           unsigned int w = 0u;
           if constexpr (VPL == 1 && DIRAL_PREFETCH) w = pre_w[c];
-          else if (k < N && u < N) w = p.tkey[(bN + k) * NV + u];
+          else if (k < N && u < N) w = p.tkey[(bR + k) * NV + u];
           if (do_step) {
             // Vehicle.periodic_update (vehicle.py:56-70)
             unsigned int seq = w >> 8, age = w & 255u;
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
           const bool upd = ((kf ^ w) >> 8) != 0u;
           double xo = 0.0;
           if constexpr (VPL == 1 && DIRAL_PREFETCH) xo = pre_x[c];
-          else if (u < N) xo = p.tx[(bN + k) * NV + u];
+          else if (u < N) xo = p.tx[(bR + k) * NV + u];
           if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
           double xg = xo;
           if constexpr (VPL == 1) {
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
             const int hi = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2hiint(xo));
             if (upd) xg = __hiloint2double(hi, lo);
           } else {
-            if (upd) xg = ((int)src == k) ? pxk : p.tx[(bN + k) * NV + src];
+            if (upd) xg = ((int)src == k) ? pxk : p.tx[(bR + k) * NV + src];
           }
           xn[j] = xg;
           wn[j] = upd ? (kf & ~255u) : w;
@@ -562,8 +563,8 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
           for (int j = 0; j < VPL; ++j) {
             const int u = lane + 64 * j;
             if (u < N) {
-              p.tkey[(bN + k) * NV + u] = wn[j];
-              if (changed[j] || u == k) p.tx[(bN + k) * NV + u] = xn[j];
+              p.tkey[(bR + k) * NV + u] = wn[j];
+              if (changed[j] || u == k) p.tx[(bR + k) * NV + u] = xn[j];
             }
           }
         }

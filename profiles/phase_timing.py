@@ -3,8 +3,8 @@
 
   DIRAL_LIB=diral_amd/variants/timing.so python profiles/phase_timing.py
 
-Stamps (s_memtime, per wave): 0 start, 1 after P0 barrier, 2 end P1, 3 after
-barrier, 4 end P2, 5 end merge, 6 end finalize/hist, 7 after barrier.
+Stamps (s_memtime, per wave): 0 start, 1 end P0, 2 end P1, 3 after barrier + P2,
+4 end merge, 5 end finalize/hist, 6 after barrier, 7 end of P4 (kernel end).
 """
 import ctypes
 import os
@@ -29,13 +29,13 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros((B, 4, 8), np.uint64)
 assert fn(env._h, buf.ctypes.data_as(ctypes.c_void_p), 4) == 0
 t = buf.astype(np.int64)
-names = ["P0 load+barrier", "P1 closest-tx", "wait barrier", "P2 rewards", "P3 merge", "P3 finalize+hist", "wait barrier"]
+names = ["P0 loads/init", "P1 closest-tx", "barrier+P2", "P3 merge", "P3 finalize+hist", "wait barrier", "P4 output"]
 d = np.diff(t, axis=2)
 print("B=%d; mean cycles per wave per phase (s_memtime ticks), by wave:" % B)
 for i, n in enumerate(names):
     print("  %-18s %s   all=%.0f" % (n, " ".join("%7.0f" % d[:, w, i].mean() for w in range(4)), d[:, :, i].mean()))
 life = (t[:, :, 7] - t[:, :, 0])
-print("  wave lifetime to last barrier: mean %.0f  p50 %.0f  p99 %.0f" % (life.mean(), np.median(life), np.percentile(life, 99)))
+print("  wave lifetime: mean %.0f  p50 %.0f  p99 %.0f" % (life.mean(), np.median(life), np.percentile(life, 99)))
 span = t[:, :, 7].max() - t[:, :, 0].min()
 print("  kernel span %d ticks" % span)
 start = t[:, 0, 0] - t[:, 0, 0].min()

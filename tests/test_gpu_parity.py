@@ -421,3 +421,45 @@ def test_testenv_shim_on_gpu_reads_like_the_reference(name):
         assert ulp_diff(np.array(state), g["state"][i]) <= DIST_ULP
         assert env.get_x_pos() == list(g["pos_x"][i])
         assert env.network.get_information_age(t) == list(g["ia"][i])
+
+
+@pytest.mark.parametrize("stale_frac", [0.0, 0.02, 0.5])
+def test_fast64_packed_merge_and_its_fallback_on_stale_tables(stale_frac):
+    """The fast kernel merges 16-bit (rank, source) keys when every entry of a
+    wave is younger than 1023 slots (or never heard) and falls back to 32-bit
+    keys otherwise.  Imported tables with arbitrarily stale sequence numbers
+    exercise both, per wave, against the oracle."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = c2_config().replace(track_arrival=False)
+    B, N, A, T0 = 12, 64, 32, 5000
+    rng = np.random.default_rng(int(stale_frac * 1000) + 3)
+    x0 = rng.integers(0, 2000, size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    seq = T0 - rng.integers(0, 40, size=(B, N, N))                      # fresh-ish entries
+    stale = rng.random((B, N, N)) < stale_frac
+    seq = np.where(stale, rng.integers(0, T0 - 1023, size=(B, N, N)), seq)  # lag >= 1023, some seq == 0
+    seq[:, np.arange(N), np.arange(N)] = T0
+    age = rng.integers(0, 40, size=(B, N, N))
+    # a table entry is the subject's stamp at that sequence number, so entries about the same
+    # subject with equal seq carry equal xpos in every reachable state; keep that invariant
+    kk = np.arange(N)[None, None, :]
+    bb = np.arange(B)[:, None, None]
+    x = ((kk * 7919 + seq * 104729 + bb * 31) % 200000) / 100.0
+    fast = make_env(cfg, B, dtype=torch.float32)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    fast.reset_topology(x0, None, v0)
+    fast.import_state(seq=seq, age=age, x=x)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    orc.import_state(seq=seq, age=age, x=x, y=np.zeros((B, N, N)))
+    for t in range(30):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = fast.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert np.array_equal(obs.cpu().numpy(), o_state.astype(np.float32)), t
+    st, oe = fast.export_state(), orc.export()
+    assert np.array_equal(st["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    fast.check()
