@@ -89,7 +89,7 @@ def cpu_baseline(cfg, seconds_target: float = 12.0):
         t += 1
         slots += 1
         el = time.perf_counter() - t0
-        if el >= seconds_target or slots >= 2000:
+        if el >= seconds_target or slots >= 20000:
             break
     return {
         "value": B * N * slots / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
@@ -228,7 +228,9 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args.workload),
-                "kernel": "diral::step_kernel<%d>" % (1 if N <= 64 else 2 if N <= 128 else 4),
+                "kernel": ("diral::step_fast64_kernel<true>" if (N <= 64 and A <= 32 and args.out_dtype == "f32")
+                           else "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
+                                                               "true" if args.out_dtype == "f32" else "false")),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_launch,
             },
