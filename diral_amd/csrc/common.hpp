@@ -33,7 +33,7 @@ struct StepParams {
   int B, N, A, K, S, NV, NR;   // NV: padded viewer stride, NR: padded subject rows per env
   uint32_t flags;
   int mode;            // DiralStepMode or kModeObserve
-  int reward_design, state_type;
+  int reward_design, state_type, posdist_type;
   int age_limit, pf_threshold;
   double pf_penalty;
   double L, H, Rc, Rb, hist_inv_width;   // K / (Rb - (-Rb)): bin-index estimate only

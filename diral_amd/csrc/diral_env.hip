@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "step_kernel.hpp"
 #include "step_fast64.hpp"
+#include "posdist_kernel.hpp"
 
 using namespace diral;
 
@@ -33,6 +34,7 @@ struct DiralEnv {
   double* metrics = nullptr;
   uint32_t* err = nullptr;
   double* edges = nullptr;
+  double* edges1 = nullptr;   // np.linspace(-1, 1, K+1) for the type-1 histogram
   int64_t hbm_bytes = 0;
   bool flat_y = true;      // every pos_y == 0 (random topologies, network.py:104): |dx| distance path
   uint32_t* yflag = nullptr;
@@ -109,7 +111,7 @@ hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
 bool is_fast(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
-  return (p.flags & ~ignore) == want && p.mode == DIRAL_STEP_MY_STEP && !p.out_f64 &&
+  return (p.flags & ~ignore) == want && p.posdist_type == 2 && p.mode == DIRAL_STEP_MY_STEP && !p.out_f64 &&
          p.state_out != nullptr && p.chobs_out == nullptr;
 }
 
@@ -146,6 +148,20 @@ hipError_t set_lds_attr(uint32_t lds) {
 }
 
 int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
+
+// Secondary observation modes (a15/a16) run as their own launch after the step.
+hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_t s) {
+  const bool full = (p.flags & DIRAL_F_ADD_POSDIST) != 0;
+  const bool type1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1;
+  if (!p.state_out || !(full || type1)) return hipSuccess;
+  PosdistParams q;
+  q.N = p.N; q.A = p.A; q.K = p.K; q.S = p.S; q.NV = p.NV; q.NR = p.NR; q.flags = p.flags;
+  q.posdist_type = p.posdist_type; q.age_limit = p.age_limit; q.out_f64 = p.out_f64;
+  q.off_posdist = p.off_posdist; q.off_hist = p.off_hist;
+  q.pos_x = p.pos_x; q.pos_y = p.pos_y; q.tkey = p.tkey; q.tx = p.tx; q.edges1 = e->edges1; q.state_out = p.state_out;
+  hipLaunchKernelGGL(posdist_kernel, dim3(p.B), dim3(64 * kPdWaves), posdist_lds_bytes(p.N, p.K), s, q);
+  return hipGetLastError();
+}
 
 // Recompute DiralEnv::flat_y (all pos_y == 0) after pos_y was written by the
 // caller.  Synchronises the stream; only reset/import call it, never step.
@@ -213,9 +229,7 @@ int diral_env_validate(const DiralCfg* c) {
     if (c->posdist_type != 1 && c->posdist_type != 2) return DIRAL_ERR_BAD_CONFIG;  // test_env.py:555-560
     if (c->num_bins < 1 || !(c->bin_range > 0)) return DIRAL_ERR_BAD_CONFIG;
     if (c->num_bins > DIRAL_MAX_BINS) return DIRAL_ERR_UNSUPPORTED;
-    if (c->posdist_type == 1) return DIRAL_ERR_UNSUPPORTED;   // a15: not built yet
   }
-  if (has(c, DIRAL_F_ADD_POSDIST)) return DIRAL_ERR_UNSUPPORTED;  // a16: not built yet
   if (c->num_users > DIRAL_MAX_USERS || c->num_channels > DIRAL_MAX_CHANNELS) return DIRAL_ERR_UNSUPPORTED;
   const int vpl = vpl_for(c->num_users);
   const LdsLayout l = lds_layout(64 * vpl, c->num_channels, c->num_bins > 0 ? c->num_bins : 1, vpl, 4 * vpl);
@@ -270,6 +284,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->err, 4));
   CREATE_TRY(alloc((void**)&e->yflag, 4));
   CREATE_TRY(alloc((void**)&e->edges, (size_t)(e->K + 1) * 8));
+  CREATE_TRY(alloc((void**)&e->edges1, (size_t)(e->K + 1) * 8));
   if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
   if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
 
@@ -278,6 +293,10 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   for (int i = 0; i < e->K; ++i)   // np.histogram: "Too many bins for data range"
     if (!(edges[i] < edges[i + 1])) return fail(DIRAL_ERR_BAD_CONFIG);
   CREATE_TRY(hipMemcpy(e->edges, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
+  np_linspace(-1.0, 1.0, e->K + 1, edges);
+  CREATE_TRY(hipMemcpy(e->edges1, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
+  CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)posdist_lds_bytes(e->N, e->K)));
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
   CREATE_TRY(hipMemset(e->vel, 0, bn * 8));
@@ -299,7 +318,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   std::memset(&p, 0, sizeof(p));
   p.B = e->B; p.N = e->N; p.A = e->A; p.K = e->K; p.S = e->S; p.NV = e->NV; p.NR = e->NR;
   p.flags = cfg->flags;
-  p.reward_design = cfg->reward_design; p.state_type = cfg->state_type;
+  p.reward_design = cfg->reward_design; p.state_type = cfg->state_type; p.posdist_type = cfg->posdist_type;
   p.age_limit = cfg->info_age_limit; p.pf_threshold = cfg->pf_threshold; p.pf_penalty = cfg->pf_penalty;
   p.L = cfg->highway_length; p.H = cfg->highway_height; p.Rc = cfg->communication_range;
   p.Rb = cfg->bin_range;
@@ -320,7 +339,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   (void)hipSetDevice(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
@@ -367,6 +386,7 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
   p.chobs_in = nullptr; p.rew_in = nullptr;
   HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
+  HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
 }
 
@@ -381,6 +401,7 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
   p.chobs_in = chobs_in; p.rew_in = rew_in;
   HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
+  HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
 }
 

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
   const int mode = FAST ? (int)DIRAL_STEP_MY_STEP : p.mode;
   const bool do_step = FAST || mode != kModeObserve;
   const bool piggy = FAST || (p.flags & DIRAL_F_ADD_POSDIST_PIGGY);
-  const bool want_hist = FAST || (piggy && p.state_out != nullptr && p.off_hist >= 0);
+  // type-1 histograms (network.py:432-471) are built by posdist_kernel.hpp after this launch
+  const bool want_hist = FAST || (piggy && p.posdist_type == 2 && p.state_out != nullptr && p.off_hist >= 0);
   const bool track_la = !FAST && (p.flags & DIRAL_F_TRACK_ARRIVAL) && p.la != nullptr;
   const bool want_prr = !FAST && do_step && (mode == DIRAL_STEP_MY_STEP_CH ||
                                               (mode == DIRAL_STEP_MY_STEP && (p.flags & DIRAL_F_TRACK_PRR)));
@@ -671,9 +672,12 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
         if (do_step) write = false;   // written in P1
         else val = p.chobs_in ? p.chobs_in[(bN + u) * A + (s - p.off_chobs)] : 0.0;
       } else if (p.off_hist >= 0 && s >= p.off_hist && s < p.off_hist + K) {
+        if (p.posdist_type != 2) write = false;   // written by posdist_kernel
         const unsigned int n = s_cnt[u];
         const unsigned int h = s_hist[u * KP + (s - p.off_hist)];
         val = n ? (double)h / (double)n : 0.0;                                   // network.py:501
+      } else if (p.off_posdist >= 0 && s >= p.off_posdist && s < p.off_posdist + N - 1) {
+        write = false;                            // written by posdist_kernel
       } else if (s == p.off_rew) {
         val = s_rew[u];
       } else if (s == p.off_idx) {

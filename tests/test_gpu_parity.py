@@ -23,7 +23,7 @@ EXP_ATOL = 2e-15   # device exp() vs glibc exp(): <= 1-2 ulp of exp(x) <= e; the
                    # from it (1-exp(1-R), test_env.py:414) cancel, so the bound is absolute
 DIST_ULP = 1       # sqrt(x*x+y*y) vs sqrt(pow(x,2)+pow(y,2))
 
-UNBUILT = {"g1_posdist_full", "g1_posdist_type1"}   # secondary obs modes, SURVEY a15/a16 (next rows)
+UNBUILT = set()
 
 
 def make_env(cfg, B, mode=STEP_MY_STEP, dtype=torch.float64):
@@ -84,6 +84,7 @@ def test_golden_replay_on_gpu(name):
                 K = cfg.State.num_bins
                 off = (cfg.num_channels if cfg.State.action_index == "binary" else 1) if cfg.State.add_action else 0
                 off += cfg.num_channels if cfg.State.add_channel_obs else 0
+                off += cfg.num_users - 1 if cfg.State.add_positional_dist else 0
                 assert np.array_equal(obs[b][:, off:off + K], ref_state[:, off:off + K]), "histogram bins"
             assert done[b] == ((t % cfg.episode_interval) == cfg.episode_interval - 1)
         if i in g.vel_updates:
@@ -463,3 +464,15 @@ def test_fast64_packed_merge_and_its_fallback_on_stale_tables(stale_frac):
     assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
     assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
     fast.check()
+
+
+@pytest.mark.parametrize("N,A,full,ptype", [(64, 32, True, 2), (64, 32, False, 1), (64, 32, True, 1),
+                                            (70, 9, True, 1), (130, 40, True, 2), (200, 16, False, 1),
+                                            (5, 3, True, 1)])
+def test_secondary_observation_modes_vs_oracle(N, A, full, ptype):
+    """add_positional_dist (sorted signed true distances / max)
+    and add_positional_dist_type 1 (inf-norm scaled, weighted np.histogram with
+    explicit edges = sequential prefix sums), bit-exact against the oracle."""
+    cfg = bench_config(N, A, 30.0 * N + 50, State=dict(add_positional_dist=full, add_positional_dist_type=ptype,
+                                                        num_bins=20 if N != 70 else 7))
+    random_rollout(cfg, B=5, T=26, seed=500 + N + ptype)
