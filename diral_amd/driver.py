@@ -1,0 +1,162 @@
+"""The env-facing half of the reference driver, vectorised.
+
+``main_test.marl_test`` (main_test.py:86-236) interleaves the TF agent with a
+fixed sequence of env calls and some reward post-processing.  This module keeps
+that sequence - bootstrap, prefill, slot loop, information age, reward shaping,
+episode boundary - for B envs at once on top of :class:`VecV2VEnv` (or any
+object with its method names), so a PyTorch agent can be dropped where the
+reference's ``mainDRQN`` sat.  The agent itself is out of scope.
+
+    loop = DriverLoop(env, global_reward_avg=True, episode_interval=25)
+    state = loop.bootstrap()                         # main_test.py:89-94
+    for _ in range(prefill): state = loop.prefill_step(env.sample())     # :99-114
+    for t in range(time_slots):
+        out = loop.slot(policy(state), t)            # :119-236, one fused launch + small torch ops
+        state = out["next_state"]
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+
+def calculate_ia_penalty(ia: torch.Tensor) -> torch.Tensor:
+    """utils/misc.py:1-12: sum over bins of (i+1)*ia[i] (bins with ia > 0);
+    ia [..., 100] integer -> [...] int64."""
+    ia = torch.as_tensor(ia).to(torch.int64)
+    w = torch.arange(1, ia.shape[-1] + 1, dtype=torch.int64, device=ia.device)
+    return (torch.clamp(ia, min=0) * w).sum(-1)
+
+
+def np_sum_lastdim(a: torch.Tensor) -> torch.Tensor:
+    """Sum over the last axis in NumPy's order (`np.sum(reward)`, main_test.py:171):
+    numpy/_core/src/umath/loops_utils.h pairwise_sum - fewer than 8 elements
+    sequentially, otherwise eight running accumulators combined as
+    ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail, blocks above 128
+    elements split recursively.  Float addition is not associative; keeping the
+    order keeps the driver's shaped rewards bit-identical."""
+    n = a.shape[-1]
+    if n < 8:
+        res = torch.zeros_like(a[..., 0])
+        for i in range(n):
+            res = res + a[..., i]
+        return res
+    if n <= 128:
+        r = [a[..., j] for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = r[j] + a[..., i + j]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res = res + a[..., i]
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return np_sum_lastdim(a[..., :n2]) + np_sum_lastdim(a[..., n2:])
+
+
+class DriverLoop:
+    """Call-sequence and reward post-processing of main_test.py:86-236."""
+
+    def __init__(self, env: Any, enable_channel: bool = False, global_reward_avg: bool = False,
+                 ia_averaging: bool = False, ia_penalty_enable: bool = False, ia_penalty_threshold: int = 5,
+                 ia_penalty_value: float = -10, episode_interval: int = 25,
+                 eps_init: float = 0.99, eps_decay: float = 0.9992, eps_min: float = 0.001):
+        self.env = env
+        self.enable_channel = enable_channel                  # main_test.py:40
+        self.global_reward_avg = global_reward_avg            # :38
+        self.ia_averaging = ia_averaging                      # :43
+        self.ia_penalty_enable = ia_penalty_enable            # :42
+        self.ia_penalty_threshold = ia_penalty_threshold      # :50
+        self.ia_penalty_value = ia_penalty_value              # :51
+        self.episode_interval = episode_interval              # :31
+        self.eps, self.eps_decay, self.eps_min = eps_init, eps_decay, eps_min   # algorithms/policies.py:38-77
+        self.episode = 0
+        self.N = env.get_total_users()
+        self.A = env.get_action_space()
+        self._rews0: Optional[torch.Tensor] = None
+        self._sum_ia_prev: Optional[torch.Tensor] = None
+        self._pen_counter: Optional[torch.Tensor] = None
+        self._prev_actions: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def _t(x) -> torch.Tensor:
+        return x if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+
+    def _actions(self, a) -> torch.Tensor:
+        a = self._t(a)
+        return a if a.dim() == 2 else a.unsqueeze(0)
+
+    # main_test.py:89-94
+    def bootstrap(self, action=None) -> torch.Tensor:
+        action = self.env.sample() if action is None else action
+        obs, rews = self.env.my_step(action, 0)
+        self._rews0 = self._t(rews).clone()
+        state = self._t(self.env.obtain_state(obs, action, self._rews0)).clone()
+        return state
+
+    # main_test.py:99-114 (the stored reward is the stale bootstrap `rews`, :110-112)
+    def prefill_step(self, action) -> torch.Tensor:
+        if self.enable_channel:
+            obs, _ = self.env.my_step_ch(action, 0)
+        else:
+            obs, _ = self.env.my_step_design(action, 0)
+        return self._t(self.env.obtain_state(obs, action, self._rews0)).clone()
+
+    # main_test.py:119-236, everything between the agent's action and memory.add
+    def slot(self, action, time_step: int, want_ia: Optional[bool] = None) -> Dict[str, Any]:
+        env = self.env
+        if self.enable_channel:
+            obs, reward = env.my_step_ch(action, time_step)                  # :144
+        else:
+            obs, reward = env.my_step(action, time_step)                     # :146
+        reward = self._t(reward).clone()
+        raw = reward.clone()
+        out: Dict[str, Any] = {}
+        need_ia = self.ia_averaging if want_ia is None else want_ia
+        ia_penalty = None
+        if need_ia:
+            ia = self._t(env.info_age(time_step))                            # :150
+            ia_sum = calculate_ia_penalty(ia)                                # :151
+            out["ia"], out["ia_sum"] = ia, ia_sum
+            if self.ia_averaging:                                            # :153-160
+                prev = self._sum_ia_prev if self._sum_ia_prev is not None else torch.zeros_like(ia_sum)
+                ia_penalty = torch.where(ia_sum > prev, -1, torch.where(ia_sum < prev, 1, 0)).to(reward.dtype)
+                self._sum_ia_prev = ia_sum
+                out["ia_penalty"] = ia_penalty
+        next_state = self._t(env.obtain_state(obs, action, reward, self.episode, self.eps)).clone()   # :164
+        sum_r = np_sum_lastdim(reward)                                       # :171 (NumPy's summation order)
+        collision = self.A - sum_r                                           # :178
+        a = self._actions(action).to(reward.device)
+        if ia_penalty is not None:
+            reward = reward + ia_penalty.unsqueeze(-1)                       # :190-192
+        if self.ia_penalty_enable:                                           # :194-203
+            if self._pen_counter is None:
+                self._pen_counter = torch.zeros_like(a, dtype=torch.int64)
+                self._prev_actions = torch.full_like(a, -1)
+            stuck = (reward < 1) & (a == self._prev_actions)
+            self._pen_counter = torch.where(stuck, self._pen_counter + 1, torch.zeros_like(self._pen_counter))
+            reward = torch.where(self._pen_counter > self.ia_penalty_threshold,
+                                 torch.as_tensor(float(self.ia_penalty_value), dtype=reward.dtype, device=reward.device),
+                                 reward)
+            self._prev_actions = a.clone()
+        if self.global_reward_avg:
+            reward = reward + (sum_r / self.N).unsqueeze(-1)                 # :205-206
+        episode_end = (time_step % self.episode_interval) == self.episode_interval - 1   # :226
+        out.update(next_state=next_state, reward=reward, raw_reward=raw, sum_r=sum_r, collision=collision,
+                   episode_end=episode_end, episode=self.episode, eps=self.eps)
+        return out
+
+    # main_test.py:226-233: call when out["episode_end"]; `draws` are the
+    # random.randrange(1,4) values of Network.update_velocity (None = device RNG)
+    def end_episode(self, draws=None) -> None:
+        self.episode += 1
+        self.eps = max(self.eps * self.eps_decay, self.eps_min)
+        if draws is None:
+            self.env.update_velocity()
+        else:
+            self.env.update_velocity(draws)

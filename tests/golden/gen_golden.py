@@ -188,6 +188,109 @@ def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
         name, N, A, len(steps), os.path.getsize(path) / 1024))
 
 
+def run_driver_case(name, cfg, init, n_prefill, T, enable_channel, global_reward_avg, ia_averaging,
+                    episode_interval, seed, ia_penalty_enable=False, ia_penalty_threshold=5, ia_penalty_value=-10):
+    """The env-facing call sequence of main_test.marl_test (main_test.py:86-236)
+    with the TF agent replaced by recorded random actions: bootstrap, prefill with
+    my_step_design (or my_step_ch), slot loop with information age, reward shaping,
+    episode boundaries.  utils/misc.calculate_ia_penalty is the reference's own."""
+    sys.path.insert(0, "/root/reference")
+    from utils.misc import calculate_ia_penalty
+    rng = np.random.default_rng(seed)
+    env = make_env(cfg)
+    N, A = env.NUM_USERS, env.NUM_CHANNELS
+    if isinstance(init, str) and init == "fixed4":
+        env.reset_mobility_env()
+    else:
+        set_init(env, *init)
+    x0 = np.array([float(v.pos_x) for v in env.network.vehicles])
+    y0 = np.array([float(v.pos_y) for v in env.network.vehicles])
+    v0 = np.array([float(v.velocity) for v in env.network.vehicles])
+    rec = dict(boot_action=None, boot_state=None, pre_actions=[], pre_states=[], actions=[], states=[],
+               raw_reward=[], shaped_reward=[], sum_r=[], collision=[], ia=[], ia_sum=[], ia_pen=[],
+               episode_end=[], vel_draws=[], episode=[], eps=[])
+    with contextlib.redirect_stdout(io.StringIO()):
+        action = rng.integers(0, A, size=N).astype(np.int32)           # env.sample() (main_test.py:89)
+        obs, rews = env.my_step(action, 0)                               # :92
+        rews = list(rews)
+        state = env.obtain_state(obs, action, rews)                      # :94
+        rec["boot_action"], rec["boot_state"] = action, np.array(state, dtype=np.float64)
+        for ii in range(n_prefill):                                      # :99-114
+            action = rng.integers(0, A, size=N).astype(np.int32)
+            if enable_channel:
+                obs, reward = env.my_step_ch(action, 0)
+            else:
+                obs, reward = env.my_step_design(action, 0)
+            next_state = env.obtain_state(obs, action, rews)             # stale `rews` (main_test.py:110)
+            rec["pre_actions"].append(action)
+            rec["pre_states"].append(np.array(next_state, dtype=np.float64))
+        episode, eps, sum_ia_prev = 0, 0.99, 0
+        pen_counter = np.zeros(N, int)
+        prev_actions = -np.ones(N, int)
+        for time_step in range(T):                                       # :119
+            action = rng.integers(0, A, size=N).astype(np.int32)
+            if enable_channel:
+                obs, reward = env.my_step_ch(action, time_step)          # :144
+            else:
+                obs, reward = env.my_step(action, time_step)             # :146
+            raw = np.array(reward, dtype=np.float64)
+            ia = env.network.get_information_age(time_step)             # :150
+            ia_sum = calculate_ia_penalty(ia)                            # :151
+            ia_penalty = 0
+            if ia_averaging:                                             # :153-160
+                if ia_sum > sum_ia_prev:
+                    ia_penalty = -1
+                elif ia_sum < sum_ia_prev:
+                    ia_penalty = 1
+                sum_ia_prev = ia_sum
+            next_state = env.obtain_state(obs, action, reward, episode, eps)   # :164
+            sum_r = np.sum(reward)                                       # :171
+            collision = A - sum_r                                        # :178
+            for i in range(len(reward)):                                 # :188-206
+                if ia_averaging:
+                    reward[i] += ia_penalty
+                if ia_penalty_enable:
+                    if reward[i] < 1 and action[i] == prev_actions[i]:
+                        pen_counter[i] += 1
+                    else:
+                        pen_counter[i] = 0
+                    if pen_counter[i] > ia_penalty_threshold:
+                        reward[i] = ia_penalty_value
+                    prev_actions[i] = action[i]
+                if global_reward_avg:
+                    reward[i] = reward[i] + sum_r / len(reward)
+            end = (time_step % episode_interval == episode_interval - 1)  # :226
+            draws = np.zeros(N, np.uint8)
+            if end:
+                episode += 1
+                eps = max(eps * 0.9992, 0.001)
+                draws = rng.integers(1, 4, size=N).astype(np.uint8)
+                dl = list(draws)
+                with mock.patch.object(ref_network.random, "randrange", side_effect=lambda a, b: dl.pop(0)):
+                    env.update_velocity()                                # :233
+            for k, v in (("actions", action), ("states", np.array(next_state, dtype=np.float64)),
+                         ("raw_reward", raw), ("shaped_reward", np.array(reward, dtype=np.float64)),
+                         ("sum_r", sum_r), ("collision", collision), ("ia", np.array(ia)), ("ia_sum", ia_sum),
+                         ("ia_pen", ia_penalty), ("episode_end", end), ("vel_draws", draws),
+                         ("episode", episode), ("eps", eps)):
+                rec[k].append(v)
+    seq, age, tx, ty = tables(env)
+    out = dict(cfg=np.array(json.dumps(cfg)), x0=x0, y0=y0, v0=v0,
+               opts=np.array(json.dumps(dict(n_prefill=n_prefill, T=T, enable_channel=enable_channel,
+                                             global_reward_avg=global_reward_avg, ia_averaging=ia_averaging,
+                                             episode_interval=episode_interval, ia_penalty_enable=ia_penalty_enable,
+                                             ia_penalty_threshold=ia_penalty_threshold,
+                                             ia_penalty_value=ia_penalty_value))),
+               final_seq=seq, final_age=age, final_x=tx,
+               final_pos=np.array([float(v.pos_x) for v in env.network.vehicles]),
+               final_vel=np.array([float(v.velocity) for v in env.network.vehicles]))
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s N=%-3d A=%-2d slots=%-3d  %7.1f KB" % (name, N, A, T, os.path.getsize(path) / 1024))
+
+
 def rand_init(rng, N, L, vary):
     # network.py:103-110: x=randint(0,L) (integer valued), y=randint(0,1)=0,
     # v = 1.7 if mobility_vary else uniform(1.1, 2.7)
@@ -315,5 +418,21 @@ def main():
              rand_steps(rng, "step", 4, 33, 1), full_tables=False)
 
 
+def main_driver():
+    # ---- D: driver-loop fixtures -------------------
+    run_driver_case("d1_driver_toy", cfg_with(), "fixed4", n_prefill=12, T=60, enable_channel=False,
+                    global_reward_avg=True, ia_averaging=False, episode_interval=25, seed=71)
+    rng = np.random.default_rng(72)
+    run_driver_case("d2_driver_ch_vary", big_cfg(16, 6, 600, mobility_vary=True, reward_design=3,
+                                                 communication_range=150),
+                    rand_init(rng, 16, 600, True), n_prefill=8, T=80, enable_channel=True,
+                    global_reward_avg=True, ia_averaging=True, episode_interval=25, seed=73,
+                    ia_penalty_enable=True, ia_penalty_threshold=2)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "driver":
+        main_driver()
+    else:
+        main()
+        main_driver()

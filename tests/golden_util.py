@@ -16,9 +16,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODES = {"step": STEP_MY_STEP, "ch": STEP_MY_STEP_CH, "design": STEP_DESIGN}
 
 
-def golden_names():
+def golden_names(prefix="g"):
+    """step-level fixtures are g*.npz; driver-loop fixtures (main_test.py call sequence) are d*.npz"""
     return sorted(os.path.splitext(os.path.basename(p))[0]
-                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
 
 
 class Golden:

@@ -12,6 +12,15 @@ class OracleBackend:
         self.cfg, self.B, self.N, self.A = cfg, batch, cfg.num_users, cfg.num_channels
         self.o = Oracle(cfg, batch=batch, sq_mode=SQ_POW)
 
+    def get_total_users(self):
+        return self.N
+
+    def get_action_space(self):
+        return self.A
+
+    def get_state_space(self):
+        return self.cfg.state_space
+
     def reset_topology(self, x0=None, y0=None, v0=None, seed=0):
         rng = np.random.default_rng(seed)
         L = int(self.cfg.highway_length)

@@ -1,0 +1,96 @@
+"""the driver-loop harness (diral_amd/driver.py)
+against fixtures recorded from the reference env under main_test.py's own call
+sequence (tests/golden/gen_golden.py::run_driver_case).  CPU run: oracle-backed
+env stand-in, bit-exact; GPU run: the real VecV2VEnv."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diral_amd.config import EnvConfig
+from diral_amd.driver import DriverLoop, calculate_ia_penalty, np_sum_lastdim
+from tests.golden_util import GOLDEN_DIR, golden_names, ulp_diff
+from tests.oracle_backend import OracleBackend
+
+
+def load(name):
+    d = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cfg = EnvConfig.from_dict(json.loads(str(d["cfg"])), track_arrival=True)
+    return d, cfg, json.loads(str(d["opts"]))
+
+
+def run(env, d, opts, exact):
+    loop = DriverLoop(env, enable_channel=opts["enable_channel"], global_reward_avg=opts["global_reward_avg"],
+                      ia_averaging=opts["ia_averaging"], ia_penalty_enable=opts["ia_penalty_enable"],
+                      ia_penalty_threshold=opts["ia_penalty_threshold"], ia_penalty_value=opts["ia_penalty_value"],
+                      episode_interval=opts["episode_interval"])
+    env.reset_topology(d["x0"], d["y0"], d["v0"])
+
+    def np_(t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def same(a, b, what):
+        a = np_(a).astype(np.float64)
+        if exact:
+            assert np.array_equal(a, b), what
+        else:
+            assert ulp_diff(a, b) <= 1 or np.allclose(a, b, rtol=0, atol=4e-15), what
+
+    st = loop.bootstrap(d["boot_action"])
+    same(st[0], d["boot_state"], "bootstrap state")
+    for i in range(opts["n_prefill"]):
+        st = loop.prefill_step(d["pre_actions"][i])
+        same(st[0], d["pre_states"][i], ("prefill", i))
+    for t in range(opts["T"]):
+        assert loop.episode == (0 if t == 0 else int(d["episode"][t - 1]))
+        out = loop.slot(d["actions"][t], t, want_ia=True)
+        same(out["next_state"][0], d["states"][t], ("state", t))
+        same(out["raw_reward"][0], d["raw_reward"][t], ("raw reward", t))
+        same(out["reward"][0], d["shaped_reward"][t], ("shaped reward", t))
+        same(out["sum_r"][0], d["sum_r"][t], ("sum_r", t))
+        same(out["collision"][0], d["collision"][t], ("collision", t))
+        assert np.array_equal(np_(out["ia"])[0], d["ia"][t]), ("ia", t)
+        assert int(np_(out["ia_sum"])[0]) == int(d["ia_sum"][t])
+        if opts["ia_averaging"]:
+            assert int(np_(out["ia_penalty"])[0]) == int(d["ia_pen"][t])
+        assert bool(out["episode_end"]) == bool(d["episode_end"][t])
+        if out["episode_end"]:
+            loop.end_episode(d["vel_draws"][t])
+        assert abs(loop.eps - float(d["eps"][t])) < 1e-15 and loop.episode == int(d["episode"][t])
+    fin = env.export_state()
+    assert np.array_equal(np_(fin["pos_x"])[0], d["final_pos"])
+    assert np.array_equal(np_(fin["vel"])[0], d["final_vel"])
+    assert np.array_equal(np_(fin["seq"])[0], d["final_seq"])
+    assert np.array_equal(np_(fin["x"])[0], d["final_x"])
+
+
+@pytest.mark.parametrize("name", golden_names("d"))
+def test_driver_loop_reproduces_reference_sequence_cpu(name):
+    d, cfg, opts = load(name)
+    run(OracleBackend(cfg), d, opts, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names("d"))
+def test_driver_loop_reproduces_reference_sequence_gpu(name):
+    from diral_amd.vec_env import VecV2VEnv
+    d, cfg, opts = load(name)
+    run(VecV2VEnv(cfg, batch=1, out_dtype=torch.float64), d, opts, exact=False)
+
+
+def test_ia_penalty_helper_matches_utils_misc():
+    rng = np.random.default_rng(0)
+    ia = rng.integers(0, 9, size=(7, 100))
+    want = [sum((i + 1) * v for i, v in enumerate(row) if v > 0) for row in ia]      # utils/misc.py:1-12
+    assert calculate_ia_penalty(torch.as_tensor(ia)).tolist() == want
+
+
+def test_np_sum_order_matches_numpy():
+    rng = np.random.default_rng(1)
+    for n in (1, 3, 7, 8, 9, 16, 63, 64, 100, 128, 129, 200, 256, 1000):
+        a = rng.normal(size=(5, n)) * 10.0 ** rng.integers(-3, 4, size=(5, n))
+        got = np_sum_lastdim(torch.as_tensor(a)).numpy()
+        want = np.array([np.sum(row) for row in a])
+        assert np.array_equal(got, want), n
