@@ -20,7 +20,7 @@ SYMBOLS = [
     "diral_env_abi_version", "diral_env_create", "diral_env_destroy", "diral_env_hbm_bytes",
     "diral_env_reset", "diral_env_step", "diral_env_observe", "diral_env_update_velocity",
     "diral_env_sample", "diral_env_info_age", "diral_env_export_state", "diral_env_import_state",
-    "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error",
+    "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error", "diral_sps_step", "diral_sps_init",
 ]
 
 _lib = None
@@ -69,6 +69,8 @@ def load() -> ctypes.CDLL:
         "diral_env_metrics": (I, [P, P, I, P]),
         "diral_env_check": (I, [P, P]),
         "diral_env_last_hip_error": (ctypes.c_char_p, [P]),
+        "diral_sps_step": (I, [I, I, P, P, P, D, D, D, P, P, P, U64, P, P]),
+        "diral_sps_init": (I, [I, I, P, P, U64, P]),
     }
     for name in SYMBOLS:
         try:

@@ -117,6 +117,68 @@ __global__ void info_age_kernel(int N, long long t, const int32_t* la, int32_t* 
   for (int j = threadIdx.x; j < 100; j += blockDim.x) out[(size_t)b * 100 + j] = bins[j];
 }
 
+// SemiPersistentScheduling.__init__ (algorithms/v2x_sps.py:8-22)
+__global__ void sps_init_kernel(int agents, int window, uint64_t seed, int32_t* prev_action, int32_t* counter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= agents) return;
+  prev_action[i] = (int32_t)(rng_u64(seed, 5, (uint64_t)i) % (uint64_t)(window + 1));   // randint(0, window)
+  counter[i] = 5 + (int32_t)(rng_u64(seed, 6, (uint64_t)i) % 11ull);                     // randint(5, 15)
+}
+
+// SemiPersistentScheduling.step + choose_new_resource (algorithms/v2x_sps.py:76-104,
+// 24-74); one thread per agent.  Reselection is rare (counter expiry x 20 %), so
+// the O(A^2) stable rank selection only runs for a few lanes.
+__global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* prev_action, int32_t* counter,
+                                double threshold, double inc_db, double keep_prob, const int32_t* draw_counter,
+                                const double* draw_keep, const int32_t* draw_choice, uint64_t seed,
+                                int32_t* actions_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= agents) return;
+  int action = prev_action[i];
+  int cnt = counter[i];
+  if (cnt != 0) {                                                      // v2x_sps.py:85-89
+    cnt -= 1;
+  } else {
+    cnt = draw_counter ? draw_counter[i] : 5 + (int)(rng_u64(seed, 7, (uint64_t)i) % 12ull);   // randint(5, 16)
+    const double u = draw_keep ? draw_keep[i] : rng_unit(rng_u64(seed, 8, (uint64_t)i));
+    if (!(u < keep_prob)) {                                            // v2x_sps.py:93-98
+      const double* w = win + (size_t)i * A;
+      const int prev = action;
+      const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
+      double thr = threshold;
+      int n_sa = 0;
+      for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
+        n_sa = 0;
+        for (int s = 0; s < A; ++s) n_sa += (s != prev && w[s] < thr) ? 1 : 0;
+        thr += inc_db;
+        if (!((double)n_sa < min_sA)) break;
+      }
+      thr -= inc_db;                                                   // the threshold sA was built with
+      const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
+      int need = (int)min_len;
+      if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
+      if (need < 1) need = 1;
+      const unsigned int r = draw_choice ? (unsigned int)draw_choice[i]
+                                         : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
+      const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
+      int chosen = prev;
+      for (int s = 0; s < A; ++s) {                                    // sorted(sA.items(), key=value): stable
+        if (s == prev || !(w[s] < thr)) continue;
+        int rank = 0;
+        for (int q = 0; q < A; ++q) {
+          if (q == prev || !(w[q] < thr)) continue;
+          rank += (w[q] < w[s] || (w[q] == w[s] && q < s)) ? 1 : 0;
+        }
+        if (rank == pick) chosen = s;
+      }
+      action = chosen;
+      prev_action[i] = action;                                         // v2x_sps.py:98
+    }
+  }
+  counter[i] = cnt;
+  actions_out[i] = action;
+}
+
 __global__ void any_nonzero_kernel(int total, const double* v, uint32_t* flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total && v[i] != 0.0) atomicOr(flag, 1u);

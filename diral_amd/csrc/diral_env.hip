@@ -496,6 +496,26 @@ int diral_env_debug_timing(DiralEnv* e, unsigned long long* host_out, int waves)
   return DIRAL_OK;
 }
 
+int diral_sps_step(int agents, int num_channels, const double* selection_window, int32_t* prev_action,
+                   int32_t* counter, double rssi_threshold, double inc_db, double keep_prob,
+                   const int32_t* draw_counter, const double* draw_keep, const int32_t* draw_choice, uint64_t seed,
+                   int32_t* actions_out, void* stream) {
+  if (agents < 1 || num_channels < 1 || !selection_window || !prev_action || !counter || !actions_out)
+    return DIRAL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sps_step_kernel, dim3(blocks((size_t)agents, 128)), dim3(128), 0, (hipStream_t)stream, agents,
+                     num_channels, selection_window, prev_action, counter, rssi_threshold, inc_db, keep_prob,
+                     draw_counter, draw_keep, draw_choice, seed, actions_out);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
+int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32_t* counter, uint64_t seed,
+                   void* stream) {
+  if (agents < 1 || selection_window < 0 || !prev_action || !counter) return DIRAL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sps_init_kernel, dim3(blocks((size_t)agents, 256)), dim3(256), 0, (hipStream_t)stream, agents,
+                     selection_window, seed, prev_action, counter);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
 int diral_env_check(DiralEnv* e, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   uint32_t flags = 0;

@@ -229,6 +229,30 @@ int diral_env_metrics(DiralEnv* env, double* out, int clear, void* stream);
  * first error. */
 int diral_env_check(DiralEnv* env, void* stream);
 
+/* ---- SPS baseline policy (agent side, stateless entry points) ----------------- */
+
+/* Replaces SemiPersistentScheduling.step + choose_new_resource
+ * (algorithms/v2x_sps.py:76-104, 24-74) for `agents` independent agents in one
+ * launch.  selection_window [agents][A] float64: the averaged-RSSI vector each
+ * agent senses (lower = better); prev_action, counter [agents] int32: the
+ * per-agent state (self.prev_action, self.reselection_counter), updated in place;
+ * actions_out [agents] int32.  The reference draws from Python's global RNG; here
+ * every draw is injectable (NULL => counter-based device RNG from `seed`):
+ *   draw_counter [agents] int32 in [5,16]   random.randint(5, 16)      (v2x_sps.py:91)
+ *   draw_keep    [agents] float64 in [0,1)  random.random()           (v2x_sps.py:93)
+ *   draw_choice  [agents] int32 >= 0        random.choice(sB) = sB[draw % len(sB)] (v2x_sps.py:57)
+ * rssi_threshold, inc_db (3), keep_prob (0.8): v2x_sps.py:12,18,22. */
+int diral_sps_step(int agents, int num_channels, const double* selection_window, int32_t* prev_action,
+                   int32_t* counter, double rssi_threshold, double inc_db, double keep_prob,
+                   const int32_t* draw_counter, const double* draw_keep, const int32_t* draw_choice,
+                   uint64_t seed, int32_t* actions_out, void* stream);
+
+/* Replaces SemiPersistentScheduling.__init__ (v2x_sps.py:8-22): prev_action =
+ * randint(0, selection_window) (inclusive, as in the reference), counter =
+ * randint(5, 15); device RNG from `seed`. */
+int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32_t* counter, uint64_t seed,
+                   void* stream);
+
 /* last HIP error string seen by this handle (host-side, for DIRAL_ERR_HIP) */
 const char* diral_env_last_hip_error(const DiralEnv* env);
 
