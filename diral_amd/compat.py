@@ -130,8 +130,11 @@ class TestEnv:
             self._env.update_velocity(draws)
 
     def load_saved_positions(self) -> None:                               # test_env.py:109-114
-        # the reference only prints when load_positions is False (the only mode built)
-        print("Load the saved positions disabled !!!")
+        if self.cfg.load_positions:
+            print("Load the saved positions !!!")
+            self._env.load_saved_positions(self.cfg.extra.get("load_file_pos"))
+        else:
+            print("Load the saved positions disabled !!!")
 
     def one_hot(self, num: int, len: int) -> np.ndarray:                  # test_env.py:585-595
         assert num >= 0 and num < len, "error"

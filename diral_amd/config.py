@@ -251,9 +251,6 @@ class EnvConfig:
                               "enable_design_topology (network.py:54-60)")
         if st.add_positional_dist_piggy and st.num_bins < 1:
             raise ConfigError("num_bins must be >= 1")
-        if self.load_positions:
-            raise ConfigError("load_positions (trace replay, network.py:171-178) is not "
-                              "built yet; see DESIGN.md")
         if self.episode_interval < 1:
             raise ConfigError("episode_interval must be >= 1")
 

@@ -54,6 +54,8 @@ struct StepParams {
   double* metrics;
   uint32_t* err;
   const double* edges;  // [K+1] np.linspace(-Rb, Rb, K+1), built on the host
+  const double* trace;  // replayed x positions [T][N] or [B][T][N] (network.py:171-178), or null
+  int trace_len, trace_per_env;
   // per-call I/O
   const int32_t* actions;
   void* state_out;

@@ -34,7 +34,9 @@ struct DiralEnv {
   double* metrics = nullptr;
   uint32_t* err = nullptr;
   double* edges = nullptr;
-  double* edges1 = nullptr;   // np.linspace(-1, 1, K+1) for the type-1 histogram
+  double* edges1 = nullptr;
+  double* trace = nullptr;    // handle-owned copy of the replay trace
+  int trace_len = 0, trace_per_env = 0;   // np.linspace(-1, 1, K+1) for the type-1 histogram
   int64_t hbm_bytes = 0;
   bool flat_y = true;      // every pos_y == 0 (random topologies, network.py:104): |dx| distance path
   uint32_t* yflag = nullptr;
@@ -112,7 +114,7 @@ bool is_fast(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
   return (p.flags & ~ignore) == want && p.posdist_type == 2 && p.mode == DIRAL_STEP_MY_STEP && !p.out_f64 &&
-         p.state_out != nullptr && p.chobs_out == nullptr;
+         p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
 }
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
@@ -339,7 +341,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   (void)hipSetDevice(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
@@ -475,6 +477,23 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
     if (!e->la) return DIRAL_ERR_BAD_CONFIG;
     HIP_TRY(e, hipMemcpyAsync(e->la, last_arrival, bn * e->N * 4, hipMemcpyDeviceToDevice, s));
   }
+  return DIRAL_OK;
+}
+
+int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_env, void* stream) {
+  if (!e || T < 0) return DIRAL_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(e, hipStreamSynchronize(s));               // no launch may still read the old copy
+  if (e->trace) { (void)hipFree(e->trace); e->trace = nullptr; }
+  e->trace_len = 0; e->trace_per_env = 0;
+  if (x_positions && T > 0) {
+    const size_t n = (size_t)(per_env ? e->B : 1) * T * e->N;
+    HIP_TRY(e, hipMalloc((void**)&e->trace, n * 8));
+    HIP_TRY(e, hipMemcpyAsync(e->trace, x_positions, n * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    e->trace_len = T; e->trace_per_env = per_env ? 1 : 0;
+  }
+  e->base.trace = e->trace; e->base.trace_len = e->trace_len; e->base.trace_per_env = e->trace_per_env;
   return DIRAL_OK;
 }
 

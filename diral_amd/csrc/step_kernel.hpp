@@ -236,7 +236,16 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
       y = p.pos_y[bN + u];
       v = p.vel[bN + u];
       nx = x;
-      if (do_step && mobile) nx = py_mod_pos(x + v + p.L, p.L);  // network.py:203
+      if (do_step && mobile) {
+        if (!FAST && p.trace) {                                    // replay branch, network.py:194-199
+          long long tt = p.t % p.trace_len;
+          if (tt < 0) tt += p.trace_len;
+          const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
+          nx = p.trace[(base + (size_t)tt) * N + u];
+        } else {
+          nx = py_mod_pos(x + v + p.L, p.L);                        // network.py:203
+        }
+      }
     }
     s_act[u] = a; s_px[u] = x; s_py[u] = y; s_vel[u] = v; s_npx[u] = nx;
     s_cnt[u] = 0u; s_rtx[u] = 1.0; s_rew[u] = 0.0; s_inr[u] = 0;

@@ -270,6 +270,30 @@ class VecV2VEnv:
         self._ok(self.lib.diral_env_update_velocity(self._h, _ptr(d), int(seed) & (2**64 - 1), self._stream()),
                  "diral_env_update_velocity")
 
+    def load_saved_positions(self, x_positions=None) -> None:
+        """test_env.py:109-114 -> network.py:171-178: replay recorded x positions,
+        `pos_x[u] = x_positions[t % T][u]` after every step.  `x_positions`: [T, N]
+        (shared, the reference's `positions_*.npy` shape), [B, T, N] (per env), a
+        path to such a .npy, or None to go back to the velocity model.  With no
+        argument the config's `load_file_pos` is used when `load_positions` is set."""
+        if x_positions is None and self.cfg.load_positions:
+            x_positions = self.cfg.extra.get("load_file_pos")
+        if x_positions is None:
+            self._ok(self.lib.diral_env_set_trace(self._h, None, 0, 0, self._stream()), "diral_env_set_trace")
+            return
+        if isinstance(x_positions, str):
+            import numpy as np
+            x_positions = np.load(x_positions)
+        tr = torch.as_tensor(x_positions, dtype=torch.float64, device=self.device).contiguous()
+        if tr.dim() == 2 and tr.shape[1] == self.N:
+            per_env, T = 0, tr.shape[0]
+        elif tr.dim() == 3 and tuple(tr.shape[::2]) == (self.B, self.N):
+            per_env, T = 1, tr.shape[1]
+        else:
+            raise ValueError("x_positions must be [T, N] or [B, T, N]")
+        self._ok(self.lib.diral_env_set_trace(self._h, _ptr(tr), int(T), per_env, self._stream()),
+                 "diral_env_set_trace")
+
     # ---- state access ---------------------------------------------------------
     def get_x_pos(self) -> torch.Tensor:
         """test_env.py:471-476, [B, N] float64."""

@@ -201,6 +201,14 @@ int diral_env_sample(DiralEnv* env, int32_t* actions_out, uint64_t seed,
  * out [B][100] int32.  Needs DIRAL_F_TRACK_ARRIVAL. */
 int diral_env_info_age(DiralEnv* env, int64_t t, int32_t* out, void* stream);
 
+/* Replaces Network.load_x_positions + the replay branch of update_positions
+ * (network.py:171-178, 194-199; TestEnv.load_saved_positions, test_env.py:109-114):
+ * after each step pos_x[u] = x_positions[t % T][u] instead of the velocity move.
+ * x_positions: float64 device array [T][N] (per_env == 0, shared by all envs, the
+ * reference's shape) or [B][T][N] (per_env != 0).  The trace is COPIED into
+ * handle-owned HBM (synchronises `stream`); T == 0 or NULL removes it. */
+int diral_env_set_trace(DiralEnv* env, const double* x_positions, int T, int per_env, void* stream);
+
 /* ---- state export / import (checkpoint, golden replay, debugging) --------- */
 
 /* Reference-shaped copies of the env state, all device pointers, any NULL

@@ -48,6 +48,8 @@ typedef struct {
   int B, N, A, K, S, sq_mode, threads;
   double *edges;              /* [K+1] np.linspace(-Rb, Rb, K+1) */
   double *edges1;             /* [K+1] np.linspace(-1, 1, K+1)   */
+  double *trace;              /* [T][N] Network.x_positions (network.py:171-178), NULL = none */
+  int trace_len;
   OEnv *envs;
 } Oracle;
 
@@ -202,8 +204,14 @@ static double reward_design_tx(const Oracle *o, const OEnv *e, int tx_user,
 
 /* Network.update_mobility / update_positions (network.py:302-305, 189-206);
  * all vehicles drive "right" (network.py:101,111) */
-static void update_mobility(const Oracle *o, OEnv *e) {
+static void update_mobility(const Oracle *o, OEnv *e, int64_t timestep) {
   if (!has(o, DIRAL_F_MOBILITY)) return;
+  if (o->trace) {                                   /* network.py:194-199: replay, t % len */
+    int64_t tt = timestep % o->trace_len;
+    if (tt < 0) tt += o->trace_len;                 /* Python's % */
+    for (int u = 0; u < o->N; ++u) e->px[u] = o->trace[(size_t)tt * o->N + u];
+    return;
+  }
   double L = o->cfg.highway_length;
   for (int u = 0; u < o->N; ++u) e->px[u] = py_mod(e->px[u] + e->vel[u] + L, L);
 }
@@ -331,7 +339,7 @@ static void step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
       }
     }
   }
-  update_mobility(o, e);                                /* test_env.py:259 */
+  update_mobility(o, e, t);                             /* test_env.py:259 */
   e->metrics[DIRAL_M_SLOTS] += 1;
   for (int u = 0; u < N; ++u) e->metrics[DIRAL_M_SUM_REWARD] += rews[u];
   free(txs); free(is_tx); free(r_tx);
@@ -534,7 +542,7 @@ void oracle_destroy(void *h) {
     free(e->px); free(e->py); free(e->vel); free(e->seq); free(e->age);
     free(e->tx); free(e->ty); free(e->la); free(e->pf);
   }
-  free(o->envs); free(o->edges); free(o->edges1); free(o);
+  free(o->envs); free(o->edges); free(o->edges1); free(o->trace); free(o);
 }
 
 /* fresh Vehicles: vehicle.py:24-33 (tables zero), network.py:39-42 (la = -1) */
@@ -649,6 +657,18 @@ void oracle_import(void *h, const double *px, const double *py, const double *ve
     if (tx) memcpy(e->tx, tx + b * N * N, N * N * sizeof(double));
     if (ty) memcpy(e->ty, ty + b * N * N, N * N * sizeof(double));
     if (la) memcpy(e->la, la + b * N * N, N * N * sizeof(int64_t));
+  }
+}
+
+/* Network.load_x_positions (network.py:171-178): one [T][N] trace shared by all envs */
+void oracle_set_trace(void *h, const double *trace, int T) {
+  Oracle *o = (Oracle *)h;
+  free(o->trace);
+  o->trace = NULL; o->trace_len = 0;
+  if (trace && T > 0) {
+    o->trace = (double *)malloc(sizeof(double) * (size_t)T * o->N);
+    memcpy(o->trace, trace, sizeof(double) * (size_t)T * o->N);
+    o->trace_len = T;
   }
 }
 

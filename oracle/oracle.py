@@ -51,6 +51,7 @@ def _load():
     lib.oracle_export.argtypes = [P] + [P] * 9
     lib.oracle_import.argtypes = [P] + [P] * 8
     lib.oracle_metrics.argtypes = [P, P]
+    lib.oracle_set_trace.argtypes = [P, P, ctypes.c_int]
     lib.oracle_edges.argtypes = [P, P]
     lib.oracle_state_space.argtypes = [ctypes.POINTER(DiralCfg)]
     lib.oracle_state_space.restype = ctypes.c_int
@@ -130,6 +131,14 @@ class Oracle:
                 c(seq, np.int32), c(age, np.int32), c(x, np.float64), c(y, np.float64),
                 c(la, np.int64)]
         self.lib.oracle_import(self.h, *[_p(a) for a in arrs])
+
+    def set_trace(self, trace) -> None:
+        """Network.load_x_positions (network.py:171-178): [T, N] x-positions."""
+        if trace is None:
+            self.lib.oracle_set_trace(self.h, None, 0)
+            return
+        tr = np.ascontiguousarray(trace, dtype=np.float64).reshape(-1, self.N)
+        self.lib.oracle_set_trace(self.h, _p(tr), tr.shape[0])
 
     def metrics(self) -> np.ndarray:
         out = np.empty((self.B, M_COLUMNS), np.float64)

@@ -110,9 +110,14 @@ def sha(a):
 
 
 def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
-             full_tables=True, episode_eps=None):
+             full_tables=True, episode_eps=None, trace=None, trace_after=None):
     """steps: list of (mode, actions, t).  vel_updates: {step_index: draws[N]}
     applied AFTER that step (main_test.py:226-233 order)."""
+    if trace is not None:
+        # trace replay (network.py:171-178): the reference np.load()s `load_file_pos`
+        tpath = "/tmp/diral_golden_trace_%s.npy" % name
+        np.save(tpath, np.asarray(trace, dtype=np.float64))
+        cfg = cfg_with(cfg, load_positions=True, load_file_pos=tpath)
     env = make_env(cfg)
     N, A = env.NUM_USERS, env.NUM_CHANNELS
     if isinstance(init, str) and init == "fixed4":
@@ -153,6 +158,9 @@ def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
                                    side_effect=lambda a, b: draws.pop(0)):
                 env.update_velocity()
         rec["vel"].append(np.array([float(v.velocity) for v in env.network.vehicles]))
+        if trace is not None and si == trace_after:
+            with contextlib.redirect_stdout(io.StringIO()):
+                env.load_saved_positions()                      # main_test.py:118
         seq, age, tx, ty = tables(env)
         la = last_arrival(env)
         tab_sha.append([sha(seq), sha(age), sha(tx), sha(ty), sha(la)])
@@ -177,6 +185,8 @@ def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
                              [(0, 1)] * len(steps), dtype=np.float64),
         state_space=np.int64(env.get_state_space()),
         table_sha=np.array(tab_sha),
+        trace=np.asarray(trace if trace is not None else np.zeros((0, N)), dtype=np.float64),
+        trace_after=np.int64(-1 if trace_after is None else trace_after),
     )
     for k, v in rec.items():
         out[k] = np.array(v)
@@ -418,6 +428,16 @@ def main():
              rand_steps(rng, "step", 4, 33, 1), full_tables=False)
 
 
+def main_trace():
+    # ---- T: trace replay (load_positions, network.py:171-178, 194-199) ----------
+    rng = np.random.default_rng(91)
+    N, A, L = 12, 5, 500
+    tr = np.sort(rng.uniform(0, L, size=(7, N)), axis=1) + rng.normal(0, 3, size=(7, N))
+    run_case("g9_trace_replay", big_cfg(N, A, L, communication_range=140), rand_init(rng, N, L, False),
+             rand_steps(rng, "step", 6, N, A) + [("step", rng.integers(0, A, size=N), t) for t in (6, 7, 13, 20, 3)]
+             + rand_steps(rng, "ch", 4, N, A), trace=tr, trace_after=2, table_every=5)
+
+
 def main_driver():
     # ---- D: driver-loop fixtures -------------------
     run_driver_case("d1_driver_toy", cfg_with(), "fixed4", n_prefill=12, T=60, enable_channel=False,
@@ -433,6 +453,9 @@ def main_driver():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "driver":
         main_driver()
+    elif len(sys.argv) > 1 and sys.argv[1] == "trace":
+        main_trace()
     else:
         main()
+        main_trace()
         main_driver()

@@ -33,6 +33,10 @@ class Golden:
         self.T = len(self.d["modes"])
         self.vel_updates = {int(s): self.d["vel_update_draws"][i]
                             for i, s in enumerate(self.d["vel_update_steps"])}
+        # trace replay fixtures: the recorded [T, N] trace and the step after which
+        # the reference called load_saved_positions()
+        self.trace = self.d["trace"] if "trace" in self.d and self.d["trace"].shape[0] else None
+        self.trace_after = int(self.d["trace_after"]) if "trace_after" in self.d else -1
 
     def __getitem__(self, k):
         return self.d[k]

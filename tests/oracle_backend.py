@@ -60,6 +60,11 @@ class OracleBackend:
             draws = np.random.default_rng(seed).integers(1, 4, size=(self.B, self.N))
         self.o.update_velocity(draws)
 
+    def load_saved_positions(self, x_positions=None):
+        if isinstance(x_positions, str):
+            x_positions = np.load(x_positions)
+        self.o.set_trace(x_positions)
+
     def get_x_pos(self):
         return self.o.export()["pos_x"]
 

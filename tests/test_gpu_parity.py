@@ -90,6 +90,9 @@ def test_golden_replay_on_gpu(name):
         if i in g.vel_updates:
             env.update_velocity(g.vel_updates[i])
             orc.update_velocity(g.vel_updates[i])
+        if g.trace is not None and i == g.trace_after:
+            env.load_saved_positions(g.trace)
+            orc.set_trace(g.trace)
         ia = env.info_age(t).cpu().numpy()
         st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
         oe = orc.export()
@@ -529,3 +532,35 @@ def test_sps_policy_drives_the_env():
     coll = (m[3] / (m[2] + m[3])).item()
     assert coll < 0.80, coll                              # iid-uniform actions give ~0.865
     env.check()
+
+
+def test_per_env_trace_replay_vs_oracle():
+    """load_positions with one trace PER env ([B, T, N], build extension of the
+    reference's single [T, N] file): each env against its own oracle."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(20, 6, 800.0, communication_range=200.0)
+    B, N, A, T = 4, 20, 6, 9
+    rng = np.random.default_rng(33)
+    x0 = rng.integers(0, 800, size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    traces = rng.uniform(0, 800, size=(B, T, N))
+    env = make_env(cfg, B)
+    env.reset_topology(x0, None, v0)
+    env.load_saved_positions(traces)
+    orcs = [Oracle(cfg, batch=1, sq_mode=SQ_IEEE) for _ in range(B)]
+    for b, o in enumerate(orcs):
+        o.reset(x0[b:b + 1], np.zeros((1, N)), v0[b:b + 1])
+        o.set_trace(traces[b])
+    for t in list(range(14)) + [40, 41, 5]:
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, a, t)
+        for b, o in enumerate(orcs):
+            o_rew, o_chobs = o.step(STEP_MY_STEP, a[b:b + 1], t)
+            assert np.array_equal(obs[b], o.obtain_state(a[b:b + 1], o_chobs, o_rew)[0]), (t, b)
+            assert np.array_equal(rew[b], o_rew[0])
+    px = env.get_x_pos().cpu().numpy()
+    assert np.array_equal(px, traces[:, 5 % T, :])
+    env.load_saved_positions(None)            # back to the velocity model
+    env.step(np.zeros((B, N), np.int32), 0)
+    torch.cuda.synchronize()
+    assert not np.array_equal(env.get_x_pos().cpu().numpy(), px)

@@ -32,6 +32,8 @@ def replay(g, sq_mode, batch=1):
         out["ia"].append(o.info_age(t))
         if i in g.vel_updates:
             o.update_velocity(g.vel_updates[i])
+        if g.trace is not None and i == g.trace_after:
+            o.set_trace(g.trace)
         e = o.export()
         out["pos_x"].append(e["pos_x"])
         out["vel"].append(e["vel"])
