@@ -285,15 +285,22 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 
   // ---- P3a: stamp + gossip merge over this wave's 16 subject columns -------------
   unsigned int key[16];
+  {
+    // Vehicle.periodic_update (vehicle.py:56-70), branch-free: the own entry gets
+    // seq+1 / age 0, every other entry age+1 (saturating at 255)
+    const int own_c = live ? lane - wave * 16 : -1;            // column of this lane's own entry, if in this wave
+    bool ovf = false;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int k = wave * 16 + c;
-    unsigned int w = w1[c];
-    unsigned int seq = w >> 8, age = w & 255u;                 // Vehicle.periodic_update (vehicle.py:56-70)
-    if (lane == k && live) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
-    else age = (age < 255u) ? age + 1u : 255u;
-    w = (seq << 8) | age;
-    w1[c] = w;
+    for (int c = 0; c < 16; ++c) {
+      const unsigned int w = w1[c];
+      const bool own = (own_c == c);
+      const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
+      const unsigned int a0 = w & 255u;
+      const unsigned int age = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
+      ovf = ovf || (own && seq >= (1u << 24) - 1u);
+      w1[c] = (seq << 8) | age;
+    }
+    if (ovf) atomicOr(p.err, kErrSeq);
   }
   // Vehicle.received_update for every (resource, rx), resources ascending:
   // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
@@ -350,7 +357,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       const unsigned int rank = k16 >> 6, src = k16 & 63u;
       const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)(w1[c] >> 8), (wave * 16 + c) & 63);
       const unsigned int seqf = tk_own - 1023u + rank;
-      key[c] = rank ? ((seqf << 8) | src) : ((w1[c] & ~255u) | (unsigned int)lane);
+      // select without a branch (the compiler turns the plain ternary into exec-mask control flow)
+      const unsigned int m = 0u - (unsigned int)(rank != 0u);
+      key[c] = (((seqf << 8) | src) & m) | (((w1[c] & ~255u) | (unsigned int)lane) & ~m);
     }
   }
 #endif
