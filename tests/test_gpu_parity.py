@@ -564,3 +564,61 @@ def test_per_env_trace_replay_vs_oracle():
     env.step(np.zeros((B, N), np.int32), 0)
     torch.cuda.synchronize()
     assert not np.array_equal(env.get_x_pos().cpu().numpy(), px)
+
+
+def test_long_run_past_the_packed_rank_horizon():
+    """1300 slots in a sparse topology: pairs that never hear each other keep
+    seq == 0 entries whose lag passes 1023 (the packed-merge rank saturates) and
+    ages saturate at 255; everything must still match the oracle bit for bit."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(24, 6, 3000.0, communication_range=60.0)
+    B, N, A = 3, 24, 6
+    rng = np.random.default_rng(8)
+    x0 = rng.integers(0, 3000, size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    fast = make_env(cfg, B, dtype=torch.float32)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE)
+    fast.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(1300):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = fast.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        if t % 50 == 49 or t > 1270:
+            o_state = orc.obtain_state(a, o_chobs, o_rew)
+            torch.cuda.synchronize()
+            assert np.array_equal(obs.cpu().numpy(), o_state.astype(np.float32)), t
+    st, oe = fast.export_state(), orc.export()
+    assert (oe["seq"] == 0).any() and (oe["age"] > 255).any()
+    assert np.array_equal(st["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    fast.check()
+
+
+def test_step_is_capturable_in_a_hip_graph():
+    """diral_env_step only enqueues on the given stream (no allocation, no host
+    sync): a captured sequence of steps replays to the same result as eager."""
+    cfg = c2_config()
+    B = 32
+    rng = np.random.default_rng(4)
+    x0 = rng.integers(0, 2000, size=(B, 64)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, 64))
+    acts = [torch.as_tensor(rng.integers(0, 32, size=(B, 64)).astype(np.int32), device="cuda") for _ in range(4)]
+    eager, graphed = make_env(cfg, B, dtype=torch.float32), make_env(cfg, B, dtype=torch.float32)
+    for e in (eager, graphed):
+        e.reset_topology(x0, None, v0)
+    for i in range(4):
+        obs_e, rew_e, _ = eager.step(acts[i], i)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for i in range(4):
+                obs_g, rew_g, _ = graphed.step(acts[i], i)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(obs_e, obs_g) and torch.equal(rew_e, rew_g)
+    se, sg = eager.export_state(), graphed.export_state()
+    assert torch.equal(se["seq"], sg["seq"]) and torch.equal(se["x"], sg["x"])
