@@ -61,7 +61,7 @@ struct FastParams {
 };
 
 struct FastLds {
-  uint32_t rv, edges, mask, rx, act, hist, cnt, mtab, total;
+  uint32_t rv, edges, mask, act, hist, cnt, mtab, total;
 };
 __host__ __device__ inline FastLds fast_lds_layout(int K) {
   FastLds l;
@@ -69,7 +69,6 @@ __host__ __device__ inline FastLds fast_lds_layout(int K) {
   l.rv = o;    o += 8u * kFastMaxA;
   l.edges = o; o += 8u * (K + 2);
   l.mask = o;  o += 8u * kFastMaxA;
-  l.rx = o;    o += 8u * 64;                // receiver set of each transmitter
   l.act = o;   o += 4u * 64;
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;

@@ -10,7 +10,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline $*"
+# the kernel-trace pass profiles the SAME command the driver runs (default steps/warmup)
+BENCH="python $R/bench.py --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 pmc() { # name counters...
   local name=$1; shift
