@@ -29,6 +29,8 @@
 // float64 everywhere the reference uses Python floats; build with
 // -ffp-contract=off so a*b+c is never fused (bin edges, distances).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace diral {
@@ -43,6 +45,9 @@ namespace diral {
 #endif
 #ifndef DIRAL_PREFETCH
 #define DIRAL_PREFETCH 1
+#endif
+#ifndef DIRAL_PACKED_WIDE
+#define DIRAL_PACKED_WIDE 1            // N > 64: 16-bit packed gossip merge (exact; falls back per pass)
 #endif
 
 template <int VPL>
@@ -106,6 +111,12 @@ __device__ inline void store_out(void* base, size_t idx, double v, int f64) {
   else reinterpret_cast<float*>(base)[idx] = (float)v;
 }
 
+// Orders this wave's LDS accesses for the COMPILER only.  The hardware already
+// executes one wave's DS instructions in issue order, so a later ds_read sees an
+// earlier ds_write of the same wave without any wait; a real fence would drain
+// lgkmcnt at every merge step (measured: the dominant cost at N > 64).
+__device__ inline void wave_lds_order() { asm volatile("" ::: "memory"); }
+
 // wave-uniform 64-bit value -> SGPR pair, so branches on it are scalar
 __device__ inline unsigned long long uniform_u64(unsigned long long v) {
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
@@ -165,7 +176,7 @@ __device__ inline int reward_weight(const StepParams& p, const unsigned long lon
 // code with the optional branches removed at compile time; every other config
 // runs FAST=false.
 template <int VPL, bool FAST>
-__global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1)) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4)) void step_kernel(const StepParams p) {
   using G = Geo<VPL>;
   constexpr int NPAD = G::NPAD, WAVES = G::WAVES, CC = G::CC, NCH = G::NCH;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
       }
       if (!FAST && want_prr && c > 1) {
         // received[tx] = #rx whose nearest tx is tx (test_env.py:398-400)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        wave_lds_order();
 #pragma unroll
         for (int jt = 0; jt < VPL; ++jt) {
           unsigned long long m = mk[jt];
@@ -465,141 +476,255 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 1))
     for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
     const double inv_w = p.hist_inv_width;
 
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int kbase = wave * 16 + ch * CC;
-      if (kbase >= N) break;
-      unsigned int w1[CC * VPL];   // post-stamp (seq << 8) | age
-      unsigned int key[CC * VPL];  // (seq << 8) | source viewer
+    // load + Vehicle.periodic_update (vehicle.py:56-70), branch-free
+    bool seq_ovf = false;
+    auto load_stamp = [&](int k, int j, unsigned int pre) -> unsigned int {
+      const int u = lane + 64 * j;
+      unsigned int w = pre;
+      if (VPL > 1 || !DIRAL_PREFETCH) w = (k < N && u < N) ? p.tkey[(bR + k) * NV + u] : 0u;
+      if (do_step) {
+        const bool own = (u == k) && (u < N);
+        const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
+        const unsigned int a0 = w & 255u;
+        const unsigned int age = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
+        seq_ovf = seq_ovf || (own && seq >= (1u << 24) - 1u);
+        w = (seq << 8) | age;
+      }
+      return w;
+    };
+
+    // finalize one column: xpos follows the winning sequence number, age resets on
+    // change, then the viewer-side histogram contribution of the entry
+    auto finalize = [&](int k, const unsigned int* kf_j, const unsigned int* w_j, double xpre) {
+      const double pxk = s_px[k], pyk = s_py[k];
+      double xn[VPL];
+      unsigned int wn[VPL];
+      bool changed[VPL];
 #pragma unroll
-      for (int c = 0; c < CC; ++c) {
-        const int k = kbase + c;
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;
+        const unsigned int kf = kf_j[j], w = w_j[j];
+        const unsigned int src = kf & 255u;
+        const bool upd = ((kf ^ w) >> 8) != 0u;
+        double xo = xpre;
+        if (VPL > 1 || !DIRAL_PREFETCH) xo = (u < N) ? p.tx[(bR + k) * NV + u] : 0.0;
+        if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
+        double xg = xo;
+        if constexpr (VPL == 1) {
+          const int lo = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2loint(xo));
+          const int hi = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2hiint(xo));
+          if (upd) xg = __hiloint2double(hi, lo);
+        } else {
+          // (all gathers of the column are issued before any of its stores below)
+          if (upd) xg = ((int)src == k) ? pxk : p.tx[(bR + k) * NV + src];
+        }
+        xn[j] = xg;
+        wn[j] = upd ? (kf & ~255u) : w;
+        changed[j] = upd;
+      }
+      if (do_step) {
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
-          unsigned int w = 0u;
-          if constexpr (VPL == 1 && DIRAL_PREFETCH) w = pre_w[c];
-          else if (k < N && u < N) w = p.tkey[(bR + k) * NV + u];
-          if (do_step) {
-            // Vehicle.periodic_update (vehicle.py:56-70)
-            unsigned int seq = w >> 8, age = w & 255u;
-            if (u == k) { seq += 1u; age = 0u; if (seq >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq); }
-            else age = (age < 255u) ? age + 1u : 255u;
-            w = (seq << 8) | age;
+          if (u < N) {
+            p.tkey[(bR + k) * NV + u] = wn[j];
+            if (changed[j] || u == k) p.tx[(bR + k) * NV + u] = xn[j];
           }
-          w1[c * VPL + j] = w;
-          key[c * VPL + j] = (w & ~255u) | (unsigned int)u;
         }
       }
-      if (do_step) {
-        // Vehicle.received_update for every (resource, rx) in reference order
-        if constexpr (VPL == 1) {
-          for (int i = 0; i < A; ++i) {
+      if (want_hist) {
+        // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          const int age = (int)(wn[j] & 255u);
+          if (u < N && u != k && age < p.age_limit) {
+            const double x1 = xn[j];
+            const double y1 = ((wn[j] >> 8) > 0u) ? pyk : 0.0;
+            const double x2 = mynpx[j], y2 = mypy[j];
+            const double d = dist2d(x1, y1, x2, y2);
+            if (d < p.Rb) {
+              const double v = (x1 - x2 > 0.0) ? d : -d;
+              const int bin = hist_bin(v, -p.Rb, inv_w, K, s_edges);
+              atomicAdd(&s_hist[u * KP + bin], 1u);
+              mycnt[j] += 1u;
+            }
+          }
+        }
+      }
+    };
+
+    // 32-bit merge of NC columns held in LDS scratch (N > 64): Vehicle.received_update
+    // for every (resource, rx) in reference order; a wave's own LDS queue is in order
+    auto merge32_wide = [&](unsigned int* key, auto nc_tag) {
+      constexpr int NC = decltype(nc_tag)::value;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) scratch[c * NPAD + lane + 64 * j] = key[c * VPL + j];
+      wave_lds_order();
+      for (int i = 0; i < A; ++i) {
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
+        if (uniform_u64(any) == 0ull) continue;
+        int m[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
+        unsigned int v[NC * VPL];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) v[c * VPL + j] = scratch[c * NPAD + m[j]];
+        // tx entries are not written in resource i (a tx never merges on its own
+        // resource), so all gathers of step i may precede all writes
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const unsigned int nk = max(key[c * VPL + j], v[c * VPL + j]);
+            if (nk != key[c * VPL + j]) scratch[c * NPAD + lane + 64 * j] = nk;
+            key[c * VPL + j] = nk;
+          }
+        wave_lds_order();
+      }
+    };
+
+    if constexpr (VPL == 1) {
+      const int kbase = wave * 16;
+      if (kbase < N) {
+        unsigned int w1[16], key[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          w1[c] = load_stamp(kbase + c, 0, DIRAL_PREFETCH ? pre_w[c] : 0u);
+          key[c] = (w1[c] & ~255u) | (unsigned int)lane;
+        }
+        if (do_step) {
+          for (int i = 0; i < A; ++i) {                          // one ds_bpermute + max per column
             if (uniform_u64(s_mask[i]) == 0ull) continue;
             const int m4 = (int)s_mtab[i * NPAD + lane] << 2;
 #pragma unroll
-            for (int c = 0; c < CC; ++c) {
+            for (int c = 0; c < 16; ++c) {
               const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
               key[c] = max(key[c], v);
             }
           }
-        } else {
+        }
+        DIRAL_STAMP(5);
 #pragma unroll
-          for (int c = 0; c < CC; ++c)
+        for (int c = 0; c < 16; ++c)
+          if (kbase + c < N) finalize(kbase + c, &key[c], &w1[c], DIRAL_PREFETCH ? pre_x[c] : 0.0);
+      }
+    } else {
+      // N > 64.  CC columns per pass (16 key registers); packed as CC/2 column PAIRS of 16-bit keys
+      // (rank << 8) | source, rank = 255 - lag, merged with v_pk_max_u16 - half the
+      // LDS traffic and VALU work of the 32-bit merge.  Exact while no entry of the
+      // pass has lag >= 255 with seq != 0 (see step_fast64.hpp for the argument);
+      // otherwise the pass takes the 32-bit merge.
+      constexpr int PC = CC, HP = CC / 2;
+      for (int pch = 0; pch < 16 / PC; ++pch) {
+        const int kbase = wave * 16 + pch * PC;
+        if (kbase >= N) break;
+        unsigned int w1[PC * VPL], key[PC * VPL];
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) scratch[c * NPAD + lane + 64 * j] = key[c * VPL + j];
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          for (int i = 0; i < A; ++i) {
-            unsigned long long any = 0ull;
+        for (int c = 0; c < PC; ++c)
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
-            if (uniform_u64(any) == 0ull) continue;
-            int m[VPL];
+          for (int j = 0; j < VPL; ++j) w1[c * VPL + j] = load_stamp(kbase + c, j, 0u);
+        // (key[] is built inside each branch so it is not live across the packed merge)
+        auto init_key = [&]() {
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
-            unsigned int v[CC * VPL];
+          for (int c = 0; c < PC; ++c)
 #pragma unroll
-            for (int c = 0; c < CC; ++c)
+            for (int j = 0; j < VPL; ++j)
+              key[c * VPL + j] = (w1[c * VPL + j] & ~255u) | (unsigned int)(lane + 64 * j);
+        };
+        if (!do_step) init_key();
+        if (do_step) {
+          typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+          unsigned int kp[HP * VPL];
+          unsigned int tk_own[PC];
+          bool bad = false;
 #pragma unroll
-              for (int j = 0; j < VPL; ++j) v[c * VPL + j] = scratch[c * NPAD + m[j]];
-            // tx entries are not written in resource i (a tx never merges on its
-            // own resource), so all gathers of step i may precede all writes
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          for (int c = 0; c < PC; ++c) {
+            const int k = kbase + c;
+            // the subject's own fresh sequence number: entry (viewer k, subject k)
+            unsigned int tko = 0u;
 #pragma unroll
-            for (int c = 0; c < CC; ++c)
+            for (int j = 0; j < VPL; ++j) {
+              const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(w1[c * VPL + j] >> 8), k & 63);
+              tko = ((k >> 6) == j) ? cand : tko;
+            }
+            tk_own[c] = tko;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const unsigned int seq = w1[c * VPL + j] >> 8;
+              const unsigned int lag = tko - seq;
+              bad = bad || (lag >= 255u && seq != 0u);
+              const unsigned int rank = lag < 255u ? 255u - lag : 0u;
+              const unsigned int k16 = (rank << 8) | (unsigned int)(lane + 64 * j);
+              if ((c & 1) == 0) kp[(c >> 1) * VPL + j] = k16;
+              else kp[(c >> 1) * VPL + j] |= k16 << 16;
+            }
+          }
+          const bool packed_ok = (DIRAL_PACKED_WIDE != 0) && (__ballot(bad) == 0ull);
+          if (packed_ok) {
+#pragma unroll
+            for (int c2 = 0; c2 < HP; ++c2)
+#pragma unroll
+              for (int j = 0; j < VPL; ++j) scratch[c2 * NPAD + lane + 64 * j] = kp[c2 * VPL + j];
+            wave_lds_order();
+            for (int i = 0; i < A; ++i) {
+              unsigned long long any = 0ull;
+#pragma unroll
+              for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
+              if (uniform_u64(any) == 0ull) continue;
+              int m[VPL];
+#pragma unroll
+              for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
+              unsigned int v[HP * VPL];
+#pragma unroll
+              for (int c2 = 0; c2 < HP; ++c2)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) v[c2 * VPL + j] = scratch[c2 * NPAD + m[j]];
+              wave_lds_order();
+#pragma unroll
+              for (int c2 = 0; c2 < HP; ++c2)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                  const unsigned int old = kp[c2 * VPL + j];
+                  const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, old),
+                                                            __builtin_bit_cast(u16x2, v[c2 * VPL + j]));
+                  const unsigned int nk = __builtin_bit_cast(unsigned int, r);
+                  if (nk != old) scratch[c2 * NPAD + lane + 64 * j] = nk;
+                  kp[c2 * VPL + j] = nk;
+                }
+              wave_lds_order();
+            }
+            // back to (seq << 8) | source; rank 0 never results from an update
+#pragma unroll
+            for (int c = 0; c < PC; ++c)
 #pragma unroll
               for (int j = 0; j < VPL; ++j) {
-                const unsigned int nk = max(key[c * VPL + j], v[c * VPL + j]);
-                if (nk != key[c * VPL + j]) scratch[c * NPAD + lane + 64 * j] = nk;
-                key[c * VPL + j] = nk;
+                const unsigned int k16 = (kp[(c >> 1) * VPL + j] >> (16 * (c & 1))) & 0xffffu;
+                const unsigned int rank = k16 >> 8, src = k16 & 255u;
+                const unsigned int seqf = tk_own[c] - 255u + rank;
+                const unsigned int msk = 0u - (unsigned int)(rank != 0u);
+                const unsigned int own_key = (w1[c * VPL + j] & ~255u) | (unsigned int)(lane + 64 * j);
+                key[c * VPL + j] = (((seqf << 8) | src) & msk) | (own_key & ~msk);
               }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          }
-        }
-      }
-      DIRAL_STAMP(5);
-      // finalize: xpos follows the winning sequence number; age reset on change
-#pragma unroll
-      for (int c = 0; c < CC; ++c) {
-        const int k = kbase + c;
-        if (k >= N) continue;
-        const double pxk = s_px[k], pyk = s_py[k];
-        double xn[VPL];
-        unsigned int wn[VPL];
-        bool changed[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          const unsigned int kf = key[c * VPL + j], w = w1[c * VPL + j];
-          const unsigned int src = kf & 255u;
-          const bool upd = ((kf ^ w) >> 8) != 0u;
-          double xo = 0.0;
-          if constexpr (VPL == 1 && DIRAL_PREFETCH) xo = pre_x[c];
-          else if (u < N) xo = p.tx[(bR + k) * NV + u];
-          if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
-          double xg = xo;
-          if constexpr (VPL == 1) {
-            const int lo = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2loint(xo));
-            const int hi = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2hiint(xo));
-            if (upd) xg = __hiloint2double(hi, lo);
           } else {
-            if (upd) xg = ((int)src == k) ? pxk : p.tx[(bR + k) * NV + src];
+            init_key();
+            merge32_wide(&key[0], std::integral_constant<int, CC>{});
           }
-          xn[j] = xg;
-          wn[j] = upd ? (kf & ~255u) : w;
-          changed[j] = upd;
         }
-        if (do_step) {
+        DIRAL_STAMP(5);
 #pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const int u = lane + 64 * j;
-            if (u < N) {
-              p.tkey[(bR + k) * NV + u] = wn[j];
-              if (changed[j] || u == k) p.tx[(bR + k) * NV + u] = xn[j];
-            }
-          }
-        }
-        if (want_hist) {
-          // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const int u = lane + 64 * j;
-            const int age = (int)(wn[j] & 255u);
-            if (u < N && u != k && age < p.age_limit) {
-              const double x1 = xn[j];
-              const double y1 = ((wn[j] >> 8) > 0u) ? pyk : 0.0;
-              const double x2 = mynpx[j], y2 = mypy[j];
-              const double d = dist2d(x1, y1, x2, y2);
-              if (d < p.Rb) {
-                const double v = (x1 - x2 > 0.0) ? d : -d;
-                const int bin = hist_bin(v, -p.Rb, inv_w, K, s_edges);
-                atomicAdd(&s_hist[u * KP + bin], 1u);
-                mycnt[j] += 1u;
-              }
-            }
-          }
-        }
+        for (int c = 0; c < PC; ++c)
+          if (kbase + c < N) finalize(kbase + c, &key[c * VPL], &w1[c * VPL], 0.0);
       }
     }
+    if (seq_ovf) atomicOr(p.err, kErrSeq);
     if (want_hist) {
 #pragma unroll
       for (int j = 0; j < VPL; ++j)
