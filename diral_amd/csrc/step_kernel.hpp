@@ -514,13 +514,25 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
           const int lo = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2loint(xo));
           const int hi = __builtin_amdgcn_ds_bpermute((int)src << 2, __double2hiint(xo));
           if (upd) xg = __hiloint2double(hi, lo);
-        } else {
-          // (all gathers of the column are issued before any of its stores below)
-          if (upd) xg = ((int)src == k) ? pxk : p.tx[(bR + k) * NV + src];
         }
         xn[j] = xg;
         wn[j] = upd ? (kf & ~255u) : w;
         changed[j] = upd;
+      }
+      if constexpr (VPL > 1) {
+        // N > 64: the source viewer may sit in another lane slot - stage the column's
+        // xpos in the wave's LDS scratch (free after the merge) and gather from there;
+        // un-branched (a lane that did not update re-reads its own value)
+        double* sx = reinterpret_cast<double*>(scratch);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xn[j];
+        wave_lds_order();
+        double xg[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) xg[j] = sx[changed[j] ? (int)(kf_j[j] & 255u) : lane + 64 * j];
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) xn[j] = xg[j];
       }
       if (do_step) {
 #pragma unroll
@@ -541,7 +553,9 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
           if (u < N && u != k && age < p.age_limit) {
             const double x1 = xn[j];
             const double y1 = ((wn[j] >> 8) > 0u) ? pyk : 0.0;
-            const double x2 = mynpx[j], y2 = mypy[j];
+            // (N > 64 re-reads its own position from LDS: keeping 3*VPL doubles live across the
+            // merge spills under the 128-VGPR cap of a 1024-thread workgroup)
+            const double x2 = (VPL == 1) ? mynpx[j] : s_npx[u], y2 = (VPL == 1) ? mypy[j] : s_py[u];
             const double d = dist2d(x1, y1, x2, y2);
             if (d < p.Rb) {
               const double v = (x1 - x2 > 0.0) ? d : -d;
@@ -550,6 +564,46 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
               mycnt[j] += 1u;
             }
           }
+        }
+      }
+    };
+
+    // Resources with at least one transmitter, as wave-uniform bit words (computed
+    // once: no per-step LDS round trip for the mask), visited in ascending order with
+    // the NEXT resource's gather sources already in flight.
+    unsigned long long act_w[4] = {0ull, 0ull, 0ull, 0ull};
+    if (VPL > 1 && do_step) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = q * 64 + lane;
+        unsigned long long any = 0ull;
+        if (q * 64 < A && i < A) {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
+        }
+        act_w[q] = __ballot(any != 0ull);
+      }
+    }
+    auto for_each_active_resource = [&](auto&& body) {
+      int m_next[VPL];
+      bool have_next = false;
+      const int nwords = (A + 63) >> 6;
+#pragma unroll 1
+      for (int q = 0; q < nwords; ++q) {                       // rolled: one copy of the body
+        unsigned long long w = q == 0 ? act_w[0] : (q == 1 ? act_w[1] : (q == 2 ? act_w[2] : act_w[3]));
+        while (w) {
+          const int i = q * 64 + __builtin_ctzll(w);
+          w &= w - 1;
+          int m[VPL];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) m[j] = have_next ? m_next[j] : (int)s_mtab[i * NPAD + lane + 64 * j];
+          have_next = (w != 0ull);                             // prefetch within the word only
+          if (have_next) {
+            const int inext = q * 64 + __builtin_ctzll(w);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) m_next[j] = s_mtab[inext * NPAD + lane + 64 * j];
+          }
+          body(m);
         }
       }
     };
@@ -563,14 +617,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
 #pragma unroll
         for (int j = 0; j < VPL; ++j) scratch[c * NPAD + lane + 64 * j] = key[c * VPL + j];
       wave_lds_order();
-      for (int i = 0; i < A; ++i) {
-        unsigned long long any = 0ull;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
-        if (uniform_u64(any) == 0ull) continue;
-        int m[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
+      for_each_active_resource([&](const int (&m)[VPL]) {
         unsigned int v[NC * VPL];
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -584,11 +631,12 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
 #pragma unroll
           for (int j = 0; j < VPL; ++j) {
             const unsigned int nk = max(key[c * VPL + j], v[c * VPL + j]);
-            if (nk != key[c * VPL + j]) scratch[c * NPAD + lane + 64 * j] = nk;
+            // unconditional: one ds_write is cheaper to ISSUE than compare + exec-mask + write
+            scratch[c * NPAD + lane + 64 * j] = nk;
             key[c * VPL + j] = nk;
           }
         wave_lds_order();
-      }
+      });
     };
 
     if constexpr (VPL == 1) {
@@ -674,14 +722,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
 #pragma unroll
               for (int j = 0; j < VPL; ++j) scratch[c2 * NPAD + lane + 64 * j] = kp[c2 * VPL + j];
             wave_lds_order();
-            for (int i = 0; i < A; ++i) {
-              unsigned long long any = 0ull;
-#pragma unroll
-              for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
-              if (uniform_u64(any) == 0ull) continue;
-              int m[VPL];
-#pragma unroll
-              for (int j = 0; j < VPL; ++j) m[j] = s_mtab[i * NPAD + lane + 64 * j];
+            for_each_active_resource([&](const int (&m)[VPL]) {
               unsigned int v[HP * VPL];
 #pragma unroll
               for (int c2 = 0; c2 < HP; ++c2)
@@ -696,11 +737,11 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
                   const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, old),
                                                             __builtin_bit_cast(u16x2, v[c2 * VPL + j]));
                   const unsigned int nk = __builtin_bit_cast(unsigned int, r);
-                  if (nk != old) scratch[c2 * NPAD + lane + 64 * j] = nk;
+                  scratch[c2 * NPAD + lane + 64 * j] = nk;
                   kp[c2 * VPL + j] = nk;
                 }
               wave_lds_order();
-            }
+            });
             // back to (seq << 8) | source; rank 0 never results from an update
 #pragma unroll
             for (int c = 0; c < PC; ++c)

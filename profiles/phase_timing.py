@@ -14,11 +14,15 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diral_amd.config import c2_config  # noqa: E402
+from diral_amd.config import bench_config, c2_config  # noqa: E402
 from diral_amd.vec_env import VecV2VEnv  # noqa: E402
 
 B = int(os.environ.get("B", 4096))
-env = VecV2VEnv(c2_config(), batch=B, out_dtype=torch.float32)
+WL = os.environ.get("WORKLOAD", "c2")
+cfg = {"c2": c2_config(), "c3": bench_config(256, 64, 4000.0), "c5": bench_config(128, 64, 4000.0)}[WL]
+NW = {"c2": 4, "c3": 16, "c5": 8}[WL]
+GENERAL = WL != "c2"
+env = VecV2VEnv(cfg, batch=B, out_dtype=torch.float32)
 env.reset_topology(seed=1)
 acts = [env.sample(seed=i) for i in range(8)]
 for t in range(60):
@@ -26,14 +30,17 @@ for t in range(60):
 torch.cuda.synchronize()
 fn = env.lib.diral_env_debug_timing
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros((B, 4, 8), np.uint64)
-assert fn(env._h, buf.ctypes.data_as(ctypes.c_void_p), 4) == 0
+buf = np.zeros((B, NW, 8), np.uint64)
+assert fn(env._h, buf.ctypes.data_as(ctypes.c_void_p), NW) == 0
 t = buf.astype(np.int64)
 names = ["P0 loads/init", "P1 closest-tx", "barrier+P2", "P3 merge", "P3 finalize+hist", "wait barrier", "P4 output"]
+if GENERAL:   # step_kernel.hpp stamps (merge/finalize of the LAST pass only)
+    names = ["P0 load+barrier", "P1 closest-tx", "wait barrier", "P2 rewards", "P3 all passes but last finalize",
+             "P3 last finalize+hist", "wait barrier"]
 d = np.diff(t, axis=2)
 print("B=%d; mean cycles per wave per phase (s_memtime ticks), by wave:" % B)
 for i, n in enumerate(names):
-    print("  %-18s %s   all=%.0f" % (n, " ".join("%7.0f" % d[:, w, i].mean() for w in range(4)), d[:, :, i].mean()))
+    print("  %-32s %s   all=%.0f" % (n, " ".join("%7.0f" % d[:, w, i].mean() for w in range(min(NW, 4))), d[:, :, i].mean()))
 life = (t[:, :, 7] - t[:, :, 0])
 print("  wave lifetime: mean %.0f  p50 %.0f  p99 %.0f" % (life.mean(), np.median(life), np.percentile(life, 99)))
 span = t[:, :, 7].max() - t[:, :, 0].min()
