@@ -495,7 +495,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
 
     // finalize one column: xpos follows the winning sequence number, age resets on
     // change, then the viewer-side histogram contribution of the entry
-    auto finalize = [&](int k, const unsigned int* kf_j, const unsigned int* w_j, double xpre) {
+    auto finalize = [&](int k, const unsigned int* kf_j, const unsigned int* w_j, const double* xo_j) {
       const double pxk = s_px[k], pyk = s_py[k];
       double xn[VPL];
       unsigned int wn[VPL];
@@ -506,8 +506,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
         const unsigned int kf = kf_j[j], w = w_j[j];
         const unsigned int src = kf & 255u;
         const bool upd = ((kf ^ w) >> 8) != 0u;
-        double xo = xpre;
-        if (VPL > 1 || !DIRAL_PREFETCH) xo = (u < N) ? p.tx[(bR + k) * NV + u] : 0.0;
+        double xo = xo_j[j];                                   // loaded by the caller, all columns at once
         if (do_step && u == k) xo = pxk;                       // own stamp (vehicle.py:63)
         double xg = xo;
         if constexpr (VPL == 1) {
@@ -660,9 +659,15 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
           }
         }
         DIRAL_STAMP(5);
+        double xo1[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (DIRAL_PREFETCH) xo1[c] = pre_x[c];
+          else xo1[c] = (kbase + c < N && lane < N) ? p.tx[(bR + kbase + c) * NV + lane] : 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-          if (kbase + c < N) finalize(kbase + c, &key[c], &w1[c], DIRAL_PREFETCH ? pre_x[c] : 0.0);
+          if (kbase + c < N) finalize(kbase + c, &key[c], &w1[c], &xo1[c]);
       }
     } else {
       // N > 64.  CC columns per pass (16 key registers); packed as CC/2 column PAIRS of 16-bit keys
@@ -760,9 +765,20 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
           }
         }
         DIRAL_STAMP(5);
+        // every xpos load of the pass is issued before the first column is finalized
+        // (the LDS-ordering barriers inside finalize() would otherwise pin each
+        // column's loads behind the previous column: one HBM round trip per column)
+        double xo_all[PC * VPL];
 #pragma unroll
         for (int c = 0; c < PC; ++c)
-          if (kbase + c < N) finalize(kbase + c, &key[c * VPL], &w1[c * VPL], 0.0);
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            xo_all[c * VPL + j] = (kbase + c < N && u < N) ? p.tx[(bR + kbase + c) * NV + u] : 0.0;
+          }
+#pragma unroll
+        for (int c = 0; c < PC; ++c)
+          if (kbase + c < N) finalize(kbase + c, &key[c * VPL], &w1[c * VPL], &xo_all[c * VPL]);
       }
     }
     if (seq_ovf) atomicOr(p.err, kErrSeq);
