@@ -192,16 +192,18 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (!live) { myact = -1; mypx = 0.0; mypy = 0.0; myvel = 0.0; }
   // this wave's 16 subject columns (rows are padded to a multiple of 16, viewers
   // to 64: no predicate), issued AFTER the small loads (vmcnt retires in order)
-  unsigned int* const tk = p.tkey + ((size_t)b * p.NR + wave * 16) * NV + lane;
-  double* const txp = p.tx + ((size_t)b * p.NR + wave * 16) * NV + lane;
+  // wave-uniform base pointers + a per-lane element offset: lets the compiler use the
+  // scalar-base addressing form instead of 64-bit per-lane pointer arithmetic
+  unsigned int* const tk = p.tkey + ((size_t)b * p.NR + wave * 16) * NV;
+  double* const txp = p.tx + ((size_t)b * p.NR + wave * 16) * NV;
   const bool has_cols = wave * 16 < p.NR;      // uniform: idle waves of a small env
   // (unconditional: a branch around the loads would make the compiler wait for
   // ALL of them at the first use of the per-vehicle values - the waitcnt pass
   // merges both paths conservatively; idle waves of a small env re-read row 0)
-  const unsigned int* const tk_ld = has_cols ? tk : p.tkey + (size_t)b * p.NR * NV + lane;
+  const unsigned int* const tk_ld = has_cols ? tk : p.tkey + (size_t)b * p.NR * NV;
   unsigned int w1[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) w1[c] = tk_ld[c * NV];
+  for (int c = 0; c < 16; ++c) w1[c] = tk_ld[c * NV + lane];
   __builtin_amdgcn_sched_barrier(0);
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
   const double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;       // network.py:203
@@ -388,12 +390,11 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // unrolled form, which costs 27 VGPRs = 3 waves/SIMD of occupancy; the next
   // column's xpos load is issued one iteration ahead)
   const int ncol = has_cols ? 16 : 0;
-  double x_next = has_cols ? txp[0] : 0.0;
+  double x_next = has_cols ? txp[lane] : 0.0;
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
-    {
     const int k = wave * 16 + c;
-    const int off = c * NV;
+    const int off = c * NV + lane;
     const unsigned int kf = key[c], w = w1[c];
     const bool upd = ((kf ^ w) >> 8) != 0u;
     const double x_cur = x_next;
@@ -406,20 +407,33 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const unsigned int wn = upd ? (kf & ~255u) : w;
     tk[off] = wn;
     if (upd || lane == k) txp[off] = xg;
-    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
-    double y1 = 0.0;
-    if (!FLAT) { const double pyk = readlane_f64(mypy, k); y1 = (wn >> 8) ? pyk : 0.0; }
-    const double d = fast_dist<FLAT>(xg, y1, mynpx, mypy);
+    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513):
+    // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
+    double d, v;
+    if constexpr (FLAT) {
+      // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v|
+      v = xg - mynpx;
+      const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+      d = __hiloint2double((int)vh, __double2loint(v));
+      if (!((vh - 0x20b00000u) <= (0x5f300000u - 0x20b00000u))) {   // |v| outside [2^-500, 2^500] or 0
+        d = dist_general(mynpx - xg, 0.0);
+        v = (xg - mynpx > 0.0) ? d : -d;
+      }
+    } else {
+      const double pyk = readlane_f64(mypy, k);
+      d = fast_dist<false>(xg, (wn >> 8) ? pyk : 0.0, mynpx, mypy);
+      v = (xg - mynpx > 0.0) ? d : -d;
+    }
     const bool ok = live && (k < N) && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
     if (ok) {
-      const double v = (xg - mynpx > 0.0) ? d : -d;
+      // |v| < Rb, so the estimate is in [0, K] and the edge correction needs no bounds
+      // tests: edges[0] = -Rb <= v and v < Rb = edges[K] hold by construction
       int est = (int)((v + p.Rb) * inv_w);
-      est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
+      est = est > K - 1 ? K - 1 : est;
       const double e0 = s_edges[est], e1 = s_edges[est + 1];
-      const int bin = est + ((v >= e1 && est < K - 1) ? 1 : 0) - ((v < e0 && est > 0) ? 1 : 0);
+      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
       atomicAdd(&hrow[bin], 1u);
       mycnt += 1u;
-    }
     }
   }
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
