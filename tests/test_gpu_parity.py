@@ -622,3 +622,69 @@ def test_step_is_capturable_in_a_hip_graph():
     assert torch.equal(obs_e, obs_g) and torch.equal(rew_e, rew_g)
     se, sg = eager.export_state(), graphed.export_state()
     assert torch.equal(se["seq"], sg["seq"]) and torch.equal(se["x"], sg["x"])
+
+
+def test_cabi_optional_outputs_and_seeds():
+    """C-ABI details: NULL reward/done/chobs outputs are allowed; the device
+    topology RNG is a pure function of the seed; metrics clear on request."""
+    import ctypes
+    from diral_amd import _lib
+    cfg = c2_config()
+    lib = _lib.load()
+    a, b, c = make_env(cfg, 16, dtype=torch.float32), make_env(cfg, 16, dtype=torch.float32), \
+        make_env(cfg, 16, dtype=torch.float32)
+    a.reset_topology(seed=11)
+    b.reset_topology(seed=11)
+    c.reset_topology(seed=12)
+    sa, sb, sc = a.export_state(False), b.export_state(False), c.export_state(False)
+    assert torch.equal(sa["pos_x"], sb["pos_x"]) and torch.equal(sa["vel"], sb["vel"])
+    assert not torch.equal(sa["pos_x"], sc["pos_x"])
+    acts = a.sample(seed=5)
+    assert torch.equal(acts, b.sample(seed=5)) and not torch.equal(acts, b.sample(seed=6))
+    # state only: no reward / done / channel-obs buffers
+    obs = torch.zeros((16, 64, 52), dtype=torch.float32, device="cuda")
+    st = lib.diral_env_step(a._h, 0, acts.data_ptr(), 0, obs.data_ptr(), None, None, None, 0, 0.0, 1.0,
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    ob, _, _ = b.step(acts, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(obs, ob)
+    # nothing at all requested but the state advance (state_out NULL => general kernel)
+    assert lib.diral_env_step(a._h, 0, acts.data_ptr(), 1, None, None, None, None, 0, 0.0, 1.0, None) == 0
+    b.step(acts, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a.export_state()["seq"], b.export_state()["seq"])
+    # bad arguments are rejected, not executed
+    assert lib.diral_env_step(a._h, 7, acts.data_ptr(), 0, None, None, None, None, 0, 0.0, 1.0, None) == -1
+    assert lib.diral_env_step(a._h, 0, None, 0, None, None, None, None, 0, 0.0, 1.0, None) == -1
+    assert lib.diral_env_step(a._h, 0, acts.data_ptr(), 0, None, None, None, None, 5, 0.0, 1.0, None) == -1
+    m = b.metrics(clear=True)
+    assert torch.all(m[:, 0] == 2) and torch.all(b.metrics()[:, 0] == 0)
+    assert b.hbm_bytes() > 16 * 64 * 64 * 12
+
+
+def test_two_envs_on_two_streams():
+    """Handles are independent: two envs stepped concurrently on different HIP
+    streams give the results of stepping them one after the other."""
+    cfg = c2_config()
+    B = 256
+    rng = np.random.default_rng(21)
+    acts = [torch.as_tensor(rng.integers(0, 32, size=(B, 64)).astype(np.int32), device="cuda") for _ in range(6)]
+    ser = [make_env(cfg, B, dtype=torch.float32) for _ in range(2)]
+    par = [make_env(cfg, B, dtype=torch.float32) for _ in range(2)]
+    for i in range(2):
+        ser[i].reset_topology(seed=50 + i)
+        par[i].reset_topology(seed=50 + i)
+    for t in range(6):
+        for i in range(2):
+            ser[i].step(acts[(t + i) % 6], t)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for t in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                par[i].step(acts[(t + i) % 6], t)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(ser[i]._obs, par[i]._obs)
+        assert torch.equal(ser[i].export_state()["x"], par[i].export_state()["x"])
