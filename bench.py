@@ -136,7 +136,10 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL group is always created - also for
+    # one rank, so the single-GPU run exercises the same collective code path
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -170,7 +173,7 @@ def main() -> int:
         one_step(t)
         t += 1
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize(device)
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -182,7 +185,7 @@ def main() -> int:
         t += 1
     ev1.record()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize(device)
     wall = time.perf_counter() - t_start
@@ -190,7 +193,7 @@ def main() -> int:
 
     env.check()
     totals = gather_metrics(env)                         # RCCL all-reduce (metrics only)
-    if world > 1:
+    if use_dist:
         w = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
@@ -239,7 +242,7 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return 0
 
