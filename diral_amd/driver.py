@@ -65,7 +65,8 @@ class DriverLoop:
     def __init__(self, env: Any, enable_channel: bool = False, global_reward_avg: bool = False,
                  ia_averaging: bool = False, ia_penalty_enable: bool = False, ia_penalty_threshold: int = 5,
                  ia_penalty_value: float = -10, episode_interval: int = 25,
-                 eps_init: float = 0.99, eps_decay: float = 0.9992, eps_min: float = 0.001):
+                 eps_init: float = 0.99, eps_decay: float = 0.9992, eps_min: float = 0.001,
+                 fused: bool = False):
         self.env = env
         self.enable_channel = enable_channel                  # main_test.py:40
         self.global_reward_avg = global_reward_avg            # :38
@@ -75,6 +76,9 @@ class DriverLoop:
         self.ia_penalty_value = ia_penalty_value              # :51
         self.episode_interval = episode_interval              # :31
         self.eps, self.eps_decay, self.eps_min = eps_init, eps_decay, eps_min   # algorithms/policies.py:38-77
+        # fused=True: my_step + obtain_state in ONE launch (VecV2VEnv.step semantics; same
+        # values, but the channel observation `obs` is not materialised)
+        self.fused = fused
         self.episode = 0
         self.N = env.get_total_users()
         self.A = env.get_action_space()
@@ -110,7 +114,13 @@ class DriverLoop:
     # main_test.py:119-236, everything between the agent's action and memory.add
     def slot(self, action, time_step: int, want_ia: Optional[bool] = None) -> Dict[str, Any]:
         env = self.env
-        if self.enable_channel:
+        fused_state = None
+        if self.fused:
+            from .config import STEP_MY_STEP, STEP_MY_STEP_CH
+            mode = STEP_MY_STEP_CH if self.enable_channel else STEP_MY_STEP
+            fused_state, reward, _ = env._step(mode, env._actions(action), time_step, self.episode, self.eps)
+            obs = None
+        elif self.enable_channel:
             obs, reward = env.my_step_ch(action, time_step)                  # :144
         else:
             obs, reward = env.my_step(action, time_step)                     # :146
@@ -128,7 +138,10 @@ class DriverLoop:
                 ia_penalty = torch.where(ia_sum > prev, -1, torch.where(ia_sum < prev, 1, 0)).to(reward.dtype)
                 self._sum_ia_prev = ia_sum
                 out["ia_penalty"] = ia_penalty
-        next_state = self._t(env.obtain_state(obs, action, reward, self.episode, self.eps)).clone()   # :164
+        if fused_state is not None:
+            next_state = fused_state.clone()
+        else:
+            next_state = self._t(env.obtain_state(obs, action, reward, self.episode, self.eps)).clone()   # :164
         sum_r = np_sum_lastdim(reward)                                       # :171 (NumPy's summation order)
         collision = self.A - sum_r                                           # :178
         a = self._actions(action).to(reward.device)

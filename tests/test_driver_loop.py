@@ -21,8 +21,8 @@ def load(name):
     return d, cfg, json.loads(str(d["opts"]))
 
 
-def run(env, d, opts, exact):
-    loop = DriverLoop(env, enable_channel=opts["enable_channel"], global_reward_avg=opts["global_reward_avg"],
+def run(env, d, opts, exact, fused=False):
+    loop = DriverLoop(env, fused=fused, enable_channel=opts["enable_channel"], global_reward_avg=opts["global_reward_avg"],
                       ia_averaging=opts["ia_averaging"], ia_penalty_enable=opts["ia_penalty_enable"],
                       ia_penalty_threshold=opts["ia_penalty_threshold"], ia_penalty_value=opts["ia_penalty_value"],
                       episode_interval=opts["episode_interval"])
@@ -78,6 +78,8 @@ def test_driver_loop_reproduces_reference_sequence_gpu(name):
     from diral_amd.vec_env import VecV2VEnv
     d, cfg, opts = load(name)
     run(VecV2VEnv(cfg, batch=1, out_dtype=torch.float64), d, opts, exact=False)
+    if not cfg.State.add_reward:       # one fused launch per slot gives the same sequence
+        run(VecV2VEnv(cfg, batch=1, out_dtype=torch.float64), d, opts, exact=False, fused=True)
 
 
 def test_ia_penalty_helper_matches_utils_misc():

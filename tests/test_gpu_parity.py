@@ -688,3 +688,14 @@ def test_two_envs_on_two_streams():
     for i in range(2):
         assert torch.equal(ser[i]._obs, par[i]._obs)
         assert torch.equal(ser[i].export_state()["x"], par[i].export_state()["x"])
+
+
+def test_example_rollout_script_runs():
+    import subprocess
+    import sys
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    for pol in ("sps", "random"):
+        out = subprocess.run([sys.executable, "examples/rollout_sps.py", "--envs", "64", "--slots", "60",
+                              "--policy", pol], cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "collision fraction" in out.stdout
