@@ -99,6 +99,34 @@ def cpu_baseline(cfg, seconds_target: float = 12.0):
     }
 
 
+def prr_parity(cfg, device, envs: int = 64, slots: int = 60):
+    """PRR parity on a bounded sample (BASELINE.json: 'PRR matching the reference
+    within 1e-6'): the same seeded envs and actions through the HIP path
+    (my_step_ch, test_env.py:384-405 ratio R per transmission) and through the CPU
+    oracle in its reference-faithful mode; episode PRR = mean R over transmissions."""
+    import numpy as np
+    from oracle.oracle import Oracle, SQ_POW
+    from diral_amd.config import STEP_MY_STEP_CH
+    N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
+    rng = np.random.default_rng(4321)
+    x0 = rng.integers(0, int(L), size=(envs, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(envs, N))
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float64, step_mode="my_step_ch")
+    env.reset_topology(x0, None, v0)
+    orc = Oracle(cfg, batch=envs, sq_mode=SQ_POW, threads=min(usable_cores(), 16))
+    orc.reset(x0, np.zeros((envs, N)), v0)
+    for t in range(slots):
+        a = rng.integers(0, A, size=(envs, N)).astype(np.int32)
+        env.step(a, t)
+        orc.step(STEP_MY_STEP_CH, a, t)
+    m, om = env.metrics().cpu().numpy(), orc.metrics()
+    gpu = float(m[:, 4].sum() / m[:, 5].sum())
+    cpu = float(om[:, 4].sum() / om[:, 5].sum())
+    per_env = np.abs(m[:, 4] / m[:, 5] - om[:, 4] / om[:, 5]).max()
+    return {"gpu": gpu, "cpu_oracle": cpu, "abs_diff": abs(gpu - cpu), "max_abs_diff_per_env": float(per_env),
+            "tolerance": 1e-6, "sample": "%d envs x %d slots, my_step_ch, reward_design %d" % (envs, slots, cfg.reward_design)}
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the committed PMC summary (profiles/), if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -241,6 +269,7 @@ def main() -> int:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+            line["prr_parity"] = prr_parity(cfg, device)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
