@@ -152,3 +152,19 @@ def test_histogram_bin_edges_sweep():
             ref = np.histogram(sorted(vals), K, range=(-rb, rb))[0] / float(len(vals)) \
                 if vals else np.zeros(K)
             assert np.array_equal(hist, ref), (K, rb, chunk)
+
+
+def test_oracle_under_sanitizers():
+    """the CPU restatement built with -fsanitize=address,undefined
+    and driven through every step kind / reward design / observation mode."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", odir, "san_check"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(odir, "san_check")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    assert "san_check ok" in out.stdout
