@@ -259,7 +259,8 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args.workload),
-                "kernel": ("diral::step_fast64_kernel<true>" if (N <= 64 and A <= 32 and args.out_dtype == "f32")
+                "kernel": ("diral::step_fast64_kernel<true,%s>" % ("false" if args.out_dtype == "f32" else "true")
+                           if (N <= 64 and A <= 32)
                            else "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
                                                                "true" if args.out_dtype == "f32" else "false")),
                 "kernel_ms": kernel_ms,

@@ -109,28 +109,35 @@ hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
 }
 
 // FAST instantiation = the metric's configuration (see step_kernel.hpp): the
-// toy YAML's State flags, my_step, f32 outputs, no optional side outputs.
-bool is_fast(const StepParams& p) {
+// toy YAML's State flags, my_step, no optional side outputs (the generic FAST
+// instantiation additionally needs f32 outputs; step_fast64 has both).
+bool is_fast_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
-  return (p.flags & ~ignore) == want && p.posdist_type == 2 && p.mode == DIRAL_STEP_MY_STEP && !p.out_f64 &&
+  return (p.flags & ~ignore) == want && p.posdist_type == 2 && p.mode == DIRAL_STEP_MY_STEP &&
          p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
 }
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
-  const bool fast = is_fast(p);
-  if (fast && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64")) {
+  const bool fast_cfg = is_fast_cfg(p), fast = fast_cfg && !p.out_f64;
+  if (fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64")) {
     FastParams f;
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
-    f.state_out = reinterpret_cast<float*>(p.state_out); f.rew_out = reinterpret_cast<float*>(p.rew_out);
+    f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
     const uint32_t fl = fast_lds_layout(p.K).total;
-    if (flat_y) hipLaunchKernelGGL(step_fast64_kernel<true>, dim3(p.B), dim3(256), fl, s, f);
-    else hipLaunchKernelGGL(step_fast64_kernel<false>, dim3(p.B), dim3(256), fl, s, f);
+    const dim3 g(p.B), t(256);
+    if (p.out_f64) {
+      if (flat_y) hipLaunchKernelGGL((step_fast64_kernel<true, true>), g, t, fl, s, f);
+      else hipLaunchKernelGGL((step_fast64_kernel<false, true>), g, t, fl, s, f);
+    } else {
+      if (flat_y) hipLaunchKernelGGL((step_fast64_kernel<true, false>), g, t, fl, s, f);
+      else hipLaunchKernelGGL((step_fast64_kernel<false, false>), g, t, fl, s, f);
+    }
     return hipGetLastError();
   }
   switch (vpl) {

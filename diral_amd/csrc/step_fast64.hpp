@@ -1,7 +1,7 @@
 // step_fast64.hpp - the fused env-step kernel specialised for the headline
 // configuration: N <= 64 vehicles (one wavefront lane per vehicle), A <= 32
 // resources, the toy YAML's State flags (one-hot action + type-2 piggybacked
-// positional histogram), my_step + obtain_state, float32 outputs.
+// positional histogram), my_step + obtain_state, float32 or float64 outputs.
 //
 // Same semantics as step_kernel.hpp (which stays the general path and is what
 // the parity tests compare this kernel against, bit for bit); what changes is
@@ -54,8 +54,8 @@ struct FastParams {
   double* metrics;
   uint32_t* err;
   const double* edges;
-  float* state_out;
-  float* rew_out;
+  void* state_out;                // float* or double* (OUT64)
+  void* rew_out;
   uint8_t* done_out;
   unsigned long long* dbg;
 };
@@ -156,7 +156,7 @@ __device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32
 #define DIRAL_FSTAMP(i) do {} while (0)
 #endif
 
-template <bool FLAT>
+template <bool FLAT, bool OUT64>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FastLds lay = fast_lds_layout(p.K);
@@ -262,7 +262,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (live && myact >= 0) {
       const int c = __popcll(s_mask[myact]);
       if (c > 1) { r = s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222
-      if (p.rew_out) p.rew_out[bN + lane] = (float)r;
+      if (p.rew_out) {
+        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = r;
+        else static_cast<float*>(p.rew_out)[bN + lane] = (float)r;
+      }
     }
     double vr = r;
     int vs = sole, vc = coll;
@@ -441,9 +444,42 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   __syncthreads();
   DIRAL_FSTAMP(6);
 
-  // ---- P4: state = [one-hot(action) (A) | histogram (K)], float32 ----------------
+  // ---- P4: state = [one-hot(action) (A) | histogram (K)] ---------------------------
+  // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
+  // divided by the neighbour count) or float32 (= the float32 cast of that value).
   const int S = A + K;
-  float* out = p.state_out + bN * S;
+  if constexpr (OUT64) {
+    double* out = static_cast<double*>(p.state_out) + bN * S;
+    if (((A | K) & 1) == 0) {
+      const int q_per_row = S >> 1, total = N * q_per_row;
+      for (int q = tid; q < total; q += 256) {
+        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 1;
+        double2 v;
+        if (s0 < A) {
+          const int a = s_act[u] - s0;
+          v = make_double2(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0);
+        } else {
+          const unsigned int n = s_cnt[u];
+          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          const double dn = (double)n;
+          v = n ? make_double2((double)h[0] / dn, (double)h[1] / dn) : make_double2(0.0, 0.0);
+        }
+        reinterpret_cast<double2*>(out)[q] = v;
+      }
+    } else {
+      for (int e = tid; e < N * S; e += 256) {
+        const int u = e / S, s = e - u * S;
+        double val;
+        if (s < A) val = (s_act[u] == s) ? 1.0 : 0.0;
+        else {
+          const unsigned int n = s_cnt[u];
+          val = n ? (double)s_hist[u * KP + (s - A)] / (double)n : 0.0;
+        }
+        out[e] = val;
+      }
+    }
+  } else {
+  float* out = static_cast<float*>(p.state_out) + bN * S;
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
     for (int q = tid; q < total; q += 256) {
@@ -474,6 +510,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
       out[e] = val;
     }
+  }
   }
   DIRAL_FSTAMP(7);
 }

@@ -361,10 +361,22 @@ def test_replica_envs_are_identical_at_scale():
                                            (33, 7, 20, 2, False), (64, 5, 8, 2, False), (1, 1, 4, 2, False),
                                            (17, 32, 64, 2, False)])
 def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
-    """The headline-config kernel (csrc/step_fast64.hpp: f32 outputs, default
-    State flags) against the general kernel (f64 outputs) and the oracle: states
-    equal after the f32 cast, rewards, positions and every table plane identical."""
+    """The headline-config kernel (csrc/step_fast64.hpp, f32 and f64 outputs,
+    default State flags) against the general kernel (f64 outputs, forced with
+    DIRAL_NO_FAST64) and the oracle: f64 states identical, f32 states equal to
+    their cast, rewards, positions and every table plane identical."""
+    import contextlib
+    import os
     from oracle.oracle import Oracle, SQ_IEEE
+
+    @contextlib.contextmanager
+    def general_kernel():
+        os.environ["DIRAL_NO_FAST64"] = "1"      # read at every launch (csrc/diral_env.hip)
+        try:
+            yield
+        finally:
+            del os.environ["DIRAL_NO_FAST64"]
+
     L = 100.0 if toy else 30.0 * N + 100
     cfg = bench_config(N, A, L, reward_design=rd, congestion_test=toy, State=dict(num_bins=K),
                        communication_range=250.0 if N > 8 else 40.0)
@@ -373,29 +385,37 @@ def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
     y0 = rng.integers(0, 2, size=(B, N)).astype(np.float64) if toy else np.zeros((B, N))
     v0 = rng.uniform(1.1, 2.7, size=(B, N))
-    fast, gen = make_env(cfg, B, dtype=torch.float32), make_env(cfg, B, dtype=torch.float64)
+    fast, fast64, gen = (make_env(cfg, B, dtype=torch.float32), make_env(cfg, B, dtype=torch.float64),
+                         make_env(cfg, B, dtype=torch.float64))
     orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
-    for e in (fast, gen):
+    for e in (fast, fast64, gen):
         e.reset_topology(x0, y0, v0)
     orc.reset(x0, y0, v0)
     for t in range(45):
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         of, rf, df = fast.step(a, t)
-        og, rg, dg = gen.step(a, t)
+        o6, r6, d6 = fast64.step(a, t)
+        with general_kernel():
+            og, rg, dg = gen.step(a, t)
         o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
         o_state = orc.obtain_state(a, o_chobs, o_rew)
         torch.cuda.synchronize()
+        assert torch.equal(o6, og) and torch.equal(r6, rg) and torch.equal(d6, dg), t
+        assert np.array_equal(o6.cpu().numpy(), o_state), t
         assert torch.equal(of, og.to(torch.float32)), t
         assert torch.equal(df, dg)
         assert np.array_equal(of.cpu().numpy(), o_state.astype(np.float32)), t
         if rd in (3, 4):
             assert torch.allclose(rf.double(), rg, rtol=0, atol=1e-6)
+            assert np.all(np.abs(r6.cpu().numpy() - o_rew) <= EXP_ATOL), t
         else:
             assert torch.equal(rf, rg.to(torch.float32)), t
             assert np.array_equal(rf.cpu().numpy(), o_rew.astype(np.float32)), t
-    sf, sg, oe = fast.export_state(), gen.export_state(), orc.export()
+            assert np.array_equal(r6.cpu().numpy(), o_rew), t
+    sf, s6, sg, oe = fast.export_state(), fast64.export_state(), gen.export_state(), orc.export()
     for k in ("pos_x", "vel", "seq", "age", "x", "y"):
         assert torch.equal(sf[k], sg[k]), k
+        assert torch.equal(s6[k], sg[k]), k
     assert np.array_equal(sf["seq"].cpu().numpy(), oe["seq"])
     assert np.array_equal(sf["x"].cpu().numpy(), oe["x"])
     assert np.array_equal(sf["pos_x"].cpu().numpy(), oe["pos_x"])
