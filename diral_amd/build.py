@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiral_env.so")
 SOURCES = ["diral_env.hip"]
-HEADERS = ["common.hpp", "step_kernel.hpp", "aux_kernels.hpp"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))
 
 # -ffp-contract=off: the reference (CPython floats) never fuses a*b+c; the bin
 # edges, distances and the position wrap must round exactly as it does.

@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "step_kernel.hpp"
 #include "step_fast64.hpp"
+#include "step_wide.hpp"
 #include "posdist_kernel.hpp"
 
 using namespace diral;
@@ -120,15 +121,29 @@ bool is_fast_cfg(const StepParams& p) {
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
   const bool fast_cfg = is_fast_cfg(p), fast = fast_cfg && !p.out_f64;
-  if (fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64")) {
+  const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
+  const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
+  if (use_fast64 || use_wide) {
     FastParams f;
-    f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.flags = p.flags;
+    f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
+    if (use_wide) {
+      const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
+      const dim3 g(p.B), t(256 * vpl);
+      if (vpl == 2) {
+        if (p.out_f64) hipLaunchKernelGGL((step_wide_kernel<2, true>), g, t, wl, s, f);
+        else hipLaunchKernelGGL((step_wide_kernel<2, false>), g, t, wl, s, f);
+      } else {
+        if (p.out_f64) hipLaunchKernelGGL((step_wide_kernel<4, true>), g, t, wl, s, f);
+        else hipLaunchKernelGGL((step_wide_kernel<4, false>), g, t, wl, s, f);
+      }
+      return hipGetLastError();
+    }
     const uint32_t fl = fast_lds_layout(p.K).total;
     const dim3 g(p.B), t(256);
     if (p.out_f64) {
@@ -148,10 +163,21 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
 }
 
 template <int VPL>
-hipError_t set_lds_attr(uint32_t lds) {
+hipError_t set_lds_attr(uint32_t lds, int A, int K) {
   hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (r != hipSuccess) return r;
+  if constexpr (VPL > 1) {
+    if (A <= kWideMaxA) {
+      const int wl = (int)wide_lds_layout(VPL, A, K).total;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<VPL, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, wl);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<VPL, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, wl);
+      if (r != hipSuccess) return r;
+    }
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
@@ -287,8 +313,10 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->pos_x, bn * 8));
   CREATE_TRY(alloc((void**)&e->pos_y, bn * 8));
   CREATE_TRY(alloc((void**)&e->vel, bn * 8));
-  CREATE_TRY(alloc((void**)&e->tkey, tab * 4));
-  CREATE_TRY(alloc((void**)&e->tx, tab * 8));
+  // + 256 elements of slack: step_wide.hpp loads a padded viewer slot (lane + 64 j) past the
+  // end of a row without clamping (the values are masked, never stored)
+  CREATE_TRY(alloc((void**)&e->tkey, (tab + 256) * 4));
+  CREATE_TRY(alloc((void**)&e->tx, (tab + 256) * 8));
   CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(alloc((void**)&e->err, 4));
   CREATE_TRY(alloc((void**)&e->yflag, 4));
@@ -309,8 +337,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
   CREATE_TRY(hipMemset(e->vel, 0, bn * 8));
-  CREATE_TRY(hipMemset(e->tkey, 0, tab * 4));
-  CREATE_TRY(hipMemset(e->tx, 0, tab * 8));
+  CREATE_TRY(hipMemset(e->tkey, 0, (tab + 256) * 4));
+  CREATE_TRY(hipMemset(e->tx, 0, (tab + 256) * 8));
   CREATE_TRY(hipMemset(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(hipMemset(e->err, 0, 4));
   if (e->la) CREATE_TRY(hipMemset(e->la, 0xFF, bn * e->N * 4));
@@ -318,9 +346,9 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 
   const LdsLayout l = lds_layout(64 * e->vpl, e->A, e->K, e->vpl, 4 * e->vpl);
   e->lds_bytes = l.total;
-  if (e->vpl == 1) CREATE_TRY(set_lds_attr<1>(l.total));
-  else if (e->vpl == 2) CREATE_TRY(set_lds_attr<2>(l.total));
-  else CREATE_TRY(set_lds_attr<4>(l.total));
+  if (e->vpl == 1) CREATE_TRY(set_lds_attr<1>(l.total, e->A, e->K));
+  else if (e->vpl == 2) CREATE_TRY(set_lds_attr<2>(l.total, e->A, e->K));
+  else CREATE_TRY(set_lds_attr<4>(l.total, e->A, e->K));
 #undef CREATE_TRY
 
   StepParams& p = e->base;

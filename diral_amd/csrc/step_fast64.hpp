@@ -41,6 +41,7 @@ constexpr int kFastMaxA = 32;
 
 struct FastParams {
   int N, A, K, NR;               // NR: padded subject rows (multiple of 16); viewer stride is 64
+  int NV;                        // viewer stride (step_wide.hpp; 64 for step_fast64)
   uint32_t flags;
   int reward_design, age_limit, episode_interval;
   double L, Rc, Rb, inv_w;

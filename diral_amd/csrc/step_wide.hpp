@@ -1,0 +1,640 @@
+// step_wide.hpp - the fused env-step kernel specialised for 64 < N <= 256
+// vehicles (BASELINE.json configs[2] and [4]: 256-UE/64-res congested,
+// 128-UE/64-res dynamic density), the toy YAML's State flags (one-hot action +
+// type-2 piggybacked positional histogram), my_step + obtain_state, all y == 0.
+//
+// Same semantics as step_kernel.hpp (the general path; tests compare the two
+// and the oracle bit for bit).  What the profile of the general kernel showed at
+// N = 256 (profiles/r01/wide_*): one 1024-thread workgroup per CU (115 KB LDS,
+// 128 VGPRs + 40 spilled), the gossip merge moving 16-bit (rank, source) keys
+// through LDS (4.3 KB per resource step per wave), and a finalize phase of
+// ~160 VALU instructions per table entry full of exec-mask control flow.  Here:
+//   * 8-bit merge keys.  For a fixed subject k an entry is determined by its
+//     sequence number, so the merge only has to carry rank = 255 - lag
+//     (lag = t_k - seq against the subject's own fresh sequence number): FOUR
+//     columns per 32-bit LDS word, byte-wise max with SDWA.  Exact while every
+//     entry of the pass has lag < 255 or seq == 0; otherwise the pass takes a
+//     32-bit (seq, source) path, column by column.
+//   * no source tracking: after the merge an updated entry needs the xpos that
+//     belongs to its final sequence number.  Entries with equal (k, seq) hold
+//     equal xpos, so every viewer drops its old xpos into a
+//     256-entry LDS table indexed by its OLD rank and updated entries pick
+//     theirs up by their NEW rank - one LDS write + one LDS read per entry.
+//   * the per-entry state kept across the merge is 16 bits (old rank, age);
+//     64 VGPRs, two 1024-thread workgroups per CU (78 KB LDS each at N = 256).
+//   * branch-free finalize (signed distance x1 - x2 is the histogram value when
+//     all y are 0; bin = estimate + edge correction).
+#pragma once
+#include "common.hpp"
+#include "step_fast64.hpp"
+#include "step_kernel.hpp"
+
+namespace diral {
+
+constexpr int kWideMaxA = 64;
+
+struct WideLds {
+  uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, total;
+};
+__host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
+  const uint32_t npad = 64u * vpl;
+  WideLds l;
+  uint32_t o = 0;
+  l.px = o;    o += 8u * npad;
+  l.npx = o;   o += 8u * npad;
+  l.rv = o;    o += 8u * A;
+  l.edges = o; o += 8u * (K + 2);
+  l.red = o;   o += 8u * 4 * vpl;
+  l.mask = o;  o += 8u * A * vpl;
+  l.act = o;   o += 4u * npad;
+  l.cnt = o;   o += 4u * npad;
+  l.hist = o;  o += 4u * (K | 1) * npad;       // [viewer][K|1]: odd row stride
+  l.mtab = o;  o += (uint32_t)A * 64u * vpl;   // [resource][lane][slot]: gather source viewer (bytes)
+  l.scratch = align_up(o, 16);
+  o = l.scratch + 2048u * 4 * vpl;             // 2 KB per wave: merge words, then the rank -> xpos table
+  l.total = align_up(o, 16);
+  return l;
+}
+
+// byte-wise unsigned max of four packed words (16 ranks) with SDWA.  The four
+// words are interleaved so that no instruction consumes the partial result of
+// the one right before it; the trailing s_nop covers the first consumer the
+// compiler places after the block (it cannot see inside).
+__device__ inline void max_u8x16(unsigned int (&a)[4], const unsigned int (&b)[4]) {
+#define DIRAL_SDWA_MAX(B)                                                                                          \
+  "v_max_u32_sdwa %0, %0, %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %1, %1, %5 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %2, %2, %6 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %3, %3, %7 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t"
+  asm(DIRAL_SDWA_MAX(0) DIRAL_SDWA_MAX(1) DIRAL_SDWA_MAX(2) DIRAL_SDWA_MAX(3) "s_nop 0"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+#undef DIRAL_SDWA_MAX
+}
+
+// Reward of a colliding resource (test_env.py:163-199) for N > 64, positions in
+// LDS, all y == 0.  Out of line: runs ~once per colliding resource.
+template <int VPL>
+__device__ __attribute__((noinline)) double wide_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
+                                                                  const unsigned long long* mkp, int c,
+                                                                  const double* s_px) {
+  int wgt = 0;
+  if (rd == 1 || ((rd == 2 || rd == 5) && c == 2)) {
+    double s = 0.0;                    // calculate_avg_distance (network.py:307-316): combinations order
+    int cnt = 0;
+    for (int ja = 0; ja < VPL; ++ja) {
+      unsigned long long ma = mkp[ja];
+      while (ma) {
+        const int a = ja * 64 + __builtin_ctzll(ma);
+        ma &= ma - 1;
+        for (int jb = ja; jb < VPL; ++jb) {
+          unsigned long long mb = (jb == ja) ? ma : mkp[jb];
+          while (mb) {
+            const int b = jb * 64 + __builtin_ctzll(mb);
+            mb &= mb - 1;
+            s = s + dist2d(s_px[a], 0.0, s_px[b], 0.0);
+            ++cnt;
+          }
+        }
+      }
+    }
+    const double m = s / (double)cnt;
+    if (flags & DIRAL_F_TOY_WEIGHTS) {
+      double x_min = L + 1, x_max = -L - 1;      // calculate_norm (network.py:225-246)
+      int umin = 0, umax = 0;
+      for (int u = 0; u < N; ++u) {
+        const double x = s_px[u];
+        if (x < x_min) { x_min = x; umin = u; }
+        if (x > x_max) { x_max = x; umax = u; }
+      }
+      wgt = (m == dist2d(s_px[umin], 0.0, s_px[umax], 0.0));
+    } else {
+      wgt = (m > Rc);
+    }
+  }
+  if (rd == 1) { const double R = (double)wgt / (double)c; return -1.0 * (1.0 - R); }
+  if (rd == 2) return (c == 2) ? 2.0 * (double)wgt - (double)c : 0.0 - (double)c;
+  if (rd == 3) { const double R = 1.0 / (double)c; return -1.0 * exp(1.0 - R); }
+  if (rd == 4) return 1.0 / (double)c;
+  return (c == 2 && wgt == 1) ? 0.0 : -1.0;
+}
+
+// pins a wave-uniform pointer into an SGPR pair so that loads/stores use the
+// scalar-base + 32-bit lane offset form (otherwise the compiler hoists per-lane
+// 64-bit addresses out of the column loops: 16 VGPRs)
+template <typename T>
+__device__ inline T* uniform_ptr(T* ptr) {
+  return reinterpret_cast<T*>(uniform_u64(reinterpret_cast<unsigned long long>(ptr)));
+}
+
+#ifdef DIRAL_TIMING
+#define DIRAL_WSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DIRAL_WSTAMP(i) do {} while (0)
+#endif
+#ifndef DIRAL_WIDE_MINWAVES
+#define DIRAL_WIDE_MINWAVES 8
+#endif
+
+template <int VPL, bool OUT64>
+__global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kernel(const FastParams p) {
+  constexpr int NPAD = 64 * VPL, WAVES = 4 * VPL, THREADS = 256 * VPL;
+  constexpr int PC = 16 / VPL;                 // subject columns per pass
+  constexpr int NW = PC / 4;                   // packed rank words per viewer slot; NW * VPL == 4
+  static_assert(VPL == 2 || VPL == 4, "one lane holds 2 or 4 viewers");
+  typedef typename std::conditional<VPL == 4, uint32_t, uint16_t>::type mword_t;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  const WideLds lay = wide_lds_layout(VPL, p.A, p.K);
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);
+  double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
+  double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
+  double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
+  double* s_red = reinterpret_cast<double*>(smem + lay.red);
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
+  int* s_act = reinterpret_cast<int*>(smem + lay.act);
+  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
+  mword_t* s_mtab = reinterpret_cast<mword_t*>(smem + lay.mtab);
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, A = p.A, K = p.K, NV = p.NV;
+  const int KP = K | 1;
+  const size_t bN = (size_t)b * N;
+  const size_t bR = (size_t)b * p.NR;
+  DIRAL_WSTAMP(0);
+
+  // ---- P0: per-vehicle state and the post-move position into LDS --------------
+  if (tid < NPAD) {
+    const int u = tid;
+    const bool lv = u < N;
+    const size_t vi = bN + (lv ? u : 0);
+    int a = p.actions[vi];
+    double x = p.pos_x[vi];
+    const double v = p.vel[vi];
+    if (!lv) { a = -1; x = 0.0; }
+    if (lv && (a < 0 || a >= A)) { atomicOr(p.err, kErrAction); a = -1; }
+    s_act[u] = a;
+    s_px[u] = x;
+    s_npx[u] = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;      // network.py:203
+    s_cnt[u] = 0u;
+  }
+  for (int j = tid; j < KP * NPAD; j += THREADS) s_hist[j] = 0u;
+  if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+  __syncthreads();
+  DIRAL_WSTAMP(1);
+
+  int myact[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) myact[j] = s_act[lane + 64 * j];
+
+  // ---- P1: per owned resource: transmitter set, closest in-range transmitter
+  // per viewer (network.py:378-398: ascending id, strict '<'), gather sources,
+  // collision reward --------------------------------------------------------------
+  {
+    double mypx[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) mypx[j] = s_px[lane + 64 * j];
+#pragma unroll 1
+    for (int i = wave; i < A; i += WAVES) {
+      unsigned long long mk[VPL];
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) { mk[j] = __ballot(myact[j] == i); c += __popcll(mk[j]); }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) s_mask[i * VPL + j] = mk[j];
+      }
+      double best[VPL];
+      int bid[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) { best[j] = 100000.0; bid[j] = -1; }   // network.py:385-386
+#pragma unroll
+      for (int jt = 0; jt < VPL; ++jt) {
+        unsigned long long m = mk[jt];
+        while (m) {
+          const int w = jt * 64 + __builtin_ctzll(m);
+          m &= m - 1;
+          const double xw = s_px[w];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const double d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
+            const bool bt = (d < p.Rc) && (d < best[j]);
+            best[j] = bt ? d : best[j];
+            bid[j] = bt ? w : bid[j];
+          }
+        }
+      }
+      unsigned int mw = 0u;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;
+        const bool got = (myact[j] != i) && (bid[j] >= 0) && (u < N);
+        mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
+      }
+      s_mtab[i * 64 + lane] = (mword_t)mw;
+      if (c > 1) {                                              // test_env.py:159-199
+        double rw;
+        if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
+          if (c == 2) {
+            // the two transmitters, ascending (network.py:291-295 weight of a pair)
+            int ab[2], n = 0;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              unsigned long long m = mk[j];
+              while (m) { ab[n < 2 ? n : 1] = j * 64 + __builtin_ctzll(m); ++n; m &= m - 1; }
+            }
+            const double dab = fast_dist<true>(s_px[ab[0]], 0.0, s_px[ab[1]], 0.0);
+            rw = 2.0 * (double)(dab > p.Rc) - (double)c;       // (0 + d) / 1 == d exactly
+          } else {
+            rw = 0.0 - (double)c;
+          }
+        } else {
+          rw = wide_collision_reward<VPL>(p.reward_design, p.flags, p.L, p.Rc, N, s_mask + i * VPL, c, s_px);
+        }
+        if (lane == 0) s_rv[i] = rw;
+      }
+    }
+  }
+  DIRAL_WSTAMP(2);
+  __syncthreads();
+  DIRAL_WSTAMP(3);
+
+  // ---- P2 (first VPL waves): reward per transmitter, metric partials, positions --
+  if (tid < NPAD) {
+    const int u = tid;
+    double r = 0.0;
+    int sole = 0, coll = 0;
+    const int a = s_act[u];
+    if (u < N && a >= 0) {
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) c += __popcll(s_mask[a * VPL + j]);
+      if (c > 1) { r = s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222
+      if (p.rew_out) {
+        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = r;
+        else static_cast<float*>(p.rew_out)[bN + u] = (float)r;
+      }
+    }
+    if (u < N) p.pos_x[bN + u] = s_npx[u];
+    double vr = r;
+    int vs = sole, vc = coll;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      vr += __shfl_down(vr, off);
+      vs += __shfl_down(vs, off);
+      vc += __shfl_down(vc, off);
+    }
+    if (lane == 0) {
+      s_red[wave * 4 + 0] = vr; s_red[wave * 4 + 2] = (double)vs; s_red[wave * 4 + 3] = (double)vc;
+    }
+  }
+
+  // ---- P3: stamp + gossip merge + xpos + histogram over this wave's 16 columns ---
+  unsigned int* const sw = reinterpret_cast<unsigned int*>(smem + lay.scratch + 2048u * wave);   // merge words
+  double* const xt = reinterpret_cast<double*>(sw);                                             // rank -> xpos
+  const double inv_w = p.inv_w;
+
+  // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
+  unsigned long long actw;
+  {
+    unsigned long long any = 0ull;
+    if (lane < A) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) any |= s_mask[lane * VPL + j];
+    }
+    actw = __ballot(any != 0ull);
+  }
+
+  // viewer-side tail of one entry: stores, then its histogram contribution
+  // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
+  auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, unsigned int* tkrow, double* txrow) {
+    const int u = lane + 64 * j;
+    const bool lv = (u < N) && kvalid;
+    if (lv) {
+      tkrow[(unsigned int)u] = wn;
+      if (upd || u == k) txrow[(unsigned int)u] = xg;
+    }
+    // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v|
+    double v = xg - s_npx[u];
+    const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+    double d = __hiloint2double((int)vh, __double2loint(v));
+    if (!((vh - 0x20b00000u) <= (0x5f300000u - 0x20b00000u))) {     // |v| outside [2^-500, 2^500] or 0
+      d = dist_general(s_npx[u] - xg, 0.0);
+      v = (xg - s_npx[u] > 0.0) ? d : -d;
+    }
+    const bool ok = lv && (u != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    if (ok) {
+      int est = (int)((v + p.Rb) * inv_w);
+      est = est > K - 1 ? K - 1 : est;
+      const double e0 = s_edges[est], e1 = s_edges[est + 1];
+      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      atomicAdd(&s_hist[u * KP + bin], 1u);
+    }
+  };
+
+  // Table loads are unconditional and unclamped (all 16 of a pass in flight together,
+  // one lane offset + immediate slot offsets): a padded viewer slot u >= N reads past
+  // the row into the next one - or into the 256-element slack behind the last row
+  // (diral_env_create) - and is masked.
+  const unsigned int ul = (unsigned int)lane;
+  // byte c of the packed per-slot words (c wave-uniform, possibly dynamic)
+  auto pick = [&](const unsigned int (&arr)[4], int j, int c) -> unsigned int {
+    unsigned int w = arr[j];
+    if constexpr (NW == 2) w = (c & 4) ? arr[VPL + j] : w;
+    return (w >> (8 * (c & 3))) & 255u;
+  };
+
+  bool ovf = false;
+#pragma unroll 1
+  for (int pch = 0; pch < 16 / PC; ++pch) {
+    const int kbase = wave * 16 + pch * PC;
+    if (kbase >= p.NR) break;
+    // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
+    //    own fresh sequence number
+    unsigned int wraw[PC * VPL];
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const unsigned int* row = uniform_ptr(p.tkey + (bR + kbase + c) * NV);   // rows are padded to 16: in bounds
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned int kp[4] = {0u, 0u, 0u, 0u};       // [word * VPL + slot]: 4 ranks each
+    unsigned int agew[4] = {0u, 0u, 0u, 0u};     // ages, same packing
+    unsigned int tkov = 0u;                      // lane c: column c's fresh sequence number of its subject
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const int k = kbase + c;
+      const bool kval = k < N;
+      unsigned int seq[VPL], age[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;
+        const unsigned int w = (kval && u < N) ? wraw[c * VPL + j] : 0u;
+        const bool own = kval && (u == k);
+        seq[j] = (w >> 8) + (own ? 1u : 0u);
+        const unsigned int a0 = w & 255u;
+        age[j] = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
+        ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
+      }
+      unsigned int t = 0u;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)seq[j], k & 63);
+        t = ((k >> 6) == j) ? cand : t;
+      }
+      tkov = (lane == c) ? t : tkov;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const unsigned int lag = t - seq[j];
+        bad = bad || (lag >= 255u && seq[j] != 0u);
+        const unsigned int rank = lag < 255u ? 255u - lag : 0u;
+        kp[(c >> 2) * VPL + j] |= rank << (8 * (c & 3));
+        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
+      }
+    }
+    const bool packed_ok = (__ballot(bad) == 0ull);
+
+    if (packed_ok) {
+      unsigned int kp0[4];                       // the ranks before the merge
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kp0[q] = kp[q];
+      // -- Vehicle.received_update for every (resource, rx), resources ascending:
+      //    rank[u] = max(rank[u], rank[m_i(u)]) for 4 columns per word
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+      wave_lds_order();
+      unsigned long long rem = actw;
+      unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * 64 + lane] : 0u;
+      while (rem) {
+        rem &= rem - 1;
+        const unsigned int mw = m_next;
+        if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * 64 + lane];
+        unsigned int v[4];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int src = (mw >> (8 * j)) & 255u;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v[w * VPL + j] = sw[w * NPAD + src];
+        }
+        // a transmitter's words are not written during its own resource, so all
+        // gathers of a step may precede all its writes
+        wave_lds_order();
+        max_u8x16(kp, v);
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+        wave_lds_order();
+      }
+      DIRAL_WSTAMP(4);
+
+      // -- xpos follows the winning sequence number; histogram.  One column at a time
+      //    (rolled: uniform byte extraction): old xpos -> xt[old rank]; updated entries
+      //    read xt[new rank].  The next column's xpos is loaded one iteration ahead.
+      double x_next[VPL];
+      {
+        const double* txrow0 = uniform_ptr(p.tx + (bR + kbase) * NV);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) x_next[j] = txrow0[ul + 64u * j];
+      }
+#pragma unroll 1
+      for (int c = 0; c < PC; ++c) {
+        const int k = kbase + c;
+        const bool kvalid = k < N;
+        unsigned int* tkrow = uniform_ptr(p.tkey + (bR + k) * NV);
+        double* txrow = uniform_ptr(p.tx + (bR + k) * NV);
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        double x_cur[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
+        {
+          const double* txn = uniform_ptr(txrow + ((c + 1 < PC) ? NV : 0));   // rows are padded to 16: always in bounds
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
+        }
+        const double pxk = s_px[kvalid ? k : 0];
+        unsigned int rank0[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          rank0[j] = pick(kp0, j, c);
+          x_cur[j] = (u == k) ? pxk : x_cur[j];                // own stamp (vehicle.py:63)
+          if (u < N) xt[rank0[j]] = x_cur[j];
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int rf = pick(kp, j, c);
+          const double xr = xt[rf];
+          const bool upd = rf != rank0[j];
+          const double xg = upd ? xr : x_cur[j];
+          const unsigned int seqf = rf ? tk_own - 255u + rf : 0u;
+          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, c));
+          emit(k, kvalid, j, upd, wn, xg, tkrow, txrow);
+        }
+        wave_lds_order();
+      }
+    } else {
+      // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
+      //    very stale tables: an entry with lag >= 255 and seq != 0)
+      DIRAL_WSTAMP(4);
+      double* const sx = xt;
+#pragma unroll 1
+      for (int c = 0; c < PC; ++c) {
+        const int k = kbase + c;
+        const bool kvalid = k < N;
+        unsigned int* tkrow = p.tkey + (bR + k) * NV;
+        double* txrow = p.tx + (bR + k) * NV;
+        unsigned int ws[VPL], key[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          const bool lv = (u < N);
+          unsigned int w = tkrow[lv ? u : 0];
+          w = (lv && kvalid) ? w : 0u;
+          const bool own = lv && (u == k);
+          const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
+          const unsigned int a0 = w & 255u;
+          ws[j] = (seq << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
+          key[j] = (ws[j] & ~255u) | (unsigned int)u;
+          sw[u] = key[j];
+        }
+        wave_lds_order();
+        unsigned long long rem = actw;
+        while (rem) {
+          const int i = __builtin_ctzll(rem);
+          rem &= rem - 1;
+          const unsigned int mw = (unsigned int)s_mtab[i * 64 + lane];
+          unsigned int v[VPL];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) v[j] = sw[(mw >> (8 * j)) & 255u];
+          wave_lds_order();
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) { key[j] = max(key[j], v[j]); sw[lane + 64 * j] = key[j]; }
+          wave_lds_order();
+        }
+        const double pxk = s_px[kvalid ? k : 0];
+        double xo[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          xo[j] = txrow[u < N ? u : 0];
+          xo[j] = (u == k) ? pxk : xo[j];
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
+        wave_lds_order();
+        double xs[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) xs[j] = sx[key[j] & 255u];
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
+          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow);
+        }
+        wave_lds_order();
+      }
+    }
+  }
+  if (ovf) atomicOr(p.err, kErrSeq);
+  DIRAL_WSTAMP(5);
+  __syncthreads();
+  DIRAL_WSTAMP(6);
+  // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
+  if (tid < NPAD) {
+    unsigned int n = 0u;
+    for (int q = 0; q < K; ++q) n += s_hist[tid * KP + q];
+    s_cnt[tid] = n;
+  }
+  __syncthreads();
+
+  // ---- P4: metrics, done flag, state = [one-hot(action) (A) | histogram (K)] ------
+  if (tid == 0) {
+    if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+    double sr = 0.0, ss = 0.0, sc = 0.0;
+    for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
+    double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+    mt[DIRAL_M_SLOTS] += 1.0;
+    mt[DIRAL_M_SUM_REWARD] += sr;
+    mt[DIRAL_M_TX_SOLE] += ss;
+    mt[DIRAL_M_TX_COLLIDED] += sc;
+  }
+  const int S = A + K;
+  if constexpr (OUT64) {
+    double* out = static_cast<double*>(p.state_out) + bN * S;
+    if (((A | K) & 1) == 0) {
+      const int q_per_row = S >> 1, total = N * q_per_row;
+      for (int q = tid; q < total; q += THREADS) {
+        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 1;
+        double2 v;
+        if (s0 < A) {
+          const int a = s_act[u] - s0;
+          v = make_double2(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0);
+        } else {
+          const unsigned int n = s_cnt[u];
+          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          const double dn = (double)n;
+          v = n ? make_double2((double)h[0] / dn, (double)h[1] / dn) : make_double2(0.0, 0.0);   // network.py:501
+        }
+        reinterpret_cast<double2*>(out)[q] = v;
+      }
+    } else {
+      for (int e = tid; e < N * S; e += THREADS) {
+        const int u = e / S, s = e - u * S;
+        double val;
+        if (s < A) val = (s_act[u] == s) ? 1.0 : 0.0;
+        else {
+          const unsigned int n = s_cnt[u];
+          val = n ? (double)s_hist[u * KP + (s - A)] / (double)n : 0.0;
+        }
+        out[e] = val;
+      }
+    }
+  } else {
+    float* out = static_cast<float*>(p.state_out) + bN * S;
+    if (((A | K) & 3) == 0) {
+      const int q_per_row = S >> 2, total = N * q_per_row;
+      for (int q = tid; q < total; q += THREADS) {
+        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 2;
+        float4 v;
+        if (s0 < A) {
+          const int a = s_act[u] - s0;
+          v = make_float4(a == 0 ? 1.f : 0.f, a == 1 ? 1.f : 0.f, a == 2 ? 1.f : 0.f, a == 3 ? 1.f : 0.f);
+        } else {
+          const unsigned int n = s_cnt[u];
+          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          // exact w.r.t. (float)((double)h/(double)n): see step_kernel.hpp
+          const float fn = (float)n;
+          v = n ? make_float4(__fdiv_rn((float)h[0], fn), __fdiv_rn((float)h[1], fn),
+                              __fdiv_rn((float)h[2], fn), __fdiv_rn((float)h[3], fn))
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        reinterpret_cast<float4*>(out)[q] = v;
+      }
+    } else {
+      for (int e = tid; e < N * S; e += THREADS) {
+        const int u = e / S, s = e - u * S;
+        float val;
+        if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
+        else {
+          const unsigned int n = s_cnt[u];
+          val = n ? __fdiv_rn((float)s_hist[u * KP + (s - A)], (float)n) : 0.f;
+        }
+        out[e] = val;
+      }
+    }
+  }
+  DIRAL_WSTAMP(7);
+}
+
+}  // namespace diral

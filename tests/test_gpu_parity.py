@@ -719,3 +719,115 @@ def test_example_rollout_script_runs():
                               "--policy", pol], cwd=root, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "collision fraction" in out.stdout
+
+
+def _general_kernel():
+    """Context manager: force the general step_kernel (csrc/diral_env.hip reads the
+    variables at every launch)."""
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def cm():
+        os.environ["DIRAL_NO_FAST64"] = "1"
+        os.environ["DIRAL_NO_WIDE"] = "1"
+        try:
+            yield
+        finally:
+            del os.environ["DIRAL_NO_FAST64"]
+            del os.environ["DIRAL_NO_WIDE"]
+    return cm()
+
+
+@pytest.mark.parametrize("N,A,K,rd,toy", [(256, 64, 20, 2, False), (128, 64, 20, 2, False), (130, 33, 10, 1, False),
+                                           (65, 3, 8, 2, False), (200, 64, 40, 5, False), (256, 64, 20, 3, False),
+                                           (100, 7, 20, 4, False), (129, 64, 21, 2, False), (255, 1, 20, 2, False),
+                                           (192, 48, 12, 2, True)])
+def test_wide_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
+    """csrc/step_wide.hpp (64 < N <= 256, default State flags, all y == 0; 8-bit rank
+    merge, rank-indexed xpos hand-over) against the general kernel and the oracle:
+    f64 states identical, f32 states equal to their cast, rewards, positions, metrics
+    and every table plane identical."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    L = 15.0 * N + 100
+    cfg = bench_config(N, A, L, reward_design=rd, congestion_test=toy, State=dict(num_bins=K))
+    rng = np.random.default_rng(2000 + N + A + K + rd)
+    B = 6
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    w32, w64, gen = (make_env(cfg, B, dtype=torch.float32), make_env(cfg, B, dtype=torch.float64),
+                     make_env(cfg, B, dtype=torch.float64))
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (w32, w64, gen):
+        e.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(30):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        o3, r3, d3 = w32.step(a, t)
+        o6, r6, d6 = w64.step(a, t)
+        with _general_kernel():
+            og, rg, dg = gen.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert torch.equal(o6, og) and torch.equal(d6, dg) and torch.equal(d3, dg), t
+        assert np.array_equal(o6.cpu().numpy(), o_state), t
+        assert torch.equal(o3, og.to(torch.float32)), t
+        if rd in (3, 4):
+            assert np.all(np.abs(r6.cpu().numpy() - o_rew) <= EXP_ATOL), t
+            assert torch.allclose(r3.double(), rg, rtol=0, atol=1e-6)
+        else:
+            assert torch.equal(r6, rg) and torch.equal(r3, rg.to(torch.float32)), t
+            assert np.array_equal(r6.cpu().numpy(), o_rew), t
+    s3, s6, sg, oe = w32.export_state(), w64.export_state(), gen.export_state(), orc.export()
+    for k in ("pos_x", "vel", "seq", "age", "x", "y"):
+        assert torch.equal(s3[k], sg[k]), k
+        assert torch.equal(s6[k], sg[k]), k
+    assert np.array_equal(s6["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(s6["x"].cpu().numpy(), oe["x"])
+    assert np.array_equal(s6["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    m6, mg = w64.metrics().cpu().numpy(), gen.metrics().cpu().numpy()
+    assert np.array_equal(m6[:, [0, 2, 3]], mg[:, [0, 2, 3]])
+    assert np.allclose(m6[:, 1], mg[:, 1], rtol=1e-12, atol=1e-9)
+    for e in (w32, w64, gen):
+        e.check()
+
+
+@pytest.mark.parametrize("N,stale_frac", [(256, 0.0), (256, 0.01), (128, 0.3), (150, 0.05)])
+def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac):
+    """step_wide merges 8-bit ranks when every entry of a pass is younger than 255
+    slots (or never heard) and takes the 32-bit (seq, source) path otherwise; imported
+    tables with arbitrarily stale sequence numbers exercise both against the oracle."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    A, T0, B = 64, 5000, 4
+    cfg = bench_config(N, A, 15.0 * N + 100)
+    rng = np.random.default_rng(int(stale_frac * 1000) + N)
+    x0 = rng.integers(0, int(cfg.highway_length), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    seq = T0 - rng.integers(0, 40, size=(B, N, N))
+    stale = rng.random((B, N, N)) < stale_frac
+    seq = np.where(stale, rng.integers(0, T0 - 255, size=(B, N, N)), seq)   # lag >= 255, some seq == 0
+    seq = np.where(rng.random((B, N, N)) < 0.05, 0, seq)                    # never-heard entries
+    seq[:, np.arange(N), np.arange(N)] = T0
+    age = rng.integers(0, 40, size=(B, N, N))
+    kk = np.arange(N)[None, None, :]
+    bb = np.arange(B)[:, None, None]
+    x = ((kk * 7919 + seq * 104729 + bb * 31) % 200000) / 100.0   # xpos is a function of (subject, seq)
+    env = make_env(cfg, B, dtype=torch.float64)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    env.reset_topology(x0, None, v0)
+    env.import_state(seq=seq, age=age, x=x)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    orc.import_state(seq=seq, age=age, x=x, y=np.zeros((B, N, N)))
+    for t in range(12):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert np.array_equal(obs.cpu().numpy(), o_state), t
+    st, oe = env.export_state(), orc.export()
+    assert np.array_equal(st["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    env.check()
