@@ -127,6 +127,17 @@ def prr_parity(cfg, device, envs: int = 64, slots: int = 60):
             "tolerance": 1e-6, "sample": "%d envs x %d slots, my_step_ch, reward_design %d" % (envs, slots, cfg.reward_design)}
 
 
+def kernel_name(N: int, A: int, out_dtype: str) -> str:
+    """The step kernel csrc/diral_env.hip dispatches for the bench configuration
+    (default State flags, my_step, all y == 0)."""
+    o64 = "true" if out_dtype == "f64" else "false"
+    if N <= 64 and A <= 32:
+        return "diral::step_fast64_kernel<true,%s>" % o64
+    if 64 < N <= 256 and A <= 64:
+        return "diral::step_wide_kernel<%d,%s>" % (2 if N <= 128 else 4, o64)
+    return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, "false" if out_dtype == "f64" else "true")
+
+
 def load_traffic(workload: str):
     """HBM bytes per launch from the committed PMC summary (profiles/), if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -259,10 +270,7 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args.workload),
-                "kernel": ("diral::step_fast64_kernel<true,%s>" % ("false" if args.out_dtype == "f32" else "true")
-                           if (N <= 64 and A <= 32)
-                           else "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
-                                                               "true" if args.out_dtype == "f32" else "false")),
+                "kernel": kernel_name(N, A, args.out_dtype),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_launch,
             },

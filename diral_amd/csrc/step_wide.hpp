@@ -129,8 +129,10 @@ __device__ inline T* uniform_ptr(T* ptr) {
 
 #ifdef DIRAL_TIMING
 #define DIRAL_WSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIRAL_WCLOCK(v) v = __builtin_amdgcn_s_memtime()
 #else
 #define DIRAL_WSTAMP(i) do {} while (0)
+#define DIRAL_WCLOCK(v) do {} while (0)
 #endif
 #ifndef DIRAL_WIDE_MINWAVES
 #define DIRAL_WIDE_MINWAVES 8
@@ -314,9 +316,13 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
   auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, unsigned int* tkrow, double* txrow) {
     const int u = lane + 64 * j;
     const bool lv = (u < N) && kvalid;
+    // xpos is stored for the whole 64-viewer slot as soon as one of its entries changed
+    // (unchanged lanes rewrite their value): a lane-masked store leaves partially written
+    // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic
+    const bool slot_upd = __ballot(upd || u == k) != 0ull;
     if (lv) {
       tkrow[(unsigned int)u] = wn;
-      if (upd || u == k) txrow[(unsigned int)u] = xg;
+      if (slot_upd) txrow[(unsigned int)u] = xg;
     }
     // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v|
     double v = xg - s_npx[u];
@@ -349,10 +355,13 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
   };
 
   bool ovf = false;
+  unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, acc_load = 0, acc_merge = 0, acc_fin = 0, t_p3 = 0;
+  DIRAL_WCLOCK(t_p3);
 #pragma unroll 1
   for (int pch = 0; pch < 16 / PC; ++pch) {
     const int kbase = wave * 16 + pch * PC;
     if (kbase >= p.NR) break;
+    DIRAL_WCLOCK(tc0);
     // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
     //    own fresh sequence number
     unsigned int wraw[PC * VPL];
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
       }
     }
     const bool packed_ok = (__ballot(bad) == 0ull);
+    DIRAL_WCLOCK(tc1);
 
     if (packed_ok) {
       unsigned int kp0[4];                       // the ranks before the merge
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
           for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
         wave_lds_order();
       }
-      DIRAL_WSTAMP(4);
+      DIRAL_WCLOCK(tc2);
 
       // -- xpos follows the winning sequence number; histogram.  One column at a time
       //    (rolled: uniform byte extraction): old xpos -> xt[old rank]; updated entries
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
     } else {
       // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
       //    very stale tables: an entry with lag >= 255 and seq != 0)
-      DIRAL_WSTAMP(4);
+      DIRAL_WCLOCK(tc2);
       double* const sx = xt;
 #pragma unroll 1
       for (int c = 0; c < PC; ++c) {
@@ -545,11 +555,19 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
         wave_lds_order();
       }
     }
+#ifdef DIRAL_TIMING
+    DIRAL_WCLOCK(tc3);
+    acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
+#endif
   }
   if (ovf) atomicOr(p.err, kErrSeq);
-  DIRAL_WSTAMP(5);
+#ifdef DIRAL_TIMING
+  if (lane == 0 && p.dbg) {      // synthetic stamps: accumulated load / merge / finalize time of all passes
+    unsigned long long* d = p.dbg + ((size_t)b * WAVES + wave) * 8;
+    d[3] = t_p3; d[4] = t_p3 + acc_load; d[5] = d[4] + acc_merge; d[6] = d[5] + acc_fin;
+  }
+#endif
   __syncthreads();
-  DIRAL_WSTAMP(6);
   // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
   if (tid < NPAD) {
     unsigned int n = 0u;

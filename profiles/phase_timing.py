@@ -34,7 +34,11 @@ buf = np.zeros((B, NW, 8), np.uint64)
 assert fn(env._h, buf.ctypes.data_as(ctypes.c_void_p), NW) == 0
 t = buf.astype(np.int64)
 names = ["P0 loads/init", "P1 closest-tx", "barrier+P2", "P3 merge", "P3 finalize+hist", "wait barrier", "P4 output"]
-if GENERAL:   # step_kernel.hpp stamps (merge/finalize of the LAST pass only)
+WIDE = GENERAL and not os.environ.get("DIRAL_NO_WIDE")
+if WIDE:      # step_wide.hpp: load / merge / finalize times are accumulated over the passes
+    names = ["P0 load+barrier", "P1 closest-tx", "barrier+P2", "P3 table loads+stamp+ranks", "P3 merge",
+             "P3 finalize+hist", "barrier+cnt+P4"]
+elif GENERAL:   # step_kernel.hpp stamps (merge/finalize of the LAST pass only)
     names = ["P0 load+barrier", "P1 closest-tx", "wait barrier", "P2 rewards", "P3 all passes but last finalize",
              "P3 last finalize+hist", "wait barrier"]
 d = np.diff(t, axis=2)
