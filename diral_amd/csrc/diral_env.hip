@@ -134,7 +134,7 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     f.done_out = p.done_out; f.dbg = p.dbg;
     if (use_wide) {
       const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
-      const dim3 g(p.B), t(256 * vpl);
+      const dim3 g(p.B), t(64 * wide_waves(vpl));
       if (vpl == 2) {
         if (p.out_f64) hipLaunchKernelGGL((step_wide_kernel<2, true>), g, t, wl, s, f);
         else hipLaunchKernelGGL((step_wide_kernel<2, false>), g, t, wl, s, f);

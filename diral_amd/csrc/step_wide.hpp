@@ -36,6 +36,14 @@ constexpr int kWideMaxA = 64;
 struct WideLds {
   uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, total;
 };
+#ifndef DIRAL_WIDE_WAVES4
+#define DIRAL_WIDE_WAVES4 8              // waves per workgroup at N <= 256 (each owns 256 / waves subject columns)
+#endif
+// waves per workgroup: 8 x 16 columns (N <= 128), 8 x 32 columns (N <= 256)
+__host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DIRAL_WIDE_WAVES4; }
+// histogram row stride in 32-bit words: two 16-bit bins per word (counts <= 255), odd stride
+__host__ __device__ constexpr int wide_hist_stride(int K) { return ((K + 1) / 2) | 1; }
+
 __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   const uint32_t npad = 64u * vpl;
   WideLds l;
@@ -48,10 +56,10 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   l.mask = o;  o += 8u * A * vpl;
   l.act = o;   o += 4u * npad;
   l.cnt = o;   o += 4u * npad;
-  l.hist = o;  o += 4u * (K | 1) * npad;       // [viewer][K|1]: odd row stride
+  l.hist = o;  o += 4u * wide_hist_stride(K) * npad;   // [viewer][stride]: two bins per word
   l.mtab = o;  o += (uint32_t)A * 64u * vpl;   // [resource][lane][slot]: gather source viewer (bytes)
   l.scratch = align_up(o, 16);
-  o = l.scratch + 2048u * 4 * vpl;             // 2 KB per wave: merge words, then the rank -> xpos table
+  o = l.scratch + 2048u * wide_waves(vpl);     // 2 KB per wave: merge words, then the rank -> xpos table
   l.total = align_up(o, 16);
   return l;
 }
@@ -134,15 +142,34 @@ __device__ inline T* uniform_ptr(T* ptr) {
 #define DIRAL_WSTAMP(i) do {} while (0)
 #define DIRAL_WCLOCK(v) do {} while (0)
 #endif
-#ifndef DIRAL_WIDE_MINWAVES
-#define DIRAL_WIDE_MINWAVES 8
+#ifndef DIRAL_WIDE_MINWAVES2
+#define DIRAL_WIDE_MINWAVES2 6           // N <= 128: 84 VGPRs, three 512-thread workgroups per CU (1.61 / 1.68 / 1.76 ms for 6 / 7 / 8)
+#endif
+#ifndef DIRAL_WIDE_MINWAVES4
+#define DIRAL_WIDE_MINWAVES4 6           // N <= 256: 84 VGPRs, three 512-thread workgroups per CU
+#endif
+#ifndef DIRAL_WIDE_XPRE2
+#define DIRAL_WIDE_XPRE2 1
+#endif
+#ifndef DIRAL_WIDE_XPRE4
+#define DIRAL_WIDE_XPRE4 0
+#endif
+#ifndef DIRAL_WIDE_FIN_UNROLL2
+#define DIRAL_WIDE_FIN_UNROLL2 8         // finalize column loop, N <= 128 (8 columns per pass): fully unrolled
+#endif
+#ifndef DIRAL_WIDE_FIN_UNROLL4
+#define DIRAL_WIDE_FIN_UNROLL4 2         // N <= 256 (4 columns per pass): by two (64-VGPR budget; measured 3.42 / 3.60 / 4.00 ms for 2 / 1 / 4)
 #endif
 
 template <int VPL, bool OUT64>
-__global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kernel(const FastParams p) {
-  constexpr int NPAD = 64 * VPL, WAVES = 4 * VPL, THREADS = 256 * VPL;
+__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p) {
+  constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
+  constexpr int CPW = NPAD / WAVES;            // subject columns per wave
   constexpr int PC = 16 / VPL;                 // subject columns per pass
   constexpr int NW = PC / 4;                   // packed rank words per viewer slot; NW * VPL == 4
+  constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
+  // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
+  constexpr bool XPRE = VPL == 2 ? (DIRAL_WIDE_XPRE2 != 0) : (DIRAL_WIDE_XPRE4 != 0);
   static_assert(VPL == 2 || VPL == 4, "one lane holds 2 or 4 viewers");
   typedef typename std::conditional<VPL == 4, uint32_t, uint16_t>::type mword_t;
 
@@ -164,7 +191,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, A = p.A, K = p.K, NV = p.NV;
-  const int KP = K | 1;
+  const int KP = wide_hist_stride(K);          // histogram row stride (words, two bins each)
   const size_t bN = (size_t)b * N;
   const size_t bR = (size_t)b * p.NR;
   DIRAL_WSTAMP(0);
@@ -321,8 +348,12 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
     // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic
     const bool slot_upd = __ballot(upd || u == k) != 0ull;
     if (lv) {
+#ifndef DIRAL_EXP_NO_TKSTORE
       tkrow[(unsigned int)u] = wn;
+#endif
+#ifndef DIRAL_EXP_NO_TXSTORE
       if (slot_upd) txrow[(unsigned int)u] = xg;
+#endif
     }
     // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v|
     double v = xg - s_npx[u];
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
       est = est > K - 1 ? K - 1 : est;
       const double e0 = s_edges[est], e1 = s_edges[est + 1];
       const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
-      atomicAdd(&s_hist[u * KP + bin], 1u);
+      atomicAdd(&s_hist[u * KP + (bin >> 1)], 1u << (16 * (bin & 1)));
     }
   };
 
@@ -358,8 +389,8 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
   unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, acc_load = 0, acc_merge = 0, acc_fin = 0, t_p3 = 0;
   DIRAL_WCLOCK(t_p3);
 #pragma unroll 1
-  for (int pch = 0; pch < 16 / PC; ++pch) {
-    const int kbase = wave * 16 + pch * PC;
+  for (int pch = 0; pch < CPW / PC; ++pch) {
+    const int kbase = wave * CPW + pch * PC;
     if (kbase >= p.NR) break;
     DIRAL_WCLOCK(tc0);
     // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
@@ -450,12 +481,12 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
       //    (rolled: uniform byte extraction): old xpos -> xt[old rank]; updated entries
       //    read xt[new rank].  The next column's xpos is loaded one iteration ahead.
       double x_next[VPL];
-      {
+      if constexpr (XPRE) {
         const double* txrow0 = uniform_ptr(p.tx + (bR + kbase) * NV);
 #pragma unroll
         for (int j = 0; j < VPL; ++j) x_next[j] = txrow0[ul + 64u * j];
       }
-#pragma unroll 1
+#pragma unroll FIN_UNROLL
       for (int c = 0; c < PC; ++c) {
         const int k = kbase + c;
         const bool kvalid = k < N;
@@ -463,12 +494,17 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
         double* txrow = uniform_ptr(p.tx + (bR + k) * NV);
         const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
         double x_cur[VPL];
+        if constexpr (XPRE) {
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
-        {
-          const double* txn = uniform_ptr(txrow + ((c + 1 < PC) ? NV : 0));   // rows are padded to 16: always in bounds
+          for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
+          if (c + 1 < PC) {                                      // static: the column loop is fully unrolled
+            const double* txn = uniform_ptr(txrow + NV);
 #pragma unroll
-          for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
+            for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) x_cur[j] = txrow[ul + 64u * j];
         }
         const double pxk = s_px[kvalid ? k : 0];
         unsigned int rank0[VPL];
@@ -571,7 +607,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
   // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
   if (tid < NPAD) {
     unsigned int n = 0u;
-    for (int q = 0; q < K; ++q) n += s_hist[tid * KP + q];
+    for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[tid * KP + q]; n += (w & 0xffffu) + (w >> 16); }
     s_cnt[tid] = n;
   }
   __syncthreads();
@@ -600,9 +636,9 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
           v = make_double2(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0);
         } else {
           const unsigned int n = s_cnt[u];
-          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          const unsigned int hw = s_hist[u * KP + ((s0 - A) >> 1)];           // s0 - A is even: one word
           const double dn = (double)n;
-          v = n ? make_double2((double)h[0] / dn, (double)h[1] / dn) : make_double2(0.0, 0.0);   // network.py:501
+          v = n ? make_double2((double)(hw & 0xffffu) / dn, (double)(hw >> 16) / dn) : make_double2(0.0, 0.0);   // network.py:501
         }
         reinterpret_cast<double2*>(out)[q] = v;
       }
@@ -613,7 +649,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
         if (s < A) val = (s_act[u] == s) ? 1.0 : 0.0;
         else {
           const unsigned int n = s_cnt[u];
-          val = n ? (double)s_hist[u * KP + (s - A)] / (double)n : 0.0;
+          val = n ? (double)((s_hist[u * KP + ((s - A) >> 1)] >> (16 * ((s - A) & 1))) & 0xffffu) / (double)n : 0.0;
         }
         out[e] = val;
       }
@@ -630,11 +666,12 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
           v = make_float4(a == 0 ? 1.f : 0.f, a == 1 ? 1.f : 0.f, a == 2 ? 1.f : 0.f, a == 3 ? 1.f : 0.f);
         } else {
           const unsigned int n = s_cnt[u];
-          const unsigned int* h = s_hist + u * KP + (s0 - A);
+          const unsigned int* hw = s_hist + u * KP + ((s0 - A) >> 1);        // s0 - A is a multiple of 4: two words
+          const unsigned int h01 = hw[0], h23 = hw[1];
           // exact w.r.t. (float)((double)h/(double)n): see step_kernel.hpp
           const float fn = (float)n;
-          v = n ? make_float4(__fdiv_rn((float)h[0], fn), __fdiv_rn((float)h[1], fn),
-                              __fdiv_rn((float)h[2], fn), __fdiv_rn((float)h[3], fn))
+          v = n ? make_float4(__fdiv_rn((float)(h01 & 0xffffu), fn), __fdiv_rn((float)(h01 >> 16), fn),
+                              __fdiv_rn((float)(h23 & 0xffffu), fn), __fdiv_rn((float)(h23 >> 16), fn))
                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         reinterpret_cast<float4*>(out)[q] = v;
@@ -646,7 +683,7 @@ __global__ __launch_bounds__(256 * VPL, DIRAL_WIDE_MINWAVES) void step_wide_kern
         if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
         else {
           const unsigned int n = s_cnt[u];
-          val = n ? __fdiv_rn((float)s_hist[u * KP + (s - A)], (float)n) : 0.f;
+          val = n ? __fdiv_rn((float)((s_hist[u * KP + ((s - A) >> 1)] >> (16 * ((s - A) & 1))) & 0xffffu), (float)n) : 0.f;
         }
         out[e] = val;
       }
