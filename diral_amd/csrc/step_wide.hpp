@@ -80,6 +80,23 @@ __device__ inline void max_u8x16(unsigned int (&a)[4], const unsigned int (&b)[4
 #undef DIRAL_SDWA_MAX
 }
 
+// byte j of the packed gather-source word, times 4 (the LDS byte address of that
+// viewer's rank word), one SDWA shift each instead of extract + shift
+template <int VPL>
+__device__ inline void unpack_src_x4(unsigned int mw, unsigned int (&a)[VPL]) {
+  if constexpr (VPL == 4) {
+    asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "s"(2u), "v"(mw));
+  } else {
+    asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+        : "=&v"(a[0]), "=&v"(a[1]) : "s"(2u), "v"(mw));
+  }
+}
+
 // Reward of a colliding resource (test_env.py:163-199) for N > 64, positions in
 // LDS, all y == 0.  Out of line: runs ~once per colliding resource.
 template <int VPL>
@@ -127,12 +144,16 @@ __device__ __attribute__((noinline)) double wide_collision_reward(int rd, uint32
   return (c == 2 && wgt == 1) ? 0.0 : -1.0;
 }
 
-// pins a wave-uniform pointer into an SGPR pair so that loads/stores use the
-// scalar-base + 32-bit lane offset form (otherwise the compiler hoists per-lane
-// 64-bit addresses out of the column loops: 16 VGPRs)
+// A wave-uniform row pointer pinned into an SGPR pair, typed as a GLOBAL
+// (address_space(1)) pointer: loads/stores take the scalar-base + 32-bit lane offset
+// form.  Without the pin the compiler hoists per-lane 64-bit addresses out of the column
+// loops (16 VGPRs); without the address space a pointer rebuilt from integers is generic
+// and every access becomes a FLAT instruction (which also counts on lgkmcnt).
 template <typename T>
-__device__ inline T* uniform_ptr(T* ptr) {
-  return reinterpret_cast<T*>(uniform_u64(reinterpret_cast<unsigned long long>(ptr)));
+using global_ptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
+  return (global_ptr<T>)uniform_u64((unsigned long long)(base + elem_off));
 }
 
 #ifdef DIRAL_TIMING
@@ -340,7 +361,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 
   // viewer-side tail of one entry: stores, then its histogram contribution
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
-  auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, unsigned int* tkrow, double* txrow) {
+  auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, global_ptr<unsigned int> tkrow,
+                  global_ptr<double> txrow) {
     const int u = lane + 64 * j;
     const bool lv = (u < N) && kvalid;
     // xpos is stored for the whole 64-viewer slot as soon as one of its entries changed
@@ -398,7 +420,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     unsigned int wraw[PC * VPL];
 #pragma unroll
     for (int c = 0; c < PC; ++c) {
-      const unsigned int* row = uniform_ptr(p.tkey + (bR + kbase + c) * NV);   // rows are padded to 16: in bounds
+      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c) * NV);   // rows are padded to 16: in bounds
 #pragma unroll
       for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
     }
@@ -458,12 +480,14 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         rem &= rem - 1;
         const unsigned int mw = m_next;
         if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * 64 + lane];
-        unsigned int v[4];
+        unsigned int v[4], sa[VPL];
+        unpack_src_x4<VPL>(mw, sa);
+        const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-          const unsigned int src = (mw >> (8 * j)) & 255u;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) v[w * VPL + j] = sw[w * NPAD + src];
+          for (int w = 0; w < NW; ++w)
+            v[w * VPL + j] = *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
         }
         // a transmitter's words are not written during its own resource, so all
         // gathers of a step may precede all its writes
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       //    read xt[new rank].  The next column's xpos is loaded one iteration ahead.
       double x_next[VPL];
       if constexpr (XPRE) {
-        const double* txrow0 = uniform_ptr(p.tx + (bR + kbase) * NV);
+        const global_ptr<const double> txrow0 = uniform_ptr<const double>(p.tx, (bR + kbase) * NV);
 #pragma unroll
         for (int j = 0; j < VPL; ++j) x_next[j] = txrow0[ul + 64u * j];
       }
@@ -490,15 +514,15 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       for (int c = 0; c < PC; ++c) {
         const int k = kbase + c;
         const bool kvalid = k < N;
-        unsigned int* tkrow = uniform_ptr(p.tkey + (bR + k) * NV);
-        double* txrow = uniform_ptr(p.tx + (bR + k) * NV);
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
         const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
         double x_cur[VPL];
         if constexpr (XPRE) {
 #pragma unroll
           for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
           if (c + 1 < PC) {                                      // static: the column loop is fully unrolled
-            const double* txn = uniform_ptr(txrow + NV);
+            const global_ptr<const double> txn = uniform_ptr<const double>(p.tx, (bR + k + 1) * NV);
 #pragma unroll
             for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
           }
@@ -537,8 +561,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       for (int c = 0; c < PC; ++c) {
         const int k = kbase + c;
         const bool kvalid = k < N;
-        unsigned int* tkrow = p.tkey + (bR + k) * NV;
-        double* txrow = p.tx + (bR + k) * NV;
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
         unsigned int ws[VPL], key[VPL];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
