@@ -134,7 +134,7 @@ def kernel_name(N: int, A: int, out_dtype: str) -> str:
     if N <= 64 and A <= 32:
         return "diral::step_fast64_kernel<true,%s>" % o64
     if 64 < N <= 256 and A <= 64:
-        return "diral::step_wide_kernel<%d,%s>" % (2 if N <= 128 else 4, o64)
+        return "diral::step_wide_kernel<%d,%s,%s>" % (2 if N <= 128 else 4, o64, "true" if N in (128, 256) else "false")
     return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, "false" if out_dtype == "f64" else "true")
 
 

@@ -135,13 +135,16 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     if (use_wide) {
       const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
       const dim3 g(p.B), t(64 * wide_waves(vpl));
+      const bool full = p.N == 64 * vpl;
+#define DIRAL_LAUNCH_WIDE(V, O, F) hipLaunchKernelGGL((step_wide_kernel<V, O, F>), g, t, wl, s, f)
       if (vpl == 2) {
-        if (p.out_f64) hipLaunchKernelGGL((step_wide_kernel<2, true>), g, t, wl, s, f);
-        else hipLaunchKernelGGL((step_wide_kernel<2, false>), g, t, wl, s, f);
+        if (p.out_f64) { if (full) DIRAL_LAUNCH_WIDE(2, true, true); else DIRAL_LAUNCH_WIDE(2, true, false); }
+        else { if (full) DIRAL_LAUNCH_WIDE(2, false, true); else DIRAL_LAUNCH_WIDE(2, false, false); }
       } else {
-        if (p.out_f64) hipLaunchKernelGGL((step_wide_kernel<4, true>), g, t, wl, s, f);
-        else hipLaunchKernelGGL((step_wide_kernel<4, false>), g, t, wl, s, f);
+        if (p.out_f64) { if (full) DIRAL_LAUNCH_WIDE(4, true, true); else DIRAL_LAUNCH_WIDE(4, true, false); }
+        else { if (full) DIRAL_LAUNCH_WIDE(4, false, true); else DIRAL_LAUNCH_WIDE(4, false, false); }
       }
+#undef DIRAL_LAUNCH_WIDE
       return hipGetLastError();
     }
     const uint32_t fl = fast_lds_layout(p.K).total;
@@ -170,12 +173,14 @@ hipError_t set_lds_attr(uint32_t lds, int A, int K) {
   if constexpr (VPL > 1) {
     if (A <= kWideMaxA) {
       const int wl = (int)wide_lds_layout(VPL, A, K).total;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<VPL, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, wl);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<VPL, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, wl);
-      if (r != hipSuccess) return r;
+      const void* ks[4] = {reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false>)};
+      for (const void* kf : ks) {
+        r = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, wl);
+        if (r != hipSuccess) return r;
+      }
     }
   }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, false>),

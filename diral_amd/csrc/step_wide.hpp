@@ -182,7 +182,9 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #define DIRAL_WIDE_FIN_UNROLL4 2         // N <= 256 (4 columns per pass): by two (64-VGPR budget; measured 3.42 / 3.60 / 4.00 ms for 2 / 1 / 4)
 #endif
 
-template <int VPL, bool OUT64>
+// FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
+// are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
+template <int VPL, bool OUT64, bool FULL>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, global_ptr<unsigned int> tkrow,
                   global_ptr<double> txrow) {
     const int u = lane + 64 * j;
-    const bool lv = (u < N) && kvalid;
+    const bool lv = FULL || ((u < N) && kvalid);
     // xpos is stored for the whole 64-viewer slot as soon as one of its entries changed
     // (unchanged lanes rewrite their value): a lane-masked store leaves partially written
     // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic
@@ -432,17 +434,21 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
     for (int c = 0; c < PC; ++c) {
       const int k = kbase + c;
-      const bool kval = k < N;
+      const bool kval = FULL || k < N;
       unsigned int seq[VPL], age[VPL];
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
         const int u = lane + 64 * j;
-        const unsigned int w = (kval && u < N) ? wraw[c * VPL + j] : 0u;
-        const bool own = kval && (u == k);
-        seq[j] = (w >> 8) + (own ? 1u : 0u);
+        const unsigned int w = (FULL || (kval && u < N)) ? wraw[c * VPL + j] : 0u;
+        seq[j] = w >> 8;
         const unsigned int a0 = w & 255u;
-        age[j] = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
-        ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
+        age[j] = a0 + (a0 < 255u ? 1u : 0u);
+        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
+          const bool own = kval && (lane == (k & 63));
+          seq[j] += own ? 1u : 0u;
+          age[j] = own ? 0u : age[j];
+          ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
+        }
       }
       unsigned int t = 0u;
 #pragma unroll
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll FIN_UNROLL
       for (int c = 0; c < PC; ++c) {
         const int k = kbase + c;
-        const bool kvalid = k < N;
+        const bool kvalid = FULL || k < N;
         const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
         const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
         const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
           rank0[j] = pick(kp0, j, c);
-          x_cur[j] = (u == k) ? pxk : x_cur[j];                // own stamp (vehicle.py:63)
-          if (u < N) xt[rank0[j]] = x_cur[j];
+          if (j == (k >> 6)) x_cur[j] = (lane == (k & 63)) ? pxk : x_cur[j];   // own stamp (vehicle.py:63), uniform slot
+          if (FULL || u < N) xt[rank0[j]] = x_cur[j];
         }
         wave_lds_order();
 #pragma unroll

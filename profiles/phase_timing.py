@@ -20,7 +20,7 @@ from diral_amd.vec_env import VecV2VEnv  # noqa: E402
 B = int(os.environ.get("B", 4096))
 WL = os.environ.get("WORKLOAD", "c2")
 cfg = {"c2": c2_config(), "c3": bench_config(256, 64, 4000.0), "c5": bench_config(128, 64, 4000.0)}[WL]
-NW = {"c2": 4, "c3": 16, "c5": 8}[WL]
+NW = {"c2": 4, "c3": 8 if not os.environ.get("DIRAL_NO_WIDE") else 16, "c5": 8}[WL]
 GENERAL = WL != "c2"
 env = VecV2VEnv(cfg, batch=B, out_dtype=torch.float32)
 env.reset_topology(seed=1)
