@@ -5,7 +5,7 @@
 //
 // Same semantics as step_kernel.hpp (the general path; tests compare the two
 // and the oracle bit for bit).  What the profile of the general kernel showed at
-// N = 256 (profiles/r01/wide_*): one 1024-thread workgroup per CU (115 KB LDS,
+// N = 256 (profiles/r01/general_c3_before_wide_summary.txt): one 1024-thread workgroup per CU (115 KB LDS,
 // 128 VGPRs + 40 spilled), the gossip merge moving 16-bit (rank, source) keys
 // through LDS (4.3 KB per resource step per wave), and a finalize phase of
 // ~160 VALU instructions per table entry full of exec-mask control flow.  Here:
@@ -21,7 +21,8 @@
 //     256-entry LDS table indexed by its OLD rank and updated entries pick
 //     theirs up by their NEW rank - one LDS write + one LDS read per entry.
 //   * the per-entry state kept across the merge is 16 bits (old rank, age);
-//     64 VGPRs, two 1024-thread workgroups per CU (78 KB LDS each at N = 256).
+//     8 waves per workgroup (16 columns each at N <= 128, 32 at N <= 256), at most
+//     84 VGPRs, three workgroups per CU (52 KB LDS each at N = 256).
 //   * branch-free finalize (signed distance x1 - x2 is the histogram value when
 //     all y are 0; bin = estimate + edge correction).
 #pragma once
@@ -372,12 +373,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic
     const bool slot_upd = __ballot(upd || u == k) != 0ull;
     if (lv) {
-#ifndef DIRAL_EXP_NO_TKSTORE
       tkrow[(unsigned int)u] = wn;
-#endif
-#ifndef DIRAL_EXP_NO_TXSTORE
       if (slot_upd) txrow[(unsigned int)u] = xg;
-#endif
     }
     // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v|
     double v = xg - s_npx[u];
