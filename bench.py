@@ -127,15 +127,18 @@ def prr_parity(cfg, device, envs: int = 64, slots: int = 60):
             "tolerance": 1e-6, "sample": "%d envs x %d slots, my_step_ch, reward_design %d" % (envs, slots, cfg.reward_design)}
 
 
-def kernel_name(N: int, A: int, out_dtype: str) -> str:
+def kernel_name(N: int, A: int, out_dtype: str, step_mode: str = "my_step") -> str:
     """The step kernel csrc/diral_env.hip dispatches for the bench configuration
-    (default State flags, my_step, all y == 0)."""
+    (default State flags, my_step / my_step_ch, all y == 0)."""
     o64 = "true" if out_dtype == "f64" else "false"
+    ch = "true" if step_mode == "my_step_ch" else "false"
     if N <= 64 and A <= 32:
-        return "diral::step_fast64_kernel<true,%s>" % o64
+        return "diral::step_fast64_kernel<true,%s,%s>" % (o64, ch)
     if 64 < N <= 256 and A <= 64:
-        return "diral::step_wide_kernel<%d,%s,%s>" % (2 if N <= 128 else 4, o64, "true" if N in (128, 256) else "false")
-    return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, "false" if out_dtype == "f64" else "true")
+        return "diral::step_wide_kernel<%d,%s,%s,%s>" % (2 if N <= 128 else 4, o64,
+                                                          "true" if N in (128, 256) else "false", ch)
+    return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
+                                           "true" if (out_dtype == "f32" and ch == "false") else "false")
 
 
 def load_traffic(workload: str):
@@ -159,6 +162,8 @@ def main() -> int:
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--sticky", type=float, default=0.0,
                     help="probability an agent keeps its resource (0 = iid uniform, worst case)")
+    ap.add_argument("--step-mode", default="my_step", choices=["my_step", "my_step_ch"],
+                    help="my_step = the metric's step kind; my_step_ch = the PRR-reward variant (test_env.py:351-443)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -187,7 +192,7 @@ def main() -> int:
         B = args.batch
     cfg = bench_config(N, A, L, mobility_vary=vary)
     out_dtype = torch.float32 if args.out_dtype == "f32" else torch.float64
-    env = VecV2VEnv(cfg, batch=B, device=device, out_dtype=out_dtype)
+    env = VecV2VEnv(cfg, batch=B, device=device, out_dtype=out_dtype, step_mode=args.step_mode)
     env.reset_topology(seed=1234 + rank)
 
     # synthetic actions, resident in HBM before the timed region: a ring of
@@ -256,9 +261,9 @@ def main() -> int:
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d-UE/%d-res, batch=%d envs per GPU x %d GPU, L=%g m, Rc=%g, K=%d bins, "
-                            "reward_design=2, my_step+obtain_state fused, %s actions, %s outputs" % (
+                            "reward_design=2, %s+obtain_state fused, %s actions, %s outputs" % (
                                 args.workload, N, A, B, world, L, cfg.communication_range,
-                                cfg.State.num_bins, "iid-uniform" if args.sticky == 0 else
+                                cfg.State.num_bins, args.step_mode, "iid-uniform" if args.sticky == 0 else
                                 "sticky(p=%.2f)" % args.sticky, args.out_dtype),
                 "batch_per_gpu": B, "num_users": N, "num_channels": A, "state_space": cfg.state_space,
                 "parallelism": "env-shard x%d (no data-path collective)" % world,
@@ -270,7 +275,7 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": load_traffic(args.workload),
-                "kernel": kernel_name(N, A, args.out_dtype),
+                "kernel": kernel_name(N, A, args.out_dtype, args.step_mode),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_launch,
             },

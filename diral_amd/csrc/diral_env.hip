@@ -115,12 +115,13 @@ hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
 bool is_fast_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
-  return (p.flags & ~ignore) == want && p.posdist_type == 2 && p.mode == DIRAL_STEP_MY_STEP &&
+  return (p.flags & ~ignore) == want && p.posdist_type == 2 && (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH) &&
          p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
 }
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
-  const bool fast_cfg = is_fast_cfg(p), fast = fast_cfg && !p.out_f64;
+  const bool fast_cfg = is_fast_cfg(p), ch = p.mode == DIRAL_STEP_MY_STEP_CH;
+  const bool fast = fast_cfg && !p.out_f64 && !ch;   // the generic FAST instantiation: my_step, f32
   const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
   const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
   if (use_fast64 || use_wide) {
@@ -136,26 +137,30 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
       const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
       const dim3 g(p.B), t(64 * wide_waves(vpl));
       const bool full = p.N == 64 * vpl;
-#define DIRAL_LAUNCH_WIDE(V, O, F) hipLaunchKernelGGL((step_wide_kernel<V, O, F>), g, t, wl, s, f)
+#define DIRAL_LAUNCH_WIDE(V, O, F, C) hipLaunchKernelGGL((step_wide_kernel<V, O, F, C>), g, t, wl, s, f)
+#define DIRAL_LAUNCH_WIDE_C(V, O, F) do { if (ch) DIRAL_LAUNCH_WIDE(V, O, F, true); else DIRAL_LAUNCH_WIDE(V, O, F, false); } while (0)
+#define DIRAL_LAUNCH_WIDE_F(V, O) do { if (full) DIRAL_LAUNCH_WIDE_C(V, O, true); else DIRAL_LAUNCH_WIDE_C(V, O, false); } while (0)
       if (vpl == 2) {
-        if (p.out_f64) { if (full) DIRAL_LAUNCH_WIDE(2, true, true); else DIRAL_LAUNCH_WIDE(2, true, false); }
-        else { if (full) DIRAL_LAUNCH_WIDE(2, false, true); else DIRAL_LAUNCH_WIDE(2, false, false); }
+        if (p.out_f64) DIRAL_LAUNCH_WIDE_F(2, true); else DIRAL_LAUNCH_WIDE_F(2, false);
       } else {
-        if (p.out_f64) { if (full) DIRAL_LAUNCH_WIDE(4, true, true); else DIRAL_LAUNCH_WIDE(4, true, false); }
-        else { if (full) DIRAL_LAUNCH_WIDE(4, false, true); else DIRAL_LAUNCH_WIDE(4, false, false); }
+        if (p.out_f64) DIRAL_LAUNCH_WIDE_F(4, true); else DIRAL_LAUNCH_WIDE_F(4, false);
       }
+#undef DIRAL_LAUNCH_WIDE_F
+#undef DIRAL_LAUNCH_WIDE_C
 #undef DIRAL_LAUNCH_WIDE
       return hipGetLastError();
     }
     const uint32_t fl = fast_lds_layout(p.K).total;
     const dim3 g(p.B), t(256);
+#define DIRAL_LAUNCH_F64(FL, O, C) hipLaunchKernelGGL((step_fast64_kernel<FL, O, C>), g, t, fl, s, f)
+#define DIRAL_LAUNCH_F64_C(FL, O) do { if (ch) DIRAL_LAUNCH_F64(FL, O, true); else DIRAL_LAUNCH_F64(FL, O, false); } while (0)
     if (p.out_f64) {
-      if (flat_y) hipLaunchKernelGGL((step_fast64_kernel<true, true>), g, t, fl, s, f);
-      else hipLaunchKernelGGL((step_fast64_kernel<false, true>), g, t, fl, s, f);
+      if (flat_y) DIRAL_LAUNCH_F64_C(true, true); else DIRAL_LAUNCH_F64_C(false, true);
     } else {
-      if (flat_y) hipLaunchKernelGGL((step_fast64_kernel<true, false>), g, t, fl, s, f);
-      else hipLaunchKernelGGL((step_fast64_kernel<false, false>), g, t, fl, s, f);
+      if (flat_y) DIRAL_LAUNCH_F64_C(true, false); else DIRAL_LAUNCH_F64_C(false, false);
     }
+#undef DIRAL_LAUNCH_F64_C
+#undef DIRAL_LAUNCH_F64
     return hipGetLastError();
   }
   switch (vpl) {
@@ -173,10 +178,14 @@ hipError_t set_lds_attr(uint32_t lds, int A, int K) {
   if constexpr (VPL > 1) {
     if (A <= kWideMaxA) {
       const int wl = (int)wide_lds_layout(VPL, A, K).total;
-      const void* ks[4] = {reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false>)};
+      const void* ks[8] = {reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true, false>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false, false>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true, false>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false, false>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true, true>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false, true>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true, true>),
+                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false, true>)};
       for (const void* kf : ks) {
         r = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, wl);
         if (r != hipSuccess) return r;

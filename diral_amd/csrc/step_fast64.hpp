@@ -62,7 +62,7 @@ struct FastParams {
 };
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, mtab, total;
+  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, total;
 };
 __host__ __device__ inline FastLds fast_lds_layout(int K) {
   FastLds l;
@@ -74,6 +74,8 @@ __host__ __device__ inline FastLds fast_lds_layout(int K) {
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;
   l.mtab = o;  o += 4u * 64 * kFastMaxA;    // [resource][vehicle] gather source lane * 4 (bpermute address)
+  l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
+  l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
   l.total = align_up(o, 16);
   return l;
 }
@@ -151,13 +153,28 @@ __device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32
   return (c == 2 && wgt == 1) ? 0.0 : -1.0;
 }
 
+// my_step_ch reward of one transmitter (test_env.py:411-429) from its reception ratio
+// R = received / in_range (1 for a sole transmitter).  Out of line: exp().
+__device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided, double R) {
+  if (collided) {
+    if (rd == 3) return 1.0 - exp(1.0 - R);
+    if (rd == 4) return -1.0 * exp(1.0 - R);
+    return -1.0 * (1.0 - R);
+  }
+  if (rd == 4) return exp(1.0);
+  return 1.0;
+}
+
 #ifdef DIRAL_TIMING
 #define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DIRAL_FSTAMP(i) do {} while (0)
 #endif
 
-template <bool FLAT, bool OUT64>
+// CH: my_step_ch (test_env.py:351-443) instead of my_step: the reward of a transmitter is
+// built from its reception ratio (PRR) instead of the collision count; the gossip, the
+// move and the observation are the same.
+template <bool FLAT, bool OUT64, bool CH>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FastLds lay = fast_lds_layout(p.K);
@@ -168,6 +185,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
   int* s_mtab = reinterpret_cast<int*>(smem + lay.mtab);
+  double* s_rtx = reinterpret_cast<double*>(smem + lay.rtx);
+  int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -228,13 +247,33 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       const int w = __builtin_ctzll(m);
       m &= m - 1;
       const double d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
-      const bool bt = (d < p.Rc) && (d < best);
+      const bool inr = d < p.Rc;
+      const bool bt = inr && (d < best);
       best = bt ? d : best;
       bid = bt ? w : bid;
+      if (CH && c > 1) {                                      // in_range[tx] (test_env.py:395-397)
+        const int n_in = __popcll(__ballot(live && (myact != i) && inr));
+        if (lane == 0) s_inr[w] = n_in;
+      }
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
-    if (c > 1) {                                              // test_env.py:159-199
+    if (CH) {
+      if (c > 1) {
+        // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
+        wave_lds_order();
+        unsigned long long m2 = mk;
+        while (m2) {
+          const int w = __builtin_ctzll(m2);
+          m2 &= m2 - 1;
+          const int n_rec = __popcll(__ballot(live && (myact != i) && bid == w));
+          if (lane == 0) {
+            const int n_in = s_inr[w];
+            s_rtx[w] = n_in > 0 ? (double)n_rec / (double)n_in : 1.0;
+          }
+        }
+      }
+    } else if (c > 1) {                                       // test_env.py:159-199
       double rw;
       if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
         // inlined common case (reward_design 2, network.py:291-295 weight): a pair
@@ -260,19 +299,26 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (wave == 0) {
     double r = 0.0;
     int sole = 0, coll = 0;
+    double prr = 0.0;
     if (live && myact >= 0) {
       const int c = __popcll(s_mask[myact]);
-      if (c > 1) { r = s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222
+      if (CH) {
+        const double R = (c > 1) ? s_rtx[lane] : 1.0;         // test_env.py:411-429
+        const bool plain = (p.reward_design == 2);
+        r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
+        coll = c > 1; sole = !(c > 1); prr = R;
+      } else if (c > 1) { r = s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = r;
         else static_cast<float*>(p.rew_out)[bN + lane] = (float)r;
       }
     }
-    double vr = r;
+    double vr = r, vp = prr;
     int vs = sole, vc = coll;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       vr += __shfl_down(vr, off);
+      if (CH) vp += __shfl_down(vp, off);
       vs += __shfl_down(vs, off);
       vc += __shfl_down(vc, off);
     }
@@ -282,6 +328,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       mt[DIRAL_M_SUM_REWARD] += vr;
       mt[DIRAL_M_TX_SOLE] += (double)vs;
       mt[DIRAL_M_TX_COLLIDED] += (double)vc;
+      if (CH) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
       if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
     }
     if (live) p.pos_x[bN + lane] = mynpx;

@@ -185,7 +185,8 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 
 // FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
-template <int VPL, bool OUT64, bool FULL>
+// CH: my_step_ch (PRR reward, test_env.py:351-443) instead of my_step, as in step_fast64.hpp
+template <int VPL, bool OUT64, bool FULL, bool CH>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
@@ -209,6 +210,15 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   mword_t* s_mtab = reinterpret_cast<mword_t*>(smem + lay.mtab);
+  // my_step_ch per-transmitter scratch (reception ratio R, receivers in range): viewer u's
+  // values live in the merge scratch of wave u / 64, which is idle until that wave - the
+  // one that reads them in P2 - starts its own P3
+  auto rtx_of = [&](int u) -> double* {
+    return reinterpret_cast<double*>(smem + lay.scratch + 2048u * (u >> 6)) + (u & 63);
+  };
+  auto inr_of = [&](int u) -> int* {
+    return reinterpret_cast<int*>(smem + lay.scratch + 2048u * (u >> 6) + 512u) + (u & 63);
+  };
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -272,13 +282,18 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           const int w = jt * 64 + __builtin_ctzll(m);
           m &= m - 1;
           const double xw = s_px[w];
+          int n_in = 0;
 #pragma unroll
           for (int j = 0; j < VPL; ++j) {
             const double d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
-            const bool bt = (d < p.Rc) && (d < best[j]);
+            const bool inr = d < p.Rc;
+            const bool bt = inr && (d < best[j]);
             best[j] = bt ? d : best[j];
             bid[j] = bt ? w : bid[j];
+            if (CH && c > 1)                                    // in_range[tx] (test_env.py:395-397)
+              n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
           }
+          if (CH && c > 1 && lane == 0) *inr_of(w) = n_in;
         }
       }
       unsigned int mw = 0u;
@@ -289,7 +304,28 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
       }
       s_mtab[i * 64 + lane] = (mword_t)mw;
-      if (c > 1) {                                              // test_env.py:159-199
+      if (CH) {
+        if (c > 1) {
+          // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
+          wave_lds_order();
+#pragma unroll
+          for (int jt = 0; jt < VPL; ++jt) {
+            unsigned long long m2 = mk[jt];
+            while (m2) {
+              const int w = jt * 64 + __builtin_ctzll(m2);
+              m2 &= m2 - 1;
+              int n_rec = 0;
+#pragma unroll
+              for (int j = 0; j < VPL; ++j)
+                n_rec += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && bid[j] == w));
+              if (lane == 0) {
+                const int n_in = *inr_of(w);
+                *rtx_of(w) = n_in > 0 ? (double)n_rec / (double)n_in : 1.0;
+              }
+            }
+          }
+        }
+      } else if (c > 1) {                                       // test_env.py:159-199
         double rw;
         if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
           if (c == 2) {
@@ -319,30 +355,36 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // ---- P2 (first VPL waves): reward per transmitter, metric partials, positions --
   if (tid < NPAD) {
     const int u = tid;
-    double r = 0.0;
+    double r = 0.0, prr = 0.0;
     int sole = 0, coll = 0;
     const int a = s_act[u];
     if (u < N && a >= 0) {
       int c = 0;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) c += __popcll(s_mask[a * VPL + j]);
-      if (c > 1) { r = s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222
+      if (CH) {
+        const double R = (c > 1) ? *rtx_of(u) : 1.0;                          // test_env.py:411-429
+        const bool plain = (p.reward_design == 2);
+        r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
+        coll = c > 1; sole = !(c > 1); prr = R;
+      } else if (c > 1) { r = s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = r;
         else static_cast<float*>(p.rew_out)[bN + u] = (float)r;
       }
     }
     if (u < N) p.pos_x[bN + u] = s_npx[u];
-    double vr = r;
+    double vr = r, vp = prr;
     int vs = sole, vc = coll;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       vr += __shfl_down(vr, off);
+      if (CH) vp += __shfl_down(vp, off);
       vs += __shfl_down(vs, off);
       vc += __shfl_down(vc, off);
     }
     if (lane == 0) {
-      s_red[wave * 4 + 0] = vr; s_red[wave * 4 + 2] = (double)vs; s_red[wave * 4 + 3] = (double)vc;
+      s_red[wave * 4 + 0] = vr; s_red[wave * 4 + 1] = vp; s_red[wave * 4 + 2] = (double)vs; s_red[wave * 4 + 3] = (double)vc;
     }
   }
 
@@ -642,13 +684,14 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // ---- P4: metrics, done flag, state = [one-hot(action) (A) | histogram (K)] ------
   if (tid == 0) {
     if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
-    double sr = 0.0, ss = 0.0, sc = 0.0;
-    for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
+    double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
+    for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
     double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
     mt[DIRAL_M_SLOTS] += 1.0;
     mt[DIRAL_M_SUM_REWARD] += sr;
     mt[DIRAL_M_TX_SOLE] += ss;
     mt[DIRAL_M_TX_COLLIDED] += sc;
+    if (CH) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
   }
   const int S = A + K;
   if constexpr (OUT64) {

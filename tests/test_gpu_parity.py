@@ -831,3 +831,61 @@ def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac):
     assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
     assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
     env.check()
+
+
+@pytest.mark.parametrize("N,A,K,rd", [(64, 32, 20, 2), (64, 32, 20, 3), (64, 32, 10, 4), (33, 7, 20, 2), (4, 3, 20, 3),
+                                       (256, 64, 20, 2), (128, 64, 20, 3), (130, 33, 10, 4), (65, 3, 8, 2),
+                                       (200, 64, 40, 2)])
+def test_fast_paths_run_my_step_ch_like_the_general_kernel_and_the_oracle(N, A, K, rd):
+    """my_step_ch (PRR reward, test_env.py:351-443) on the specialised kernels
+    (step_fast64 / step_wide, CH instantiation) against the general kernel and the
+    oracle: integer reception counts bit-exact, so R and the rd 2 rewards are
+    identical; rd 3/4 go through exp (absolute tolerance); states, tables and the
+    PRR metric columns identical."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    L = (30.0 if N <= 64 else 15.0) * N + 100
+    cfg = bench_config(N, A, L, reward_design=rd, State=dict(num_bins=K),
+                       communication_range=250.0 if N > 8 else 40.0)
+    rng = np.random.default_rng(3000 + N + A + K + rd)
+    B = 8
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    f32, f64, gen = (make_env(cfg, B, mode="my_step_ch", dtype=torch.float32),
+                     make_env(cfg, B, mode="my_step_ch", dtype=torch.float64),
+                     make_env(cfg, B, mode="my_step_ch", dtype=torch.float64))
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (f32, f64, gen):
+        e.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(30):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        if t % 3 == 2:                                       # some sticky slots: fewer collisions, R spread
+            a[:, ::2] = prev[:, ::2]
+        prev = a
+        o3, r3, _ = f32.step(a, t)
+        o6, r6, d6 = f64.step(a, t)
+        with _general_kernel():
+            og, rg, dg = gen.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP_CH, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert torch.equal(o6, og) and torch.equal(d6, dg), t
+        assert np.array_equal(o6.cpu().numpy(), o_state), t
+        assert torch.equal(o3, og.to(torch.float32)), t
+        if rd == 2:
+            assert torch.equal(r6, rg) and torch.equal(r3, rg.to(torch.float32)), t
+            assert np.array_equal(r6.cpu().numpy(), o_rew), t
+        else:
+            assert torch.equal(r6, rg), t                    # same device exp() on the same R
+            assert np.all(np.abs(r6.cpu().numpy() - o_rew) <= EXP_ATOL), t
+            assert torch.allclose(r3.double(), rg, rtol=0, atol=1e-6)
+    s6, sg, oe = f64.export_state(), gen.export_state(), orc.export()
+    for k in ("pos_x", "seq", "age", "x"):
+        assert torch.equal(s6[k], sg[k]), k
+    assert np.array_equal(s6["seq"].cpu().numpy(), oe["seq"])
+    m6, mg, mo = f64.metrics().cpu().numpy(), gen.metrics().cpu().numpy(), orc.metrics()
+    assert np.array_equal(m6[:, [0, 2, 3, 5]], mg[:, [0, 2, 3, 5]])
+    assert np.array_equal(m6[:, 4], mg[:, 4])                # PRR sums: same values, same summation order
+    assert np.allclose(m6[:, 4] / m6[:, 5], mo[:, 4] / mo[:, 5], rtol=0, atol=1e-12)
+    for e in (f32, f64, gen):
+        e.check()
