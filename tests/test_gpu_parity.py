@@ -889,3 +889,39 @@ def test_fast_paths_run_my_step_ch_like_the_general_kernel_and_the_oracle(N, A, 
     assert np.allclose(m6[:, 4] / m6[:, 5], mo[:, 4] / mo[:, 5], rtol=0, atol=1e-12)
     for e in (f32, f64, gen):
         e.check()
+
+
+def test_wide_long_run_in_and_out_of_the_rank_window():
+    """700 slots of a sparse 96-vehicle highway: pairs meet and drift apart, so entries
+    with a real sequence number age past the 8-bit rank window (lag >= 255) and come
+    back - step_wide alternates between its rank path and its 32-bit path per pass and
+    must match the oracle bit for bit throughout."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    N, A, L, B = 96, 8, 4000.0, 3
+    cfg = bench_config(N, A, L, communication_range=100.0)
+    rng = np.random.default_rng(18)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    env = make_env(cfg, B, dtype=torch.float64)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=4)
+    env.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(700):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        if t % 25 == 24 or t > 680:
+            o_state = orc.obtain_state(a, o_chobs, o_rew)
+            torch.cuda.synchronize()
+            assert np.array_equal(obs.cpu().numpy(), o_state), t
+            assert np.array_equal(rew.cpu().numpy(), o_rew), t
+    st, oe = env.export_state(), orc.export()
+    seq = oe["seq"]
+    own = seq[:, np.arange(N), np.arange(N)]                  # [B, k]: the subject's own sequence number
+    lag = own[:, None, :] - seq                               # seq is [B, viewer, subject]
+    assert ((lag >= 255) & (seq > 0)).any(), "the run never left the rank window"
+    assert ((lag < 255) & (seq > 0)).any()
+    assert np.array_equal(st["seq"].cpu().numpy(), seq)
+    assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    env.check()
