@@ -150,7 +150,7 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
 #undef DIRAL_LAUNCH_WIDE
       return hipGetLastError();
     }
-    const uint32_t fl = fast_lds_layout(p.K).total;
+    const uint32_t fl = fast_lds_layout(p.K, p.A).total;
     const dim3 g(p.B), t(256);
 #define DIRAL_LAUNCH_F64(FL, O, C) hipLaunchKernelGGL((step_fast64_kernel<FL, O, C>), g, t, fl, s, f)
 #define DIRAL_LAUNCH_F64_C(FL, O) do { if (ch) DIRAL_LAUNCH_F64(FL, O, true); else DIRAL_LAUNCH_F64(FL, O, false); } while (0)

@@ -37,7 +37,7 @@ namespace diral {
 #define DIRAL_PACKED_MERGE 1           // 16-bit packed gossip merge (exact; falls back per wave)
 #endif
 
-constexpr int kFastMaxA = 32;
+constexpr int kFastMaxA = 64;           // LDS is sized by the actual A (rounded up to 32): A <= 32 keeps 8 workgroups per CU
 
 struct FastParams {
   int N, A, K, NR;               // NR: padded subject rows (multiple of 16); viewer stride is 64
@@ -64,16 +64,17 @@ struct FastParams {
 struct FastLds {
   uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, total;
 };
-__host__ __device__ inline FastLds fast_lds_layout(int K) {
+__host__ __device__ inline FastLds fast_lds_layout(int K, int A) {
   FastLds l;
   uint32_t o = 0;
-  l.rv = o;    o += 8u * kFastMaxA;
+  const uint32_t a32 = A <= 32 ? 32u : 64u;
+  l.rv = o;    o += 8u * a32;
   l.edges = o; o += 8u * (K + 2);
-  l.mask = o;  o += 8u * kFastMaxA;
+  l.mask = o;  o += 8u * a32;
   l.act = o;   o += 4u * 64;
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;
-  l.mtab = o;  o += 4u * 64 * kFastMaxA;    // [resource][vehicle] gather source lane * 4 (bpermute address)
+  l.mtab = o;  o += 4u * 64 * a32;         // [resource][vehicle] gather source lane * 4 (bpermute address)
   l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
   l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
   l.total = align_up(o, 16);
@@ -177,7 +178,7 @@ __device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided
 template <bool FLAT, bool OUT64, bool CH>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const FastLds lay = fast_lds_layout(p.K);
+  const FastLds lay = fast_lds_layout(p.K, p.A);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);

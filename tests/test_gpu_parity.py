@@ -359,7 +359,8 @@ def test_replica_envs_are_identical_at_scale():
                                            (64, 32, 20, 3, False), (64, 32, 20, 4, False),
                                            (4, 3, 20, 2, True), (4, 3, 10, 1, True), (63, 31, 10, 2, False),
                                            (33, 7, 20, 2, False), (64, 5, 8, 2, False), (1, 1, 4, 2, False),
-                                           (17, 32, 64, 2, False)])
+                                           (17, 32, 64, 2, False), (64, 64, 20, 2, False), (48, 40, 10, 1, False),
+                                           (64, 33, 20, 5, False)])
 def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
     """The headline-config kernel (csrc/step_fast64.hpp, f32 and f64 outputs,
     default State flags) against the general kernel (f64 outputs, forced with
@@ -834,6 +835,7 @@ def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac):
 
 
 @pytest.mark.parametrize("N,A,K,rd", [(64, 32, 20, 2), (64, 32, 20, 3), (64, 32, 10, 4), (33, 7, 20, 2), (4, 3, 20, 3),
+                                       (64, 64, 20, 2), (50, 48, 20, 4),
                                        (256, 64, 20, 2), (128, 64, 20, 3), (130, 33, 10, 4), (65, 3, 8, 2),
                                        (200, 64, 40, 2)])
 def test_fast_paths_run_my_step_ch_like_the_general_kernel_and_the_oracle(N, A, K, rd):
