@@ -1,0 +1,65 @@
+"""Long mixed-schedule runs of the HIP path against the oracle (bit-exact): sticky and
+iid actions, velocity updates every 25 slots, dense / sparse highways, both step kinds,
+N <= 64 (step_fast64) and N > 64 (step_wide incl. ragged N).  `python tests/test_gpu_soak.py 10`
+runs the same schedules ten times longer."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pytest
+import torch
+
+from diral_amd.config import bench_config, STEP_MY_STEP, STEP_MY_STEP_CH
+
+pytestmark = pytest.mark.gpu
+
+
+def soak(N, A, L, B, T, mode, vary, rc=250.0, every=250):
+    from diral_amd.vec_env import VecV2VEnv
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(N, A, L, mobility_vary=vary, communication_range=rc)
+    rng = np.random.default_rng(N + T)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64); v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float64, step_mode="my_step_ch" if mode == STEP_MY_STEP_CH else "my_step")
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=16)
+    env.reset_topology(x0, None, v0); orc.reset(x0, np.zeros((B, N)), v0)
+    t0 = time.time(); prev = None
+    for t in range(T):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        if prev is not None and t % 2: a = np.where(rng.random((B, N)) < 0.8, prev, a)
+        prev = a
+        obs, rew, done = env.step(a, t)
+        o_rew, o_ch = orc.step(mode, a, t)
+        if t % 25 == 24:
+            d = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
+            env.update_velocity(d); orc.update_velocity(d)
+        if t % every == every - 1 or t == T - 1:
+            st = orc.obtain_state(a, o_ch, o_rew)
+            torch.cuda.synchronize()
+            assert np.array_equal(obs.cpu().numpy(), st), (N, t)
+            assert np.array_equal(rew.cpu().numpy(), o_rew), (N, t)
+    s, oe = env.export_state(), orc.export()
+    assert np.array_equal(s["seq"].cpu().numpy(), oe["seq"]) and np.array_equal(s["x"].cpu().numpy(), oe["x"])
+    assert np.array_equal(s["pos_x"].cpu().numpy(), oe["pos_x"]) and np.array_equal(s["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    m, mo = env.metrics().cpu().numpy(), orc.metrics()
+    assert np.array_equal(m[:, [0, 2, 3]], mo[:, [0, 2, 3]])
+    env.check()
+    print("soak ok N=%d A=%d L=%g B=%d T=%d mode=%d vary=%s rc=%g  %.1fs" % (N, A, L, B, T, mode, vary, rc, time.time() - t0), flush=True)
+
+SCHEDULES = [(64, 32, 2000.0, 8, 6000, STEP_MY_STEP, True, 250.0), (64, 32, 2000.0, 8, 3000, STEP_MY_STEP_CH, False, 250.0),
+             (64, 32, 6000.0, 6, 3000, STEP_MY_STEP, True, 120.0), (256, 64, 4000.0, 3, 1200, STEP_MY_STEP, False, 250.0),
+             (128, 64, 4000.0, 4, 2000, STEP_MY_STEP, True, 250.0), (128, 64, 9000.0, 3, 1500, STEP_MY_STEP_CH, True, 150.0),
+             (200, 40, 12000.0, 2, 1200, STEP_MY_STEP, True, 140.0)]
+
+
+@pytest.mark.parametrize("N,A,L,B,T,mode,vary,rc", SCHEDULES)
+def test_soak_vs_oracle(N, A, L, B, T, mode, vary, rc):
+    soak(N, A, L, B, T, mode, vary, rc)
+
+
+if __name__ == "__main__":
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    for (N, A, L, B, T, mode, vary, rc) in SCHEDULES:
+        soak(N, A, L, B, T * k, mode, vary, rc, every=250 * k)
