@@ -142,7 +142,10 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
         else:
             assert np.array_equal(rew, o_rew), t
         assert np.array_equal(chobs, o_chobs), t
-        assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
+        if uses_exp(cfg, mode) and cfg.State.add_reward:       # the state carries the exp() reward
+            assert exp_close(obs, o_state), t
+        else:
+            assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
         if vel_every and t % vel_every == vel_every - 1:
             draws = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
             env.update_velocity(draws)
