@@ -115,19 +115,21 @@ hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
 bool is_fast_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
-  return (p.flags & ~ignore) == want && p.posdist_type == 2 && (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH) &&
+  return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
+         (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN) &&
          p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
 }
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
   const bool fast_cfg = is_fast_cfg(p), ch = p.mode == DIRAL_STEP_MY_STEP_CH;
-  const bool fast = fast_cfg && !p.out_f64 && !ch;   // the generic FAST instantiation: my_step, f32
+  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP;   // the generic FAST instantiation: my_step, f32
   const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
   const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
   if (use_fast64 || use_wide) {
     FastParams f;
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
+    f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;

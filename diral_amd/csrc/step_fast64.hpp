@@ -44,6 +44,7 @@ struct FastParams {
   int NV;                        // viewer stride (step_wide.hpp; 64 for step_fast64)
   uint32_t flags;
   int reward_design, age_limit, episode_interval;
+  int design;                    // 1: my_step_design (test_env.py:269-349) - runtime switch of the non-CH instantiation
   double L, Rc, Rb, inv_w;
   long long t;
   const int32_t* actions;
@@ -256,6 +257,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const int n_in = __popcll(__ballot(live && (myact != i) && inr));
         if (lane == 0) s_inr[w] = n_in;
       }
+      if (!CH && p.design && c > 1) {
+        // my_step_design: reward by the number of transmitters of this resource within 2 Rc
+        // of this one (network.py:122-157): alone 1, else -n (a pair inside 2 Rc gets -2)
+        const int n = 1 + __popcll(__ballot((myact == i) && (lane != w) && (d < 2.0 * p.Rc)));
+        if (lane == 0) s_rtx[w] = (n == 1) ? 1.0 : -(double)n;
+      }
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           }
         }
       }
-    } else if (c > 1) {                                       // test_env.py:159-199
+    } else if (c > 1 && !p.design) {                          // test_env.py:159-199
       double rw;
       if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
         // inlined common case (reward_design 2, network.py:291-295 weight): a pair
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const bool plain = (p.reward_design == 2);
         r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222
+      } else if (c > 1) { r = p.design ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = r;
         else static_cast<float*>(p.rew_out)[bN + lane] = (float)r;

@@ -292,8 +292,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             bid[j] = bt ? w : bid[j];
             if (CH && c > 1)                                    // in_range[tx] (test_env.py:395-397)
               n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
+            if (!CH && p.design && c > 1)                       // my_step_design: tx of this resource within 2 Rc
+              n_in += __popcll(__ballot((myact[j] == i) && (lane + 64 * j != w) && (d < 2.0 * p.Rc)));
           }
           if (CH && c > 1 && lane == 0) *inr_of(w) = n_in;
+          if (!CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
         }
       }
       unsigned int mw = 0u;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             }
           }
         }
-      } else if (c > 1) {                                       // test_env.py:159-199
+      } else if (c > 1 && !p.design) {                          // test_env.py:159-199
         double rw;
         if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
           if (c == 2) {
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         const bool plain = (p.reward_design == 2);
         r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222
+      } else if (c > 1) { r = p.design ? *rtx_of(u) : s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = r;
         else static_cast<float*>(p.rew_out)[bN + u] = (float)r;

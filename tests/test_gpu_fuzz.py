@@ -54,7 +54,7 @@ def draw_fast_case(i):
     N = int(rng.integers(1, 257))
     A = int(rng.integers(1, 65))
     K = int(rng.integers(1, 65))
-    mode = int(rng.choice([STEP_MY_STEP, STEP_MY_STEP_CH]))
+    mode = int(rng.choice([STEP_MY_STEP, STEP_MY_STEP_CH, STEP_DESIGN]))
     rd = int(rng.choice([2, 3, 4])) if mode == STEP_MY_STEP_CH else int(rng.integers(1, 6))
     L = float(rng.choice([6.0, 15.0, 40.0]) * N + rng.integers(20, 300))
     cfg = bench_config(N, A, L, reward_design=rd, State=dict(num_bins=K), mobility_vary=bool(rng.random() < 0.5),
@@ -78,13 +78,13 @@ def test_random_default_flag_configuration_on_the_specialised_kernels(i):
     rng = np.random.default_rng(500 + i)
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
     v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
-    env = make_env(cfg, B, mode="my_step_ch" if mode == STEP_MY_STEP_CH else "my_step",
+    env = make_env(cfg, B, mode={STEP_MY_STEP: "my_step", STEP_MY_STEP_CH: "my_step_ch", STEP_DESIGN: "my_step_design"}[mode],
                    dtype=torch.float64 if f64 else torch.float32)
     orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
     env.reset_topology(x0, None, v0)
     orc.reset(x0, np.zeros((B, N)), v0)
     acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
-    exp_rew = cfg.reward_design in (3, 4)
+    exp_rew = cfg.reward_design in (3, 4) and mode != STEP_DESIGN
     for t in range(32):
         new = rng.integers(0, A, size=(B, N))
         acts = np.where(rng.random((B, N)) < sticky, acts, new).astype(np.int32)

@@ -930,3 +930,46 @@ def test_wide_long_run_in_and_out_of_the_rank_window():
     assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
     assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
     env.check()
+
+
+@pytest.mark.parametrize("N,A,K", [(64, 32, 20), (64, 5, 10), (6, 3, 20), (40, 48, 20), (256, 64, 20), (128, 16, 10),
+                                   (130, 33, 21), (70, 4, 8)])
+def test_specialised_kernels_run_my_step_design_like_the_general_kernel_and_the_oracle(N, A, K):
+    """my_step_design (the driver's prefill step, test_env.py:269-349: reward by the
+    number of same-resource transmitters within 2 Rc) on step_fast64 / step_wide - a
+    runtime switch of the my_step instantiation - against the general kernel and the
+    oracle, bit for bit."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    L = (20.0 if N <= 64 else 10.0) * N + 100
+    cfg = bench_config(N, A, L, State=dict(num_bins=K), communication_range=100.0 if N > 8 else 20.0)
+    rng = np.random.default_rng(4000 + N + A + K)
+    B = 6
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    f32, f64, gen = (make_env(cfg, B, mode="my_step_design", dtype=torch.float32),
+                     make_env(cfg, B, mode="my_step_design", dtype=torch.float64),
+                     make_env(cfg, B, mode="my_step_design", dtype=torch.float64))
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (f32, f64, gen):
+        e.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(24):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        o3, r3, _ = f32.step(a, t)
+        o6, r6, d6 = f64.step(a, t)
+        with _general_kernel():
+            og, rg, dg = gen.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_DESIGN, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        torch.cuda.synchronize()
+        assert torch.equal(o6, og) and torch.equal(r6, rg) and torch.equal(d6, dg), t
+        assert np.array_equal(o6.cpu().numpy(), o_state) and np.array_equal(r6.cpu().numpy(), o_rew), t
+        assert torch.equal(o3, og.to(torch.float32)) and torch.equal(r3, rg.to(torch.float32)), t
+    s6, sg, oe = f64.export_state(), gen.export_state(), orc.export()
+    for k in ("pos_x", "seq", "age", "x"):
+        assert torch.equal(s6[k], sg[k]), k
+    assert np.array_equal(s6["seq"].cpu().numpy(), oe["seq"])
+    m6, mg = f64.metrics().cpu().numpy(), gen.metrics().cpu().numpy()
+    assert np.array_equal(m6[:, [0, 1, 2, 3]], mg[:, [0, 1, 2, 3]])      # integer-valued rewards: sums exact
+    for e in (f32, f64, gen):
+        e.check()
