@@ -114,7 +114,7 @@ hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
 // instantiation additionally needs f32 outputs; step_fast64 has both).
 bool is_fast_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
-  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY;
+  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL;
   return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN) &&
          p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
@@ -122,7 +122,8 @@ bool is_fast_cfg(const StepParams& p) {
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
   const bool fast_cfg = is_fast_cfg(p), ch = p.mode == DIRAL_STEP_MY_STEP_CH;
-  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP;   // the generic FAST instantiation: my_step, f32
+  // the generic FAST instantiation: my_step, f32 outputs, no arrival stamps
+  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP && !(p.flags & DIRAL_F_TRACK_ARRIVAL);
   const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
   const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
   if (use_fast64 || use_wide) {
@@ -133,6 +134,7 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
+    f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
     if (use_wide) {

@@ -53,6 +53,7 @@ struct FastParams {
   const double* vel;
   uint32_t* tkey;
   double* tx;
+  int32_t* la;                   // last_arrival_time[tx][rx] (network.py:39-42) or null: not tracked
   double* metrics;
   uint32_t* err;
   const double* edges;
@@ -257,6 +258,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const int n_in = __popcll(__ballot(live && (myact != i) && inr));
         if (lane == 0) s_inr[w] = n_in;
       }
+      // find_closest_tx side effect (network.py:394): an out-of-range transmitter's arrival
+      // stamp at this receiver becomes -1
+      if (p.la && live && (myact != i) && !inr) p.la[(bN + w) * N + lane] = -1;
       if (!CH && p.design && c > 1) {
         // my_step_design: reward by the number of transmitters of this resource within 2 Rc
         // of this one (network.py:122-157): alone 1, else -n (a pair inside 2 Rc gets -2)
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
+    if (CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
     if (CH) {
       if (c > 1) {
         // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)

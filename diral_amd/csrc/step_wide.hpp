@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             const bool bt = inr && (d < best[j]);
             best[j] = bt ? d : best[j];
             bid[j] = bt ? w : bid[j];
+            if (p.la && (FULL || lane + 64 * j < N) && (myact[j] != i) && !inr)
+              p.la[(bN + w) * N + lane + 64 * j] = -1;          // find_closest_tx side effect (network.py:394)
             if (CH && c > 1)                                    // in_range[tx] (test_env.py:395-397)
               n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
             if (!CH && p.design && c > 1)                       // my_step_design: tx of this resource within 2 Rc
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         const int u = lane + 64 * j;
         const bool got = (myact[j] != i) && (bid[j] >= 0) && (u < N);
         mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
+        if (CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
       }
       s_mtab[i * 64 + lane] = (mword_t)mw;
       if (CH) {

@@ -973,3 +973,40 @@ def test_specialised_kernels_run_my_step_design_like_the_general_kernel_and_the_
     assert np.array_equal(m6[:, [0, 1, 2, 3]], mg[:, [0, 1, 2, 3]])      # integer-valued rewards: sums exact
     for e in (f32, f64, gen):
         e.check()
+
+
+@pytest.mark.parametrize("N,A,mode", [(64, 32, STEP_MY_STEP_CH), (64, 32, STEP_MY_STEP), (40, 6, STEP_DESIGN),
+                                      (256, 64, STEP_MY_STEP_CH), (130, 20, STEP_MY_STEP_CH), (128, 64, STEP_MY_STEP)])
+def test_arrival_stamps_and_information_age_on_the_specialised_kernels(N, A, mode):
+    """track_arrival on step_fast64 / step_wide: last_arrival_time (test_env.py:436 stamps,
+    network.py:394 '-1' side effect) and get_information_age (network.py:560-574) equal the
+    oracle's after every slot - the whole main_test.py slot sequence on the fast path."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    L = (20.0 if N <= 64 else 10.0) * N + 100
+    rd = 2
+    cfg = bench_config(N, A, L, reward_design=rd, communication_range=120.0).replace(track_arrival=True)
+    rng = np.random.default_rng(5000 + N + A + mode)
+    B = 4
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    names = {STEP_MY_STEP: "my_step", STEP_MY_STEP_CH: "my_step_ch", STEP_DESIGN: "my_step_design"}
+    env, gen = make_env(cfg, B, mode=names[mode]), make_env(cfg, B, mode=names[mode])
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (env, gen):
+        e.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(20):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(a, t)
+        with _general_kernel():
+            og, rg, _ = gen.step(a, t)
+        o_rew, o_chobs = orc.step(mode, a, t)
+        ia, iag, oia = env.info_age(t), gen.info_age(t), orc.info_age(t)
+        torch.cuda.synchronize()
+        assert torch.equal(obs, og) and torch.equal(rew, rg), t
+        assert torch.equal(ia, iag) and np.array_equal(ia.cpu().numpy(), oia), t
+    st, sg, oe = env.export_state(), gen.export_state(), orc.export()
+    assert torch.equal(st["la"], sg["la"])
+    assert np.array_equal(st["la"].cpu().numpy().astype(np.int64), oe["la"])
+    env.check()
+    gen.check()
