@@ -135,14 +135,16 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
+    const bool extra = f.design != 0 || f.la != nullptr;   // EXTRA instantiation: the run-time switches compiled in
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
     if (use_wide) {
       const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
       const dim3 g(p.B), t(64 * wide_waves(vpl));
       const bool full = p.N == 64 * vpl;
-#define DIRAL_LAUNCH_WIDE(V, O, F, C) hipLaunchKernelGGL((step_wide_kernel<V, O, F, C>), g, t, wl, s, f)
-#define DIRAL_LAUNCH_WIDE_C(V, O, F) do { if (ch) DIRAL_LAUNCH_WIDE(V, O, F, true); else DIRAL_LAUNCH_WIDE(V, O, F, false); } while (0)
+#define DIRAL_LAUNCH_WIDE(V, O, F, C, X) hipLaunchKernelGGL((step_wide_kernel<V, O, F, C, X>), g, t, wl, s, f)
+#define DIRAL_LAUNCH_WIDE_X(V, O, F, C) do { if (extra) DIRAL_LAUNCH_WIDE(V, O, F, C, true); else DIRAL_LAUNCH_WIDE(V, O, F, C, false); } while (0)
+#define DIRAL_LAUNCH_WIDE_C(V, O, F) do { if (ch) DIRAL_LAUNCH_WIDE_X(V, O, F, true); else DIRAL_LAUNCH_WIDE_X(V, O, F, false); } while (0)
 #define DIRAL_LAUNCH_WIDE_F(V, O) do { if (full) DIRAL_LAUNCH_WIDE_C(V, O, true); else DIRAL_LAUNCH_WIDE_C(V, O, false); } while (0)
       if (vpl == 2) {
         if (p.out_f64) DIRAL_LAUNCH_WIDE_F(2, true); else DIRAL_LAUNCH_WIDE_F(2, false);
@@ -151,19 +153,22 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
       }
 #undef DIRAL_LAUNCH_WIDE_F
 #undef DIRAL_LAUNCH_WIDE_C
+#undef DIRAL_LAUNCH_WIDE_X
 #undef DIRAL_LAUNCH_WIDE
       return hipGetLastError();
     }
     const uint32_t fl = fast_lds_layout(p.K, p.A).total;
     const dim3 g(p.B), t(256);
-#define DIRAL_LAUNCH_F64(FL, O, C) hipLaunchKernelGGL((step_fast64_kernel<FL, O, C>), g, t, fl, s, f)
-#define DIRAL_LAUNCH_F64_C(FL, O) do { if (ch) DIRAL_LAUNCH_F64(FL, O, true); else DIRAL_LAUNCH_F64(FL, O, false); } while (0)
+#define DIRAL_LAUNCH_F64(FL, O, C, X) hipLaunchKernelGGL((step_fast64_kernel<FL, O, C, X>), g, t, fl, s, f)
+#define DIRAL_LAUNCH_F64_X(FL, O, C) do { if (extra) DIRAL_LAUNCH_F64(FL, O, C, true); else DIRAL_LAUNCH_F64(FL, O, C, false); } while (0)
+#define DIRAL_LAUNCH_F64_C(FL, O) do { if (ch) DIRAL_LAUNCH_F64_X(FL, O, true); else DIRAL_LAUNCH_F64_X(FL, O, false); } while (0)
     if (p.out_f64) {
       if (flat_y) DIRAL_LAUNCH_F64_C(true, true); else DIRAL_LAUNCH_F64_C(false, true);
     } else {
       if (flat_y) DIRAL_LAUNCH_F64_C(true, false); else DIRAL_LAUNCH_F64_C(false, false);
     }
 #undef DIRAL_LAUNCH_F64_C
+#undef DIRAL_LAUNCH_F64_X
 #undef DIRAL_LAUNCH_F64
     return hipGetLastError();
   }
@@ -182,14 +187,15 @@ hipError_t set_lds_attr(uint32_t lds, int A, int K) {
   if constexpr (VPL > 1) {
     if (A <= kWideMaxA) {
       const int wl = (int)wide_lds_layout(VPL, A, K).total;
-      const void* ks[8] = {reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true, false>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false, false>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true, false>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false, false>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, true, true>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, true, false, true>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, true, true>),
-                           reinterpret_cast<const void*>(step_wide_kernel<VPL, false, false, true>)};
+      const void* ks[16] = {
+#define DIRAL_WK(O, F, C, X) reinterpret_cast<const void*>(step_wide_kernel<VPL, O, F, C, X>)
+          DIRAL_WK(true, true, false, false),  DIRAL_WK(true, false, false, false), DIRAL_WK(false, true, false, false),
+          DIRAL_WK(false, false, false, false), DIRAL_WK(true, true, true, false),  DIRAL_WK(true, false, true, false),
+          DIRAL_WK(false, true, true, false),  DIRAL_WK(false, false, true, false), DIRAL_WK(true, true, false, true),
+          DIRAL_WK(true, false, false, true),  DIRAL_WK(false, true, false, true),  DIRAL_WK(false, false, false, true),
+          DIRAL_WK(true, true, true, true),    DIRAL_WK(true, false, true, true),   DIRAL_WK(false, true, true, true),
+          DIRAL_WK(false, false, true, true)};
+#undef DIRAL_WK
       for (const void* kf : ks) {
         r = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, wl);
         if (r != hipSuccess) return r;

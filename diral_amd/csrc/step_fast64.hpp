@@ -177,7 +177,9 @@ __device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided
 // CH: my_step_ch (test_env.py:351-443) instead of my_step: the reward of a transmitter is
 // built from its reception ratio (PRR) instead of the collision count; the gossip, the
 // move and the observation are the same.
-template <bool FLAT, bool OUT64, bool CH>
+// EXTRA: the rarely used run-time switches (my_step_design, arrival stamps) are compiled in;
+// the plain instantiations stay free of them (they cost the headline kernel 4 spilled VGPRs).
+template <bool FLAT, bool OUT64, bool CH, bool EXTRA>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FastLds lay = fast_lds_layout(p.K, p.A);
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
       // find_closest_tx side effect (network.py:394): an out-of-range transmitter's arrival
       // stamp at this receiver becomes -1
-      if (p.la && live && (myact != i) && !inr) p.la[(bN + w) * N + lane] = -1;
-      if (!CH && p.design && c > 1) {
+      if (EXTRA && p.la && live && (myact != i) && !inr) p.la[(bN + w) * N + lane] = -1;
+      if (EXTRA && !CH && p.design && c > 1) {
         // my_step_design: reward by the number of transmitters of this resource within 2 Rc
         // of this one (network.py:122-157): alone 1, else -n (a pair inside 2 Rc gets -2)
         const int n = 1 + __popcll(__ballot((myact == i) && (lane != w) && (d < 2.0 * p.Rc)));
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
-    if (CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
+    if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
     if (CH) {
       if (c > 1) {
         // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           }
         }
       }
-    } else if (c > 1 && !p.design) {                          // test_env.py:159-199
+    } else if (c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
       double rw;
       if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
         // inlined common case (reward_design 2, network.py:291-295 weight): a pair
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const bool plain = (p.reward_design == 2);
         r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = p.design ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
+      } else if (c > 1) { r = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = r;
         else static_cast<float*>(p.rew_out)[bN + lane] = (float)r;

@@ -186,7 +186,8 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 // FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
 // CH: my_step_ch (PRR reward, test_env.py:351-443) instead of my_step, as in step_fast64.hpp
-template <int VPL, bool OUT64, bool FULL, bool CH>
+// EXTRA: run-time switches for my_step_design and the arrival stamps, as in step_fast64.hpp
+template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
@@ -290,15 +291,15 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             const bool bt = inr && (d < best[j]);
             best[j] = bt ? d : best[j];
             bid[j] = bt ? w : bid[j];
-            if (p.la && (FULL || lane + 64 * j < N) && (myact[j] != i) && !inr)
+            if (EXTRA && p.la && (FULL || lane + 64 * j < N) && (myact[j] != i) && !inr)
               p.la[(bN + w) * N + lane + 64 * j] = -1;          // find_closest_tx side effect (network.py:394)
             if (CH && c > 1)                                    // in_range[tx] (test_env.py:395-397)
               n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
-            if (!CH && p.design && c > 1)                       // my_step_design: tx of this resource within 2 Rc
+            if (EXTRA && !CH && p.design && c > 1)              // my_step_design: tx of this resource within 2 Rc
               n_in += __popcll(__ballot((myact[j] == i) && (lane + 64 * j != w) && (d < 2.0 * p.Rc)));
           }
           if (CH && c > 1 && lane == 0) *inr_of(w) = n_in;
-          if (!CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
+          if (EXTRA && !CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
         }
       }
       unsigned int mw = 0u;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         const int u = lane + 64 * j;
         const bool got = (myact[j] != i) && (bid[j] >= 0) && (u < N);
         mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
-        if (CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
+        if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
       }
       s_mtab[i * 64 + lane] = (mword_t)mw;
       if (CH) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             }
           }
         }
-      } else if (c > 1 && !p.design) {                          // test_env.py:159-199
+      } else if (c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
         double rw;
         if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
           if (c == 2) {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         const bool plain = (p.reward_design == 2);
         r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = p.design ? *rtx_of(u) : s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
+      } else if (c > 1) { r = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
       if (p.rew_out) {
         if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = r;
         else static_cast<float*>(p.rew_out)[bN + u] = (float)r;
