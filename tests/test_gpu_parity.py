@@ -1010,3 +1010,56 @@ def test_arrival_stamps_and_information_age_on_the_specialised_kernels(N, A, mod
     assert np.array_equal(st["la"].cpu().numpy().astype(np.int64), oe["la"])
     env.check()
     gen.check()
+
+
+def _default_flag_goldens():
+    out = []
+    for n in golden_names():
+        g = Golden(n)
+        st, c = g.cfg.State, g.cfg
+        if (st.type == 2 and st.add_action and st.action_index == "binary" and st.add_positional_dist_piggy
+                and st.add_positional_dist_type == 2 and not (st.add_reward or st.add_index or st.add_velocity
+                or st.add_position or st.add_positional_dist or st.add_channel_obs)
+                and c.mobility and not c.proportional_fair and not c.enable_fingerprint and g.trace is None):
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("name", _default_flag_goldens())
+def test_reference_fixtures_replayed_on_the_specialised_kernels(name):
+    """Every reference fixture recorded with the toy YAML's State flags, replayed through
+    the fused `step` (no channel-obs output, so step_fast64 / step_wide run - with the
+    arrival stamps, and whichever of my_step / my_step_ch / my_step_design the fixture
+    used at each slot) and compared with what the REFERENCE produced: rewards, state
+    vectors, positions, information age and the table planes at the recorded checkpoints."""
+    g = Golden(name)
+    B = 2
+    env = make_env(g.cfg, B)
+    env.reset_topology(g["x0"], g["y0"], g["v0"])
+    ck = g.table_checkpoints()
+    cfg = g.cfg
+    for i, mode, actions, t, (ep, eps) in g.steps():
+        a = env._actions(np.asarray(actions))
+        obs, rew, done = env._step(mode, a, t, ep, eps)
+        torch.cuda.synchronize()
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for b in range(B):
+            if uses_exp(cfg, mode) and mode != STEP_DESIGN:
+                assert exp_close(rew[b], g["rews"][i]), (name, i)
+            else:
+                assert np.array_equal(rew[b], g["rews"][i]), (name, i)
+            assert np.array_equal(obs[b], g["state"][i]), (name, i)     # one-hot + histogram: exact
+        if i in g.vel_updates:
+            env.update_velocity(g.vel_updates[i])
+        ia = env.info_age(t).cpu().numpy()
+        st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        for b in range(B):
+            assert np.array_equal(st["pos_x"][b], g["pos_x"][i]), (name, i)
+            assert np.array_equal(ia[b], g["ia"][i]), (name, i)
+            if i in ck:
+                j = ck[i]
+                assert np.array_equal(st["seq"][b], g["tab_seq"][j])
+                assert np.array_equal(st["age"][b], np.minimum(g["tab_age"][j], 255))
+                assert np.array_equal(st["x"][b], g["tab_x"][j])
+                assert np.array_equal(st["la"][b], g["tab_la"][j])
+    env.check()
