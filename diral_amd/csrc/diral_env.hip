@@ -117,13 +117,14 @@ bool is_fast_cfg(const StepParams& p) {
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL;
   return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN) &&
-         p.state_out != nullptr && p.chobs_out == nullptr && p.trace == nullptr;
+         p.state_out != nullptr && p.chobs_out == nullptr;
 }
 
 hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
   const bool fast_cfg = is_fast_cfg(p), ch = p.mode == DIRAL_STEP_MY_STEP_CH;
-  // the generic FAST instantiation: my_step, f32 outputs, no arrival stamps
-  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP && !(p.flags & DIRAL_F_TRACK_ARRIVAL);
+  // the generic FAST instantiation: my_step, f32 outputs, no arrival stamps, no trace replay
+  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP && !(p.flags & DIRAL_F_TRACK_ARRIVAL) &&
+                    p.trace == nullptr;
   const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
   const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
   if (use_fast64 || use_wide) {
@@ -135,7 +136,8 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
-    const bool extra = f.design != 0 || f.la != nullptr;   // EXTRA instantiation: the run-time switches compiled in
+    f.trace = p.trace; f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
+    const bool extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
     if (use_wide) {

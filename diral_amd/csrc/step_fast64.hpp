@@ -54,6 +54,8 @@ struct FastParams {
   uint32_t* tkey;
   double* tx;
   int32_t* la;                   // last_arrival_time[tx][rx] (network.py:39-42) or null: not tracked
+  const double* trace;           // replayed x positions (network.py:171-178, 194-199) or null
+  int trace_len, trace_per_env;
   double* metrics;
   uint32_t* err;
   const double* edges;
@@ -231,7 +233,13 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   for (int c = 0; c < 16; ++c) w1[c] = tk_ld[c * NV + lane];
   __builtin_amdgcn_sched_barrier(0);
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
-  const double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;       // network.py:203
+  double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;             // network.py:203
+  if (EXTRA && p.trace && live) {                                              // replay branch, network.py:194-199
+    long long tt = p.t % p.trace_len;
+    if (tt < 0) tt += p.trace_len;
+    const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
+    mynpx = p.trace[(base + (size_t)tt) * N + lane];
+  }
   if (wave == 0) { s_act[lane] = myact; s_cnt[lane] = 0u; }
   for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = my_edge;                 // K <= 64 < 256 threads

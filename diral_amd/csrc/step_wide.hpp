@@ -243,7 +243,14 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     if (lv && (a < 0 || a >= A)) { atomicOr(p.err, kErrAction); a = -1; }
     s_act[u] = a;
     s_px[u] = x;
-    s_npx[u] = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;      // network.py:203
+    double nx = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;     // network.py:203
+    if (EXTRA && p.trace && lv) {                            // replay branch, network.py:194-199
+      long long tt = p.t % p.trace_len;
+      if (tt < 0) tt += p.trace_len;
+      const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
+      nx = p.trace[(base + (size_t)tt) * N + u];
+    }
+    s_npx[u] = nx;
     s_cnt[u] = 0u;
   }
   for (int j = tid; j < KP * NPAD; j += THREADS) s_hist[j] = 0u;

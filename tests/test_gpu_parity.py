@@ -1020,7 +1020,7 @@ def _default_flag_goldens():
         if (st.type == 2 and st.add_action and st.action_index == "binary" and st.add_positional_dist_piggy
                 and st.add_positional_dist_type == 2 and not (st.add_reward or st.add_index or st.add_velocity
                 or st.add_position or st.add_positional_dist or st.add_channel_obs)
-                and c.mobility and not c.proportional_fair and not c.enable_fingerprint and g.trace is None):
+                and c.mobility and not c.proportional_fair and not c.enable_fingerprint):
             out.append(n)
     return out
 
@@ -1051,6 +1051,8 @@ def test_reference_fixtures_replayed_on_the_specialised_kernels(name):
             assert np.array_equal(obs[b], g["state"][i]), (name, i)     # one-hot + histogram: exact
         if i in g.vel_updates:
             env.update_velocity(g.vel_updates[i])
+        if g.trace is not None and i == g.trace_after:
+            env.load_saved_positions(g.trace)
         ia = env.info_age(t).cpu().numpy()
         st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
         for b in range(B):
