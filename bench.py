@@ -133,10 +133,10 @@ def kernel_name(N: int, A: int, out_dtype: str, step_mode: str = "my_step") -> s
     o64 = "true" if out_dtype == "f64" else "false"
     ch = "true" if step_mode == "my_step_ch" else "false"
     if N <= 64 and A <= 64:
-        return "diral::step_fast64_kernel<true,%s,%s>" % (o64, ch)
+        return "diral::step_fast64_kernel<true,%s,%s,false>" % (o64, ch)
     if 64 < N <= 256 and A <= 64:
-        return "diral::step_wide_kernel<%d,%s,%s,%s>" % (2 if N <= 128 else 4, o64,
-                                                          "true" if N in (128, 256) else "false", ch)
+        return "diral::step_wide_kernel<%d,%s,%s,%s,false>" % (2 if N <= 128 else 4, o64,
+                                                                "true" if N in (128, 256) else "false", ch)
     return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
                                            "true" if (out_dtype == "f32" and ch == "false") else "false")
 
