@@ -1,7 +1,8 @@
 // step_fast64.hpp - the fused env-step kernel specialised for the headline
-// configuration: N <= 64 vehicles (one wavefront lane per vehicle), A <= 32
+// configuration: N <= 64 vehicles (one wavefront lane per vehicle), A <= 64
 // resources, the toy YAML's State flags (one-hot action + type-2 piggybacked
-// positional histogram), my_step + obtain_state, float32 or float64 outputs.
+// positional histogram), my_step / my_step_ch / my_step_design + obtain_state,
+// float32 or float64 outputs.
 //
 // Same semantics as step_kernel.hpp (which stays the general path and is what
 // the parity tests compare this kernel against, bit for bit); what changes is
@@ -19,7 +20,7 @@
 //   * gossip merge key[u] = max(key[u], key[m_i(u)]): one ds_bpermute + max per
 //     (resource, column PAIR): two columns travel as 16-bit (rank, source) keys in
 //     one register (exactness argument and fallback at the merge loop);
-//   * a compact parameter block (no SGPR spills), 32-bit table offsets, padded
+//   * a compact parameter block, 32-bit table offsets, padded
 //     viewer stride (NV = 64) so table loads/stores need no lane predicate;
 //   * when every vehicle has y == 0 (any random topology, network.py:104) the
 //     distance is |dx| exactly and the dy logic is compiled out (FLAT);
