@@ -1065,3 +1065,30 @@ def test_reference_fixtures_replayed_on_the_specialised_kernels(name):
                 assert np.array_equal(st["x"][b], g["tab_x"][j])
                 assert np.array_equal(st["la"][b], g["tab_la"][j])
     env.check()
+
+
+@pytest.mark.parametrize("N,A,B", [(64, 32, 2048), (256, 64, 2048), (128, 64, 4096)])
+def test_default_flag_configurations_are_served_by_the_specialised_kernels(N, A, B):
+    """Dispatch guard: with the toy YAML's State flags `step` must run on step_fast64 /
+    step_wide.  They are 2x+ faster than the general kernel, so a silent fall-back shows
+    as a missing gap between the normal path and the forced general path."""
+    import time
+    cfg = bench_config(N, A, 2000.0 if N <= 64 else 4000.0)
+
+    def run(force_general):
+        env = make_env(cfg, B, dtype=torch.float32)
+        env.reset_topology(seed=3)
+        acts = [env.sample(seed=i) for i in range(4)]
+        ctx = _general_kernel() if force_general else __import__("contextlib").nullcontext()
+        with ctx:
+            for t in range(40):
+                env.step(acts[t % 4], t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(40, 140):
+                env.step(acts[t % 4], t)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+    fast, general = min(run(False), run(False)), min(run(True), run(True))
+    assert general > 1.4 * fast, (fast, general)
