@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // Vehicle.periodic_update (vehicle.py:56-70), branch-free: the own entry gets
     // seq+1 / age 0, every other entry age+1 (saturating at 255)
     const int own_c = live ? lane - wave * 16 : -1;            // column of this lane's own entry, if in this wave
-    bool ovf = false;
+    unsigned int wmax = 0u;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const unsigned int w = w1[c];
@@ -390,10 +390,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
       const unsigned int a0 = w & 255u;
       const unsigned int age = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
-      ovf = ovf || (own && seq >= (1u << 24) - 1u);
       w1[c] = (seq << 8) | age;
+      wmax = max(wmax, w1[c]);
     }
-    if (ovf) atomicOr(p.err, kErrSeq);
+    // sequence-number overflow: no entry exceeds its subject's own number, so the largest
+    // word seen reaches the limit exactly when some own stamp does
+    if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq);
   }
   // Vehicle.received_update for every (resource, rx), resources ascending:
   // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
@@ -541,8 +543,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     double* out = static_cast<double*>(p.state_out) + bN * S;
     if (((A | K) & 1) == 0) {
       const int q_per_row = S >> 1, total = N * q_per_row;
+      const int du = 256 / q_per_row, dq = 256 - du * q_per_row;
+      int u = tid / q_per_row, qr = tid - u * q_per_row;
       for (int q = tid; q < total; q += 256) {
-        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 1;
+        const int s0 = qr << 1;
         double2 v;
         if (s0 < A) {
           const int a = s_act[u] - s0;
@@ -554,6 +558,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           v = n ? make_double2((double)h[0] / dn, (double)h[1] / dn) : make_double2(0.0, 0.0);
         }
         stream_store2(out + 2 * q, v);
+        u += du; qr += dq;
+        if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
       }
     } else {
       for (int e = tid; e < N * S; e += 256) {
@@ -571,8 +577,11 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   float* out = static_cast<float*>(p.state_out) + bN * S;
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
+    // (row, quad) advance incrementally: one integer division per thread instead of one per store
+    const int du = 256 / q_per_row, dq = 256 - du * q_per_row;
+    int u = tid / q_per_row, qr = tid - u * q_per_row;
     for (int q = tid; q < total; q += 256) {
-      const int u = q / q_per_row, s0 = (q - u * q_per_row) << 2;
+      const int s0 = qr << 2;
       float4 v;
       if (s0 < A) {
         const int a = s_act[u] - s0;
@@ -587,6 +596,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
               : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       stream_store4(out + 4 * q, v);
+      u += du; qr += dq;
+      if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
     }
   } else {
     for (int e = tid; e < N * S; e += 256) {
