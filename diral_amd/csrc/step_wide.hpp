@@ -170,6 +170,9 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #ifndef DIRAL_WIDE_MINWAVES4
 #define DIRAL_WIDE_MINWAVES4 6           // N <= 256: 84 VGPRs, three 512-thread workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_REGCNT
+#define DIRAL_WIDE_REGCNT 1
+#endif
 #ifndef DIRAL_WIDE_XPRE2
 #define DIRAL_WIDE_XPRE2 1
 #endif
@@ -420,6 +423,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 
   // viewer-side tail of one entry: stores, then its histogram contribution
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
+  // neighbour count per viewer: in registers where the VGPR budget has room (N <= 128: one
+  // barrier and one pass over the histogram less), else the row sum of the histogram
+  constexpr bool REGCNT = (VPL == 2) && (DIRAL_WIDE_REGCNT != 0);
+  unsigned int mycnt[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
   auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, global_ptr<unsigned int> tkrow,
                   global_ptr<double> txrow) {
     const int u = lane + 64 * j;
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       const double e0 = s_edges[est], e1 = s_edges[est + 1];
       const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
       atomicAdd(&s_hist[u * KP + (bin >> 1)], 1u << (16 * (bin & 1)));
+      if constexpr (REGCNT) mycnt[j] += 1u;
     }
   };
 
@@ -686,14 +696,21 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     d[3] = t_p3; d[4] = t_p3 + acc_load; d[5] = d[4] + acc_merge; d[6] = d[5] + acc_fin;
   }
 #endif
-  __syncthreads();
-  // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
-  if (tid < NPAD) {
-    unsigned int n = 0u;
-    for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[tid * KP + q]; n += (w & 0xffffu) + (w >> 16); }
-    s_cnt[tid] = n;
+  if constexpr (REGCNT) {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      if (mycnt[j]) atomicAdd(&s_cnt[lane + 64 * j], mycnt[j]);
   }
   __syncthreads();
+  // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
+  if constexpr (!REGCNT) {
+    if (tid < NPAD) {
+      unsigned int n = 0u;
+      for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[tid * KP + q]; n += (w & 0xffffu) + (w >> 16); }
+      s_cnt[tid] = n;
+    }
+    __syncthreads();
+  }
 
   // ---- P4: metrics, done flag, state = [one-hot(action) (A) | histogram (K)] ------
   if (tid == 0) {
