@@ -13,6 +13,12 @@ move -> observe), actions pre-generated in HBM, outputs written to HBM.
 One process per GPU; envs are independent so ranks share nothing on the step
 path (weak scaling: B per GPU fixed); RCCL is used once, to all-reduce the
 episode metrics.  Rank 0 prints ONE JSON line.
+
+Timed region: after the reset every run first plays PREROLL untimed slots (SURVEY
+8d: >= 50, past the ghost-entry / table-filling phase of the first 19 slots, Q4),
+then the W warm-up slots it was asked for, then exactly K timed slots between
+barrier + synchronize pairs.  The kernel's own duration is measured with HIP events
+on the launch stream over the same K launches.
 """
 from __future__ import annotations
 
@@ -31,9 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from diral_amd.config import bench_config  # noqa: E402
+from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
+                              bench_config)
 from diral_amd.metrics import gather_metrics  # noqa: E402
-from diral_amd.roofline import HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot  # noqa: E402
+from diral_amd.roofline import (HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot,  # noqa: E402
+                                layout_bytes_per_env_slot)
 from diral_amd.vec_env import VecV2VEnv  # noqa: E402
 
 WORKLOADS = {
@@ -41,7 +49,10 @@ WORKLOADS = {
     "c2": (64, 32, 2000.0, 4096, False),    # BASELINE.json configs[1]: the metric's config
     "c3": (256, 64, 4000.0, 8192, False),   # configs[2] congested
     "c5": (128, 64, 4000.0, 16384, True),   # configs[4] dynamic density
+    "c4shard": (64, 32, 2000.0, 32768, False),   # configs[3]: the per-GPU share of 262144 envs over 8 GPUs
 }
+PREROLL = 60      # untimed slots after every reset, before the requested warm-up (>= 50)
+GLOBAL_SEED = 1234
 
 
 def usable_cores() -> int:
@@ -61,18 +72,23 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, seconds_target: float = 12.0):
-    """Time the CPU oracle (oracle/diral_oracle.c, the reference restated in C,
-    reference-faithful pow() mode) on this host's cores on a bounded sample of
-    the same workload.  A reported baseline, not the target."""
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _time_oracle(cfg, threads: int, seconds_target: float):
     import numpy as np
-    from oracle.oracle import Oracle, SQ_POW, has_openmp
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    cores = usable_cores()
-    threads = min(cores, 64) if has_openmp() else 1
+    from oracle.oracle import Oracle, SQ_POW
     N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
-    B = max(threads * 16, 64)
-    rng = np.random.default_rng(1234)
+    B = max(threads * 16, 16)
+    rng = np.random.default_rng(GLOBAL_SEED)
     o = Oracle(cfg, batch=B, sq_mode=SQ_POW, threads=threads)
     o.reset(rng.integers(0, int(L), size=(B, N)).astype(np.float64), np.zeros((B, N)),
             rng.uniform(1.1, 2.7, size=(B, N)))
@@ -91,11 +107,28 @@ def cpu_baseline(cfg, seconds_target: float = 12.0):
         el = time.perf_counter() - t0
         if el >= seconds_target or slots >= 20000:
             break
+    return B * N * slots / el, B, slots, warm, el
+
+
+def cpu_baseline(cfg):
+    """Time the CPU oracle (oracle/diral_oracle.c, the reference restated in C,
+    reference-faithful pow() mode) on this host: at ONE thread and on every usable
+    core, on a bounded sample of the same workload.  A reported
+    baseline, not the target."""
+    from oracle.oracle import has_openmp
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    cores = usable_cores()
+    threads = min(cores, 64) if has_openmp() else 1
+    v1, b1, s1, warm, e1 = _time_oracle(cfg, 1, 6.0)
+    vn, bn, sn, _, en = _time_oracle(cfg, threads, 10.0) if threads > 1 else (v1, b1, s1, warm, e1)
+    N, A = cfg.num_users, cfg.num_channels
     return {
-        "value": B * N * slots / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-        "sample": "%d envs x %d slots of the same %d-UE/%d-res workload after %d warm-up slots, "
-                  "oracle/diral_oracle.c (C restatement pinned to the reference goldens), "
-                  "OpenMP over envs on %d host threads, %.1f s" % (B, slots, N, A, warm, threads, el),
+        "value": vn, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+        "value_1thread": v1, "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": cores,
+        "sample": "the same %d-UE/%d-res workload after %d warm-up slots, oracle/diral_oracle.c (C restatement "
+                  "pinned to the reference goldens), my_step + obtain_state per slot: %d envs x %d slots on %d "
+                  "OpenMP threads (%.1f s); %d envs x %d slots on 1 thread (%.1f s)" % (
+                      N, A, warm, bn, sn, threads, en, b1, s1, e1),
     }
 
 
@@ -127,29 +160,116 @@ def prr_parity(cfg, device, envs: int = 64, slots: int = 60):
             "tolerance": 1e-6, "sample": "%d envs x %d slots, my_step_ch, reward_design %d" % (envs, slots, cfg.reward_design)}
 
 
-def kernel_name(N: int, A: int, out_dtype: str, step_mode: str = "my_step") -> str:
-    """The step kernel csrc/diral_env.hip dispatches for the bench configuration
-    (default State flags, my_step / my_step_ch, all y == 0)."""
-    o64 = "true" if out_dtype == "f64" else "false"
-    ch = "true" if step_mode == "my_step_ch" else "false"
-    if N <= 64 and A <= 64:
-        return "diral::step_fast64_kernel<true,%s,%s,false>" % (o64, ch)
-    if 64 < N <= 256 and A <= 64:
-        return "diral::step_wide_kernel<%d,%s,%s,%s,false>" % (2 if N <= 128 else 4, o64,
-                                                                "true" if N in (128, 256) else "false", ch)
-    return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4,
-                                           "true" if (out_dtype == "f32" and ch == "false") else "false")
+def kernel_name(code: int, N: int, out_dtype: str) -> str:
+    """Name of the instantiation `diral_env_last_kernel` reports (what rocprofv3's
+    kernel trace shows); all y == 0 in the bench topologies."""
+    def b(x):
+        return "true" if x else "false"
+    fam = code & 15
+    o64, ch, extra, rich = out_dtype == "f64", bool(code & KERNEL_CH), bool(code & KERNEL_EXTRA), bool(code & KERNEL_RICH)
+    if fam == KERNEL_FAST64:
+        return "diral::step_fast64_kernel<true,%s,%s,%s,%s>" % (b(o64), b(ch), b(extra), b(rich))
+    if fam == KERNEL_WIDE:
+        return "diral::step_wide_kernel<%d,%s,%s,%s,%s,%s>" % (2 if N <= 128 else 4, b(o64), b(N in (128, 256)), b(ch),
+                                                             b(extra), b(rich))
+    return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, b(out_dtype == "f32" and not ch))
 
 
 def load_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC summary (profiles/), if any."""
+    """HBM bytes per launch from the committed PMC summary (profiles/pmc_traffic.json:
+    rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this bench command, separate runs), if any.
+    NOT measured in this run - rocprofv3 cannot attach to itself."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            d = json.load(fh)
-        return d.get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(fh).get(workload)
     except Exception:
         return None
+
+
+def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f32", step_mode="my_step",
+                 emit_chobs=False, sticky=0.0, use_dist=False):
+    """One timed run of one workload on this rank.  Returns (env, result dict)."""
+    N, A, L, B, vary = WORKLOADS[name]
+    if batch > 0:
+        B = batch
+    cfg = bench_config(N, A, L, mobility_vary=vary)
+    dt = torch.float32 if out_dtype == "f32" else torch.float64
+    # one GLOBAL seed; rank r holds envs [r*B, (r+1)*B) of the whole batch (DIRAL_OPT_ENV_OFFSET):
+    # the sharded job draws what one GPU holding all world*B envs would draw
+    env = VecV2VEnv(cfg, batch=B, device=device, out_dtype=dt, step_mode=step_mode, env_offset=rank * B)
+    env.reset_topology(seed=GLOBAL_SEED)
+
+    # synthetic actions, resident in HBM before the timed region: a ring of
+    # pre-drawn [B,N] tensors (iid uniform, or sticky to mimic a converged policy)
+    ring = 32
+    acts = [env.sample(seed=1000 + i) for i in range(ring)]
+    if sticky > 0:
+        g = torch.Generator(device=device).manual_seed(99 + rank)
+        for i in range(1, ring):
+            keep = torch.rand((B, N), device=device, generator=g) < sticky
+            acts[i] = torch.where(keep, acts[i - 1], acts[i])
+    mode = env.step_mode
+    ei = cfg.episode_interval
+
+    def one_step(t):
+        if emit_chobs:
+            env._step(mode, acts[t % ring], t, want_chobs=True)      # state + reward + channel observation
+        else:
+            env.step(acts[t % ring], t)
+        if t % ei == ei - 1:
+            env.update_velocity(seed=t)      # main_test.py:226-233 (no-op unless mobility_vary)
+
+    t = 0
+    for _ in range(PREROLL + warmup):
+        one_step(t)
+        t += 1
+    torch.cuda.synchronize(device)
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize(device)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        one_step(t)
+        t += 1
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / steps       # HIP events on the launch stream
+    env.check()
+    if use_dist:
+        w = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    bytes_launch = algorithmic_bytes_per_env_slot(N, A, cfg.state_space) * B
+    layout_launch = layout_bytes_per_env_slot(N, A, cfg.state_space, emit_chobs) * B
+    achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
+    code = env.last_kernel()
+    res = {
+        "workload": name, "N": N, "A": A, "B": B, "L": L, "state_space": cfg.state_space, "cfg": cfg,
+        "wall": wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": kernel_ms,
+        "agent_steps_per_s": float(B) * N * steps * world / wall,
+        "kernel": kernel_name(code, N, out_dtype), "kernel_code": code,
+        "algorithmic_bytes_per_launch": bytes_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
+        "layout_bytes_per_launch": layout_launch,
+        "layout_rate_GBps": layout_launch / (kernel_ms * 1e-3) / 1e9,
+    }
+    return env, res
+
+
+def short(res):
+    """The keys of a secondary measurement that go into the JSON line."""
+    return {"workload": "%s: %d-UE/%d-res, batch=%d" % (res["workload"], res["N"], res["A"], res["B"]),
+            "agent_steps_per_s": res["agent_steps_per_s"], "ms_per_step": res["ms_per_step"],
+            "kernel_ms": res["kernel_ms"], "kernel": res["kernel"],
+            "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
+            "achieved_GBps": res["achieved"], "frac": res["frac"]}
 
 
 def main() -> int:
@@ -164,7 +284,11 @@ def main() -> int:
                     help="probability an agent keeps its resource (0 = iid uniform, worst case)")
     ap.add_argument("--step-mode", default="my_step", choices=["my_step", "my_step_ch"],
                     help="my_step = the metric's step kind; my_step_ch = the PRR-reward variant (test_env.py:351-443)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emit-chobs", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the timed step also writes the channel observation `obs` of the reference "
+                         "step (4*N*A bytes per env-slot, part of SURVEY 8d's byte model); 0: state + reward only")
+    ap.add_argument("--no-cpu-baseline", "--lean", dest="lean", action="store_true",
+                    help="only the timed run (profiling passes): no CPU baseline, PRR parity or secondary workloads")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,73 +311,25 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    N, A, L, B, vary = WORKLOADS[args.workload]
-    if args.batch > 0:
-        B = args.batch
-    cfg = bench_config(N, A, L, mobility_vary=vary)
-    out_dtype = torch.float32 if args.out_dtype == "f32" else torch.float64
-    env = VecV2VEnv(cfg, batch=B, device=device, out_dtype=out_dtype, step_mode=args.step_mode)
-    env.reset_topology(seed=1234 + rank)
-
-    # synthetic actions, resident in HBM before the timed region: a ring of
-    # pre-drawn [B,N] tensors (iid uniform, or sticky to mimic a converged policy)
-    ring = 32
-    acts = [env.sample(seed=1000 * rank + i) for i in range(ring)]
-    if args.sticky > 0:
-        g = torch.Generator(device=device).manual_seed(99 + rank)
-        for i in range(1, ring):
-            keep = torch.rand((B, N), device=device, generator=g) < args.sticky
-            acts[i] = torch.where(keep, acts[i - 1], acts[i])
-
-    ei = cfg.episode_interval
-    t = 0
-
-    def one_step(t):
-        env.step(acts[t % ring], t)
-        if t % ei == ei - 1:
-            env.update_velocity(seed=t)      # main_test.py:226-233 (no-op unless mobility_vary)
-
-    for _ in range(args.warmup):
-        one_step(t)
-        t += 1
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize(device)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        one_step(t)
-        t += 1
-    ev1.record()
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t_start
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-
-    env.check()
+    emit = bool(args.emit_chobs)
+    env, res = run_workload(args.workload, device, rank, world, args.steps, args.warmup, args.batch, args.out_dtype,
+                            args.step_mode, emit, args.sticky, use_dist)
     totals = gather_metrics(env)                         # RCCL all-reduce (metrics only)
-    if use_dist:
-        w = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+    cfg = res["cfg"]
+    del env
 
     if rank == 0:
-        agent_steps = float(B) * N * args.steps * world
-        bytes_launch = algorithmic_bytes_per_env_slot(N, A, cfg.state_space) * B
-        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        N, A, B, L = res["N"], res["A"], res["B"], res["L"]
+        tr = load_traffic(args.workload if args.batch in (0, WORKLOADS[args.workload][3]) else "")
+        traffic = tr.get("hbm_bytes_per_launch") if tr else None
         line = {
             "metric": "agent-steps/sec (envs x vehicles), %d-UE/%d-res batched env" % (N, A),
-            "value": agent_steps / wall,
+            "value": res["agent_steps_per_s"],
             "unit": "agent-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -261,27 +337,56 @@ def main() -> int:
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d-UE/%d-res, batch=%d envs per GPU x %d GPU, L=%g m, Rc=%g, K=%d bins, "
-                            "reward_design=2, %s+obtain_state fused, %s actions, %s outputs" % (
+                            "reward_design=2, %s+obtain_state fused (state + reward%s), %s actions, %s outputs" % (
                                 args.workload, N, A, B, world, L, cfg.communication_range,
-                                cfg.State.num_bins, args.step_mode, "iid-uniform" if args.sticky == 0 else
-                                "sticky(p=%.2f)" % args.sticky, args.out_dtype),
+                                cfg.State.num_bins, args.step_mode, " + channel observation" if emit else "",
+                                "iid-uniform" if args.sticky == 0 else "sticky(p=%.2f)" % args.sticky, args.out_dtype),
                 "batch_per_gpu": B, "num_users": N, "num_channels": A, "state_space": cfg.state_space,
-                "parallelism": "env-shard x%d (no data-path collective)" % world,
+                "emit_chobs": emit, "preroll_slots": PREROLL,
+                "parallelism": "env-shard x%d (no data-path collective; one global seed, rank r = envs [r*B, (r+1)*B))" % world,
             },
             "roofline": {
                 "bound": "hbm",
-                "achieved": achieved,
+                "achieved": res["achieved"],
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": load_traffic(args.workload),
-                "kernel": kernel_name(N, A, args.out_dtype, args.step_mode),
-                "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_launch": bytes_launch,
+                "frac": res["frac"],
+                "traffic": traffic,
+                "traffic_source": ("committed PMC passes of this command, not measured in this run: %s" % tr.get("source")) if tr else None,
+                "traffic_rate_GBps": (traffic / (res["kernel_ms"] * 1e-3) / 1e9) if traffic else None,
+                "kernel": res["kernel"],
+                "kernel_ms": res["kernel_ms"],
+                "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
+                # what this build's packed layout moves at least (12 B per table entry instead of the
+                # canonical 16 B of SURVEY 8d): the kernel is VALU-bound, this is its real HBM rate
+                "layout_bytes_per_launch": res["layout_bytes_per_launch"],
+                "layout_rate_GBps": res["layout_rate_GBps"],
+                "layout_frac_of_peak": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
+                "limiter": "VALU issue (float64 compare/select work of the merge and the histogram), see profiles/README.md",
             },
             "episode_metrics": totals,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.lean:
+            # short same-run measurements of the other BASELINE.json configurations and of the
+            # opposite --emit-chobs setting (each: PREROLL untimed slots + a few timed ones)
+            also = {}
+            specs = [("c2_emit_chobs_%d" % (0 if emit else 1), "c2", dict(emit_chobs=not emit, steps=300)),
+                     ("c4shard", "c4shard", dict(emit_chobs=emit, steps=100)),
+                     ("c3", "c3", dict(emit_chobs=emit, steps=40)),
+                     ("c5", "c5", dict(emit_chobs=emit, steps=60))]
+            for key, wl, kw in specs:
+                if args.workload != "c2" or args.batch:
+                    break
+                try:
+                    e2, r2 = run_workload(wl, device, 0, 1, kw["steps"], 10, 0, args.out_dtype, args.step_mode,
+                                          kw["emit_chobs"], args.sticky, False)
+                    del e2
+                    torch.cuda.empty_cache()
+                    also[key] = short(r2)
+                    also[key]["emit_chobs"] = kw["emit_chobs"]
+                except Exception as exc:                      # a secondary measurement never fails the line
+                    also[key] = {"error": repr(exc)[:200]}
+            line["also_measured"] = also
             line["cpu_baseline"] = cpu_baseline(cfg)
             line["prr_parity"] = prr_parity(cfg, device)
         print(json.dumps(line))

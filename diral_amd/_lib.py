@@ -21,7 +21,7 @@ SYMBOLS = [
     "diral_env_reset", "diral_env_step", "diral_env_observe", "diral_env_update_velocity",
     "diral_env_sample", "diral_env_info_age", "diral_env_export_state", "diral_env_import_state",
     "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error", "diral_sps_step", "diral_sps_init",
-    "diral_env_set_trace",
+    "diral_env_set_trace", "diral_env_set_option", "diral_env_last_kernel",
 ]
 
 _lib = None
@@ -73,6 +73,8 @@ def load() -> ctypes.CDLL:
         "diral_sps_step": (I, [I, I, P, P, P, D, D, D, P, P, P, U64, P, P]),
         "diral_sps_init": (I, [I, I, P, P, U64, P]),
         "diral_env_set_trace": (I, [P, P, I, I, P]),
+        "diral_env_set_option": (I, [P, I, I64]),
+        "diral_env_last_kernel": (I, [P]),
     }
     for name in SYMBOLS:
         try:

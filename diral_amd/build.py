@@ -13,13 +13,15 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiral_env.so")
-SOURCES = ["diral_env.hip"]
+# one translation unit per kernel family: hipcc compiles them in parallel
+SOURCES = ["diral_env.hip", "k_fast64.hip", "k_wide2.hip", "k_wide4.hip", "k_general.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))
 
 # -ffp-contract=off: the reference (CPython floats) never fuses a*b+c; the bin
 # edges, distances and the position wrap must round exactly as it does.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fno-fast-math", "-fPIC", "-shared"]
+               "-fno-fast-math", "-fPIC"]
+OBJDIR = os.path.join(HERE, "build")
 
 
 def hipcc_path() -> str:
@@ -38,14 +40,40 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+def _obj_stale(src: str, obj: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    deps.append(os.path.join(HERE, "..", "include", "diral_env.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB, objdir: str = OBJDIR) -> str:
+    """Compile every translation unit (in parallel, one hipcc each) and link the .so.
+    `extra_flags` / `lib` / `objdir`: tuning variants (-D...) built next to the product."""
+    if not force and lib == LIB and not is_stale():
+        return lib
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and not _obj_stale(src, obj):
+            continue
+        cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, pr in procs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1
@@ -41,6 +41,18 @@ STEP_DESIGN = 2
 
 DT_F32 = 0
 DT_F64 = 1
+
+OPT_ENV_OFFSET = 1
+OPT_KERNEL_PATH = 2
+PATH_AUTO = 0
+PATH_GENERAL = 1
+
+KERNEL_GENERAL = 0
+KERNEL_FAST64 = 1
+KERNEL_WIDE = 2
+KERNEL_RICH = 16
+KERNEL_EXTRA = 32
+KERNEL_CH = 64
 
 MAX_USERS = 256
 MAX_CHANNELS = 256

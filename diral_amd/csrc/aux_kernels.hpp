@@ -22,7 +22,10 @@ __device__ inline double rng_unit(uint64_t r) { return (double)(r >> 11) * (1.0 
 // Network.initialize_mobility_topology (network.py:92-119): x = randint(0, L)
 // (integer valued), y = randint(0, H/2) = 0, v = 1.7 if mobility_vary else
 // uniform(1.1, 2.7); any of x0/y0/v0 given => copied instead.
-__global__ void reset_kernel(int total, double L, int vary, uint64_t seed, const double* x0,
+// Device draws are indexed by the GLOBAL vehicle index idx0 + i (idx0 = env offset of this
+// handle x N, DIRAL_OPT_ENV_OFFSET): a batch sharded over several handles / GPUs draws
+// exactly what one handle holding the whole batch draws.
+__global__ void reset_kernel(int total, double L, int vary, uint64_t seed, uint64_t idx0, const double* x0,
                              const double* y0, const double* v0, double* pos_x, double* pos_y,
                              double* vel) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,27 +34,27 @@ __global__ void reset_kernel(int total, double L, int vary, uint64_t seed, const
   if (x0) x = x0[i];
   else {
     const double Lf = floor(L);
-    x = floor(rng_unit(rng_u64(seed, 1, (uint64_t)i)) * Lf);
+    x = floor(rng_unit(rng_u64(seed, 1, idx0 + (uint64_t)i)) * Lf);
     if (x >= Lf) x = Lf - 1.0;
   }
   y = y0 ? y0[i] : 0.0;
   if (v0) v = v0[i];
-  else v = vary ? 1.7 : 1.1 + rng_unit(rng_u64(seed, 2, (uint64_t)i)) * (2.7 - 1.1);
+  else v = vary ? 1.7 : 1.1 + rng_unit(rng_u64(seed, 2, idx0 + (uint64_t)i)) * (2.7 - 1.1);
   pos_x[i] = x; pos_y[i] = y; vel[i] = v;
 }
 
 // TestEnv.sample (test_env.py:116-122)
-__global__ void sample_kernel(int total, int A, uint64_t seed, int32_t* out) {
+__global__ void sample_kernel(int total, int A, uint64_t seed, uint64_t idx0, int32_t* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  out[i] = (int32_t)(rng_u64(seed, 3, (uint64_t)i) % (uint64_t)A);
+  out[i] = (int32_t)(rng_u64(seed, 3, idx0 + (uint64_t)i) % (uint64_t)A);
 }
 
 // Network.update_velocity (network.py:208-223)
-__global__ void velocity_kernel(int total, const uint8_t* draws, uint64_t seed, double* vel) {
+__global__ void velocity_kernel(int total, const uint8_t* draws, uint64_t seed, uint64_t idx0, double* vel) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int r = draws ? (int)draws[i] : 1 + (int)(rng_u64(seed, 4, (uint64_t)i) % 3ull);
+  const int r = draws ? (int)draws[i] : 1 + (int)(rng_u64(seed, 4, idx0 + (uint64_t)i) % 3ull);
   double v = vel[i];
   if (r == 1) { v += 0.55; if (v > 2.77) v = 2.77; }
   else if (r == 2) { v -= 0.55; if (v < 1.1) v = 1.1; }
@@ -145,15 +148,15 @@ __global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* p
       const double* w = win + (size_t)i * A;
       const int prev = action;
       const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
-      double thr = threshold;
+      double thr_next = threshold, thr = threshold;
       int n_sa = 0;
       for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
+        thr = thr_next;                                                // the threshold THIS sA is built with
         n_sa = 0;
         for (int s = 0; s < A; ++s) n_sa += (s != prev && w[s] < thr) ? 1 : 0;
-        thr += inc_db;
+        thr_next = thr + inc_db;                                       // tmp_threshold += self.inc_dB
         if (!((double)n_sa < min_sA)) break;
       }
-      thr -= inc_db;                                                   // the threshold sA was built with
       const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
       int need = (int)min_len;
       if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len

@@ -12,6 +12,7 @@
 
 #include "aux_kernels.hpp"
 #include "common.hpp"
+#include "launch.hpp"
 #include "step_kernel.hpp"
 #include "step_fast64.hpp"
 #include "step_wide.hpp"
@@ -24,7 +25,11 @@ struct DiralEnv {
   int B = 0, N = 0, A = 0, K = 0, S = 0, NV = 0, NR = 0, vpl = 1;
   int device = 0;
   StepParams base;       // everything that does not change per call
+  RichParams rich;       // section offsets etc. of the RICH output tail (rich_out.hpp)
   uint32_t lds_bytes = 0;
+  int64_t env_offset = 0;  // global index of env 0 (DIRAL_OPT_ENV_OFFSET): device RNG draws are indexed globally
+  int kernel_path = DIRAL_PATH_AUTO;   // DIRAL_OPT_KERNEL_PATH
+  int last_kernel = -1;    // DIRAL_KERNEL_* of the last step / observe launch
   double* pos_x = nullptr;
   double* pos_y = nullptr;
   double* vel = nullptr;
@@ -103,30 +108,51 @@ Offsets state_offsets(const DiralCfg* c) {
 
 int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
 
-template <int VPL, bool FAST>
-hipError_t launch_step(const StepParams& p, uint32_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((step_kernel<VPL, FAST>), dim3(p.B), dim3(Geo<VPL>::THREADS), lds, s, p);
-  return hipGetLastError();
-}
+// Every entry point that touches the device runs with the handle's device current and
+// restores the caller's (torch's) current device afterwards.
+struct DeviceGuard {
+  int prev = -1, dev;
+  bool ok = true;
+  explicit DeviceGuard(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 
-// FAST instantiation = the metric's configuration (see step_kernel.hpp): the
-// toy YAML's State flags, my_step, no optional side outputs (the generic FAST
-// instantiation additionally needs f32 outputs; step_fast64 has both).
-bool is_fast_cfg(const StepParams& p) {
-  const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_ACTION | DIRAL_F_ADD_POSDIST_PIGGY;
-  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL;
+// State flags that only add OUTPUT columns to the state vector (test_env.py:527-583): served
+// by the RICH instantiations of the specialised kernels (rich_out.hpp)
+constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | DIRAL_F_ADD_REWARD | DIRAL_F_ADD_INDEX |
+                                DIRAL_F_ADD_VELOCITY | DIRAL_F_ADD_POSITION | DIRAL_F_FINGERPRINT;
+
+// Configurations the specialised kernels (step_fast64 / step_wide) serve: the type-2
+// piggybacked histogram observation with any of the cheap State flags, every step kind, any
+// combination of outputs.  PF, PRR tracking in my_step, the secondary observation modes
+// (a15/a16) and static topologies stay on the general kernel.
+bool is_specialised_cfg(const StepParams& p) {
+  const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY;
+  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
+                          DIRAL_F_ADD_ACTION | kRichFlags;
   return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
-         (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN) &&
-         p.state_out != nullptr && p.chobs_out == nullptr;
+         (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN);
+}
+// ... of which the PLAIN instantiations serve the toy YAML's State flags with the state vector
+// as the only observation output (the metric's configuration)
+bool is_plain_cfg(const StepParams& p) {
+  return (p.flags & kRichFlags) == 0 && (p.flags & DIRAL_F_ADD_ACTION) && p.state_out != nullptr &&
+         p.chobs_out == nullptr;
 }
 
-hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream_t s, bool flat_y) {
-  const bool fast_cfg = is_fast_cfg(p), ch = p.mode == DIRAL_STEP_MY_STEP_CH;
-  // the generic FAST instantiation: my_step, f32 outputs, no arrival stamps, no trace replay
-  const bool fast = fast_cfg && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP && !(p.flags & DIRAL_F_TRACK_ARRIVAL) &&
-                    p.trace == nullptr;
-  const bool use_fast64 = fast_cfg && vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && !std::getenv("DIRAL_NO_FAST64");
-  const bool use_wide = fast_cfg && vpl > 1 && p.A <= kWideMaxA && flat_y && !std::getenv("DIRAL_NO_WIDE");
+hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
+  const int vpl = e->vpl;
+  const bool flat_y = e->flat_y;
+  const bool spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
+  const bool plain = spec && is_plain_cfg(p);
+  const bool ch = p.mode == DIRAL_STEP_MY_STEP_CH;
+  // the wide kernels read the reward column of a RICH state back from rew_out
+  const bool wide_rich_ok = plain || !(p.flags & DIRAL_F_ADD_REWARD) || p.state_out == nullptr || p.rew_out != nullptr;
+  const bool use_fast64 = spec && vpl == 1 && p.A <= kFastMaxA && p.NV == 64;
+  const bool use_wide = spec && vpl > 1 && p.A <= kWideMaxA && flat_y && wide_rich_ok;
   if (use_fast64 || use_wide) {
     FastParams f;
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
@@ -137,75 +163,27 @@ hipError_t launch_step_any(int vpl, const StepParams& p, uint32_t lds, hipStream
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
     f.trace = p.trace; f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
-    const bool extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
-    if (use_wide) {
-      const uint32_t wl = wide_lds_layout(vpl, p.A, p.K).total;
-      const dim3 g(p.B), t(64 * wide_waves(vpl));
-      const bool full = p.N == 64 * vpl;
-#define DIRAL_LAUNCH_WIDE(V, O, F, C, X) hipLaunchKernelGGL((step_wide_kernel<V, O, F, C, X>), g, t, wl, s, f)
-#define DIRAL_LAUNCH_WIDE_X(V, O, F, C) do { if (extra) DIRAL_LAUNCH_WIDE(V, O, F, C, true); else DIRAL_LAUNCH_WIDE(V, O, F, C, false); } while (0)
-#define DIRAL_LAUNCH_WIDE_C(V, O, F) do { if (ch) DIRAL_LAUNCH_WIDE_X(V, O, F, true); else DIRAL_LAUNCH_WIDE_X(V, O, F, false); } while (0)
-#define DIRAL_LAUNCH_WIDE_F(V, O) do { if (full) DIRAL_LAUNCH_WIDE_C(V, O, true); else DIRAL_LAUNCH_WIDE_C(V, O, false); } while (0)
-      if (vpl == 2) {
-        if (p.out_f64) DIRAL_LAUNCH_WIDE_F(2, true); else DIRAL_LAUNCH_WIDE_F(2, false);
-      } else {
-        if (p.out_f64) DIRAL_LAUNCH_WIDE_F(4, true); else DIRAL_LAUNCH_WIDE_F(4, false);
-      }
-#undef DIRAL_LAUNCH_WIDE_F
-#undef DIRAL_LAUNCH_WIDE_C
-#undef DIRAL_LAUNCH_WIDE_X
-#undef DIRAL_LAUNCH_WIDE
-      return hipGetLastError();
-    }
-    const uint32_t fl = fast_lds_layout(p.K, p.A).total;
-    const dim3 g(p.B), t(256);
-#define DIRAL_LAUNCH_F64(FL, O, C, X) hipLaunchKernelGGL((step_fast64_kernel<FL, O, C, X>), g, t, fl, s, f)
-#define DIRAL_LAUNCH_F64_X(FL, O, C) do { if (extra) DIRAL_LAUNCH_F64(FL, O, C, true); else DIRAL_LAUNCH_F64(FL, O, C, false); } while (0)
-#define DIRAL_LAUNCH_F64_C(FL, O) do { if (ch) DIRAL_LAUNCH_F64_X(FL, O, true); else DIRAL_LAUNCH_F64_X(FL, O, false); } while (0)
-    if (p.out_f64) {
-      if (flat_y) DIRAL_LAUNCH_F64_C(true, true); else DIRAL_LAUNCH_F64_C(false, true);
-    } else {
-      if (flat_y) DIRAL_LAUNCH_F64_C(true, false); else DIRAL_LAUNCH_F64_C(false, false);
-    }
-#undef DIRAL_LAUNCH_F64_C
-#undef DIRAL_LAUNCH_F64_X
-#undef DIRAL_LAUNCH_F64
-    return hipGetLastError();
+    RichParams r = e->rich;
+    r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
+    r.plain_state = ((p.flags & kRichFlags) == 0 && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
+    KernelSel k;
+    k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
+    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in
+    k.rich = !plain;
+    e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
+                     (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0);
+    if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
+    return launch_fast64(f, r, k, p.B, s);
   }
-  switch (vpl) {
-    case 1: return fast ? launch_step<1, true>(p, lds, s) : launch_step<1, false>(p, lds, s);
-    case 2: return fast ? launch_step<2, true>(p, lds, s) : launch_step<2, false>(p, lds, s);
-    default: return fast ? launch_step<4, true>(p, lds, s) : launch_step<4, false>(p, lds, s);
-  }
-}
-
-template <int VPL>
-hipError_t set_lds_attr(uint32_t lds, int A, int K) {
-  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (r != hipSuccess) return r;
-  if constexpr (VPL > 1) {
-    if (A <= kWideMaxA) {
-      const int wl = (int)wide_lds_layout(VPL, A, K).total;
-      const void* ks[16] = {
-#define DIRAL_WK(O, F, C, X) reinterpret_cast<const void*>(step_wide_kernel<VPL, O, F, C, X>)
-          DIRAL_WK(true, true, false, false),  DIRAL_WK(true, false, false, false), DIRAL_WK(false, true, false, false),
-          DIRAL_WK(false, false, false, false), DIRAL_WK(true, true, true, false),  DIRAL_WK(true, false, true, false),
-          DIRAL_WK(false, true, true, false),  DIRAL_WK(false, false, true, false), DIRAL_WK(true, true, false, true),
-          DIRAL_WK(true, false, false, true),  DIRAL_WK(false, true, false, true),  DIRAL_WK(false, false, false, true),
-          DIRAL_WK(true, true, true, true),    DIRAL_WK(true, false, true, true),   DIRAL_WK(false, true, true, true),
-          DIRAL_WK(false, false, true, true)};
-#undef DIRAL_WK
-      for (const void* kf : ks) {
-        r = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, wl);
-        if (r != hipSuccess) return r;
-      }
-    }
-  }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(step_kernel<VPL, false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // the generic FAST instantiation of the general kernel: the plain configuration on sizes the
+  // specialised kernels do not take (A > 64, vehicles off the y = 0 lane at N > 64): my_step,
+  // f32 outputs, no arrival stamps, no trace replay
+  const bool fast = is_specialised_cfg(p) && is_plain_cfg(p) && !p.out_f64 && p.mode == DIRAL_STEP_MY_STEP &&
+                    !(p.flags & DIRAL_F_TRACK_ARRIVAL) && p.trace == nullptr;
+  e->last_kernel = DIRAL_KERNEL_GENERAL;
+  return launch_general(vpl, fast, p, e->lds_bytes, s);
 }
 
 int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
@@ -325,7 +303,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   e->S = off.S;
 
   auto fail = [&](int code) { diral_env_destroy(e); return code; };
-  if (hipSetDevice(device) != hipSuccess) return fail(DIRAL_ERR_NO_DEVICE);
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(DIRAL_ERR_NO_DEVICE);
 
   const size_t bn = (size_t)e->B * e->N;
   const size_t tab = (size_t)e->B * e->NR * e->NV;
@@ -372,9 +351,9 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 
   const LdsLayout l = lds_layout(64 * e->vpl, e->A, e->K, e->vpl, 4 * e->vpl);
   e->lds_bytes = l.total;
-  if (e->vpl == 1) CREATE_TRY(set_lds_attr<1>(l.total, e->A, e->K));
-  else if (e->vpl == 2) CREATE_TRY(set_lds_attr<2>(l.total, e->A, e->K));
-  else CREATE_TRY(set_lds_attr<4>(l.total, e->A, e->K));
+  CREATE_TRY(set_attr_general(e->vpl, l.total));
+  if (e->vpl == 2 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide2(e->A, e->K));
+  if (e->vpl == 4 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide4(e->A, e->K));
 #undef CREATE_TRY
 
   StepParams& p = e->base;
@@ -395,13 +374,22 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 #endif
   p.dbg = e->dbg;
   p.la = e->la; p.pf = e->pf; p.metrics = e->metrics; p.err = e->err; p.edges = e->edges;
+  RichParams& r = e->rich;
+  std::memset(&r, 0, sizeof(r));
+  r.S = e->S; r.state_type = cfg->state_type;
+  r.off_act = off.act; r.off_chobs = off.chobs; r.off_hist = off.hist; r.off_rew = off.rew; r.off_idx = off.idx;
+  r.off_pos = off.pos; r.off_vel = off.vel; r.off_fp = off.fp;
+  r.H = cfg->highway_height; r.vel = e->vel; r.pos_y = e->pos_y;
+  // test hooks, read ONCE here (never on the step path): force the general kernel
+  if (std::getenv("DIRAL_NO_FAST64") && e->vpl == 1) e->kernel_path = DIRAL_PATH_GENERAL;
+  if (std::getenv("DIRAL_NO_WIDE") && e->vpl > 1) e->kernel_path = DIRAL_PATH_GENERAL;
   *out = e;
   return DIRAL_OK;
 }
 
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
-  (void)hipSetDevice(e->device);
+  DeviceGuard guard(e->device);
   void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
@@ -411,11 +399,30 @@ int diral_env_destroy(DiralEnv* e) {
 
 int64_t diral_env_hbm_bytes(const DiralEnv* e) { return e ? e->hbm_bytes : 0; }
 
+int diral_env_set_option(DiralEnv* e, int option, int64_t value) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  switch (option) {
+    case DIRAL_OPT_ENV_OFFSET:
+      if (value < 0) return DIRAL_ERR_BAD_ARG;
+      e->env_offset = value;
+      return DIRAL_OK;
+    case DIRAL_OPT_KERNEL_PATH:
+      if (value != DIRAL_PATH_AUTO && value != DIRAL_PATH_GENERAL) return DIRAL_ERR_BAD_ARG;
+      e->kernel_path = (int)value;
+      return DIRAL_OK;
+    default:
+      return DIRAL_ERR_BAD_ARG;
+  }
+}
+
+int diral_env_last_kernel(const DiralEnv* e) { return e ? e->last_kernel : DIRAL_ERR_BAD_ARG; }
+
 const char* diral_env_last_hip_error(const DiralEnv* e) { return e ? e->last_hip_error.c_str() : ""; }
 
 int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const double* v0, uint64_t seed,
                     void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   const size_t tab = (size_t)e->B * e->NR * e->NV;
@@ -425,7 +432,8 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));
   if (e->pf) HIP_TRY(e, hipMemsetAsync(e->pf, 0, bn * 4, s));
   hipLaunchKernelGGL(reset_kernel, dim3(blocks(bn, 256)), dim3(256), 0, s, (int)bn, e->cfg.highway_length,
-                     has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0, seed, x0, y0, v0, e->pos_x, e->pos_y, e->vel);
+                     has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0, seed, (uint64_t)e->env_offset * (uint64_t)e->N, x0, y0, v0,
+                     e->pos_x, e->pos_y, e->vel);
   HIP_TRY(e, hipGetLastError());
   if (y0) { if (refresh_flat_y(e, s) != DIRAL_OK) return DIRAL_ERR_HIP; }
   else e->flat_y = true;
@@ -442,13 +450,14 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   // my_step_ch defines rewards only for reward_design 2,3,4 (test_env.py:413-429)
   if (mode == DIRAL_STEP_MY_STEP_CH && (e->cfg.reward_design < 2 || e->cfg.reward_design > 4))
     return DIRAL_ERR_BAD_CONFIG;
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.mode = mode; p.t = t; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
   p.actions = actions;
   p.state_out = e->S > 0 ? state_out : nullptr;
   p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
   p.chobs_in = nullptr; p.rew_in = nullptr;
-  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
+  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
 }
@@ -458,12 +467,13 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   if (!e || !actions || !state_out) return DIRAL_ERR_BAD_ARG;
   if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
   if (e->S == 0) return DIRAL_OK;
+  DeviceGuard guard(e->device);
   StepParams p = e->base;
   p.mode = kModeObserve; p.t = 0; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
   p.actions = actions; p.state_out = state_out;
   p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
   p.chobs_in = chobs_in; p.rew_in = rew_in;
-  HIP_TRY(e, launch_step_any(e->vpl, p, e->lds_bytes, (hipStream_t)stream, e->flat_y));
+  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
 }
@@ -471,18 +481,20 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
 int diral_env_update_velocity(DiralEnv* e, const uint8_t* draws, uint64_t seed, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   if (!has(&e->cfg, DIRAL_F_MOBILITY_VARY)) return DIRAL_OK;   // test_env.py:503
+  DeviceGuard guard(e->device);
   const size_t bn = (size_t)e->B * e->N;
   hipLaunchKernelGGL(velocity_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, draws,
-                     seed, e->vel);
+                     seed, (uint64_t)e->env_offset * (uint64_t)e->N, e->vel);
   HIP_TRY(e, hipGetLastError());
   return DIRAL_OK;
 }
 
 int diral_env_sample(DiralEnv* e, int32_t* actions_out, uint64_t seed, void* stream) {
   if (!e || !actions_out) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   const size_t bn = (size_t)e->B * e->N;
   hipLaunchKernelGGL(sample_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, e->A, seed,
-                     actions_out);
+                     (uint64_t)e->env_offset * (uint64_t)e->N, actions_out);
   HIP_TRY(e, hipGetLastError());
   return DIRAL_OK;
 }
@@ -490,6 +502,7 @@ int diral_env_sample(DiralEnv* e, int32_t* actions_out, uint64_t seed, void* str
 int diral_env_info_age(DiralEnv* e, int64_t t, int32_t* out, void* stream) {
   if (!e || !out) return DIRAL_ERR_BAD_ARG;
   if (!e->la) return DIRAL_ERR_BAD_CONFIG;
+  DeviceGuard guard(e->device);
   hipLaunchKernelGGL(info_age_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, e->N, (long long)t, e->la, out);
   HIP_TRY(e, hipGetLastError());
   return DIRAL_OK;
@@ -498,6 +511,7 @@ int diral_env_info_age(DiralEnv* e, int64_t t, int32_t* out, void* stream) {
 int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* vel, int32_t* tab_seq,
                            int32_t* tab_age, double* tab_x, double* tab_y, int32_t* last_arrival, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   if (pos_x) HIP_TRY(e, hipMemcpyAsync(pos_x, e->pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
@@ -520,6 +534,7 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
                            const int32_t* tab_seq, const int32_t* tab_age, const double* tab_x,
                            const int32_t* last_arrival, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   if (pos_x) HIP_TRY(e, hipMemcpyAsync(e->pos_x, pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
@@ -543,15 +558,21 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
 
 int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_env, void* stream) {
   if (!e || T < 0) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(e, hipStreamSynchronize(s));               // no launch may still read the old copy
   if (e->trace) { (void)hipFree(e->trace); e->trace = nullptr; }
   e->trace_len = 0; e->trace_per_env = 0;
+  // the step parameters stop pointing at the freed copy BEFORE anything below can fail
+  e->base.trace = nullptr; e->base.trace_len = 0; e->base.trace_per_env = 0;
   if (x_positions && T > 0) {
     const size_t n = (size_t)(per_env ? e->B : 1) * T * e->N;
-    HIP_TRY(e, hipMalloc((void**)&e->trace, n * 8));
-    HIP_TRY(e, hipMemcpyAsync(e->trace, x_positions, n * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
+    double* fresh = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&fresh, n * 8));
+    hipError_t st = hipMemcpyAsync(fresh, x_positions, n * 8, hipMemcpyDeviceToDevice, s);
+    if (st == hipSuccess) st = hipStreamSynchronize(s);
+    if (st != hipSuccess) { (void)hipFree(fresh); return note_hip(e, st, "diral_env_set_trace copy"); }
+    e->trace = fresh;
     e->trace_len = T; e->trace_per_env = per_env ? 1 : 0;
   }
   e->base.trace = e->trace; e->base.trace_len = e->trace_len; e->base.trace_per_env = e->trace_per_env;
@@ -560,6 +581,7 @@ int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_e
 
 int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   const int total = e->B * DIRAL_M_COLUMNS;
   hipLaunchKernelGGL(metrics_kernel, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total, e->metrics,
                      out, clear);
@@ -598,6 +620,7 @@ int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32
 
 int diral_env_check(DiralEnv* e, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   uint32_t flags = 0;
   HIP_TRY(e, hipMemcpyAsync(&flags, e->err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));

@@ -1,0 +1,21 @@
+// k_fast64.hip - every instantiation of step_fast64_kernel (N <= 64) and its launcher.
+#include "launch.hpp"
+#include "step_fast64.hpp"
+
+namespace diral {
+namespace {
+struct LaunchFast64 {
+  const FastParams& f; const RichParams& r; dim3 g; uint32_t lds; hipStream_t s;
+  template <bool FL, bool O, bool C, bool X, bool R>
+  void operator()(std::integer_sequence<bool, FL, O, C, X, R>) const {
+    hipLaunchKernelGGL((step_fast64_kernel<FL, O, C, X, R>), g, dim3(256), lds, s, f, r);
+  }
+};
+}  // namespace
+
+hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
+  const LaunchFast64 l{f, r, dim3(B), fast_lds_layout(f.K, f.A, k.rich).total, s};
+  bool_dispatch(l, std::integer_sequence<bool>{}, k.flat, k.out64, k.ch, k.extra, k.rich);
+  return hipGetLastError();
+}
+}  // namespace diral

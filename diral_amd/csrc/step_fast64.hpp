@@ -27,6 +27,7 @@
 //   * branch-free histogram bin search; rare paths out of line.
 #pragma once
 #include "common.hpp"
+#include "rich_out.hpp"
 #include "step_kernel.hpp"
 
 namespace diral {
@@ -67,9 +68,13 @@ struct FastParams {
 };
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, total;
+  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, total;
 };
-__host__ __device__ inline FastLds fast_lds_layout(int K, int A) {
+// row stride of the gather-source table in words: 64 viewers + 1, so that the output phase of
+// the RICH instantiations (lane -> (viewer, resource quad)) reads it without bank conflicts;
+// the merge (lane = viewer) is conflict-free at any stride
+constexpr int kFastMtabStride = 65;
+__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich) {
   FastLds l;
   uint32_t o = 0;
   const uint32_t a32 = A <= 32 ? 32u : 64u;
@@ -79,9 +84,16 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A) {
   l.act = o;   o += 4u * 64;
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;
-  l.mtab = o;  o += 4u * 64 * a32;         // [resource][vehicle] gather source lane * 4 (bpermute address)
+  l.mtab = o;  o += 4u * kFastMtabStride * a32;   // [resource][vehicle] gather source lane * 4 (bpermute address)
   l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
   l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
+  l.px = l.py = l.npx = l.rew = o;
+  if (rich) {                               // RICH output tail (rich_out.hpp): per-vehicle values by index
+    l.px = o;  o += 8u * 64;
+    l.py = o;  o += 8u * 64;
+    l.npx = o; o += 8u * 64;
+    l.rew = o; o += 8u * 64;
+  }
   l.total = align_up(o, 16);
   return l;
 }
@@ -199,10 +211,12 @@ __device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided
 // move and the observation are the same.
 // EXTRA: the rarely used run-time switches (my_step_design, arrival stamps) are compiled in;
 // the plain instantiations stay free of them (they cost the headline kernel 4 spilled VGPRs).
-template <bool FLAT, bool OUT64, bool CH, bool EXTRA>
-__global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p) {
+// RICH: the output tail of rich_out.hpp (channel observation output, the cheap State flags)
+// instead of the fixed [one-hot | histogram] state; `r` is only read by these instantiations.
+template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH>
+__global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const FastLds lay = fast_lds_layout(p.K, p.A);
+  const FastLds lay = fast_lds_layout(p.K, p.A, RICH);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
@@ -212,6 +226,11 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   int* s_mtab = reinterpret_cast<int*>(smem + lay.mtab);
   double* s_rtx = reinterpret_cast<double*>(smem + lay.rtx);
   int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);       // RICH only
+  double* s_py = reinterpret_cast<double*>(smem + lay.py);
+  double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
+  double* s_rew = reinterpret_cast<double*>(smem + lay.rew);
+  constexpr int MT = kFastMtabStride;
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -258,7 +277,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
     mynpx = p.trace[(base + (size_t)tt) * N + lane];
   }
-  if (wave == 0) { s_act[lane] = myact; s_cnt[lane] = 0u; }
+  if (wave == 0) {
+    s_act[lane] = myact; s_cnt[lane] = 0u;
+    if constexpr (RICH) { s_px[lane] = mypx; s_py[lane] = mypy; s_npx[lane] = mynpx; s_rew[lane] = 0.0; }
+  }
   for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = my_edge;                 // K <= 64 < 256 threads
   DIRAL_FSTAMP(1);
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
     }
     const bool got = live && (myact != i) && (bid >= 0);
-    s_mtab[i * 64 + lane] = (got ? bid : lane) << 2;
+    s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
     if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
     if (CH) {
       if (c > 1) {
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 
   // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
   if (wave == 0) {
-    double r = 0.0;
+    double rw = 0.0;
     int sole = 0, coll = 0;
     double prr = 0.0;
     if (live && myact >= 0) {
@@ -346,15 +368,16 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (CH) {
         const double R = (c > 1) ? s_rtx[lane] : 1.0;         // test_env.py:411-429
         const bool plain = (p.reward_design == 2);
-        r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
+        rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { r = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
+      } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
       if (p.rew_out) {
-        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = r;
-        else static_cast<float*>(p.rew_out)[bN + lane] = (float)r;
+        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = rw;
+        else static_cast<float*>(p.rew_out)[bN + lane] = (float)rw;
       }
+      if constexpr (RICH) s_rew[lane] = rw;
     }
-    double vr = r, vp = prr;
+    double vr = rw, vp = prr;
     int vs = sole, vc = coll;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #pragma unroll 1
     for (int i = 0; i < A; ++i) {
       const int m4 = m_next;
-      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
+      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * MT + lane];
       if (__ballot(myact == i) == 0ull) continue;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -465,7 +488,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #pragma unroll 1
     for (int i = 0; i < A; ++i) {
       const int m4 = m_next;
-      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * 64 + lane];
+      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * MT + lane];
       if (__ballot(myact == i) == 0ull) continue;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -538,6 +561,34 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // ---- P4: state = [one-hot(action) (A) | histogram (K)] ---------------------------
   // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
   // divided by the neighbour count) or float32 (= the float32 cast of that value).
+  if constexpr (RICH) {
+    // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432), rebuilt
+    // from the gather sources: 0 on the own resource or an unused one; my_step with State.type 2:
+    // the distance to the closest in-range transmitter (the same expression P1 evaluated), 100000
+    // (network.py:385) when none is in range; every other step kind / State.type 1: the constant 1
+    const bool dist_obs = !CH && !(EXTRA && p.design) && r.state_type == 2;
+    auto chv = [&](int u, int i) -> double {
+      if (s_act[u] == i || s_mask[i] == 0ull) return 0.0;
+      if (!dist_obs) return 1.0;
+      const int src = s_mtab[i * MT + u] >> 2;
+      if (src == u) return 100000.0;
+      return fast_dist<FLAT>(s_px[src], FLAT ? 0.0 : s_py[src], s_px[u], FLAT ? 0.0 : s_py[u]);
+    };
+    if (r.chobs_out) rich_write_chobs<OUT64>(r.chobs_out, bN, N, A, tid, 256, chv);
+    if (p.state_out && !r.plain_state) {
+      rich_write_state<OUT64>(
+          r, p.flags, N, A, K, p.L, p.state_out, bN, tid, 256, [&](int u) { return s_act[u]; }, chv,
+          [&](int u, int bin) {
+            const unsigned int n = s_cnt[u];
+            return n ? (double)s_hist[u * KP + bin] / (double)n : 0.0;
+          },
+          [&](int u) { return s_rew[u]; }, [&](int u) { return s_npx[u]; },
+          [&](int u) { return FLAT ? 0.0 : s_py[u]; }, [&](int u) { return r.vel[bN + u]; });
+    }
+    // the reference's call pattern on the toy YAML's flags (my_step* with `obs` + obtain_state):
+    // channel observation above, the plain state vector by the vectorised writer below
+    if (!(p.state_out && r.plain_state)) { DIRAL_FSTAMP(7); return; }
+  }
   const int S = A + K;
   if constexpr (OUT64) {
     double* out = static_cast<double*>(p.state_out) + bN * S;

@@ -27,6 +27,7 @@
 //     all y are 0; bin = estimate + edge correction).
 #pragma once
 #include "common.hpp"
+#include "rich_out.hpp"
 #include "step_fast64.hpp"
 #include "step_kernel.hpp"
 
@@ -44,6 +45,11 @@ struct WideLds {
 __host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DIRAL_WIDE_WAVES4; }
 // histogram row stride in 32-bit words: two 16-bit bins per word (counts <= 255), odd stride
 __host__ __device__ constexpr int wide_hist_stride(int K) { return ((K + 1) / 2) | 1; }
+// row stride of the gather-source table in elements (u32 of 4 source bytes at N <= 256, u16 of
+// 2 at N <= 128): 64 lanes + one 32-bit word of padding, so that the RICH output phase
+// (lane -> (viewer, resource quad)) spreads over the banks; the merge (lane-contiguous) is
+// conflict-free at any stride
+__host__ __device__ constexpr int wide_mtab_stride(int vpl) { return vpl == 4 ? 65 : 66; }
 
 __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   const uint32_t npad = 64u * vpl;
@@ -58,7 +64,7 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   l.act = o;   o += 4u * npad;
   l.cnt = o;   o += 4u * npad;
   l.hist = o;  o += 4u * wide_hist_stride(K) * npad;   // [viewer][stride]: two bins per word
-  l.mtab = o;  o += (uint32_t)A * 64u * vpl;   // [resource][lane][slot]: gather source viewer (bytes)
+  l.mtab = o;  o += (uint32_t)A * wide_mtab_stride(vpl) * vpl;   // [resource][lane][slot]: gather source viewer (bytes)
   l.scratch = align_up(o, 16);
   o = l.scratch + 2048u * wide_waves(vpl);     // 2 KB per wave: merge words, then the rank -> xpos table
   l.total = align_up(o, 16);
@@ -190,13 +196,15 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
 // CH: my_step_ch (PRR reward, test_env.py:351-443) instead of my_step, as in step_fast64.hpp
 // EXTRA: run-time switches for my_step_design and the arrival stamps, as in step_fast64.hpp
-template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA>
-__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p) {
+// RICH: the output tail of rich_out.hpp (channel observation output, cheap State flags)
+template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH>
+__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p, const RichParams r) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
   constexpr int PC = 16 / VPL;                 // subject columns per pass
   constexpr int NW = PC / 4;                   // packed rank words per viewer slot; NW * VPL == 4
   constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
+  constexpr int MT = wide_mtab_stride(VPL);    // gather-source table row stride (elements)
   // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
   constexpr bool XPRE = VPL == 2 ? (DIRAL_WIDE_XPRE2 != 0) : (DIRAL_WIDE_XPRE4 != 0);
   static_assert(VPL == 2 || VPL == 4, "one lane holds 2 or 4 viewers");
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
         if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
       }
-      s_mtab[i * 64 + lane] = (mword_t)mw;
+      s_mtab[i * MT + lane] = (mword_t)mw;
       if (CH) {
         if (c > 1) {
           // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // ---- P2 (first VPL waves): reward per transmitter, metric partials, positions --
   if (tid < NPAD) {
     const int u = tid;
-    double r = 0.0, prr = 0.0;
+    double rw = 0.0, prr = 0.0;
     int sole = 0, coll = 0;
     const int a = s_act[u];
     if (u < N && a >= 0) {
@@ -382,16 +390,18 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       if (CH) {
         const double R = (c > 1) ? *rtx_of(u) : 1.0;                          // test_env.py:411-429
         const bool plain = (p.reward_design == 2);
-        r = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
+        rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { r = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { r = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
-      if (p.rew_out) {
-        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = r;
-        else static_cast<float*>(p.rew_out)[bN + u] = (float)r;
-      }
+      } else if (c > 1) { rw = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { rw = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
+    }
+    // (RICH: also for a vehicle whose action was rejected - the output phase reads the
+    // reward column of the state back from rew_out, which therefore must be defined)
+    if (u < N && (RICH || a >= 0) && p.rew_out) {
+      if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = rw;
+      else static_cast<float*>(p.rew_out)[bN + u] = (float)rw;
     }
     if (u < N) p.pos_x[bN + u] = s_npx[u];
-    double vr = r, vp = prr;
+    double vr = rw, vp = prr;
     int vs = sole, vc = coll;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -544,11 +554,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
       wave_lds_order();
       unsigned long long rem = actw;
-      unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * 64 + lane] : 0u;
+      unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
       while (rem) {
         rem &= rem - 1;
         const unsigned int mw = m_next;
-        if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * 64 + lane];
+        if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
         unsigned int v[4], sa[VPL];
         unpack_src_x4<VPL>(mw, sa);
         const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         while (rem) {
           const int i = __builtin_ctzll(rem);
           rem &= rem - 1;
-          const unsigned int mw = (unsigned int)s_mtab[i * 64 + lane];
+          const unsigned int mw = (unsigned int)s_mtab[i * MT + lane];
           unsigned int v[VPL];
 #pragma unroll
           for (int j = 0; j < VPL; ++j) v[j] = sw[(mw >> (8 * j)) & 255u];
@@ -723,6 +733,40 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     mt[DIRAL_M_TX_SOLE] += ss;
     mt[DIRAL_M_TX_COLLIDED] += sc;
     if (CH) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
+  }
+  if constexpr (RICH) {
+    // `obs[user][i]` of the reference step, rebuilt from the gather sources (see step_fast64.hpp)
+    const bool dist_obs = !CH && !(EXTRA && p.design) && r.state_type == 2;
+    auto chv = [&](int u, int i) -> double {
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
+      if (s_act[u] == i || any == 0ull) return 0.0;
+      if (!dist_obs) return 1.0;
+      const int src = (int)(((unsigned int)s_mtab[i * MT + (u & 63)] >> (8 * (u >> 6))) & 255u);
+      if (src == u) return 100000.0;                                          // network.py:385
+      return fast_dist<true>(s_px[src], 0.0, s_px[u], 0.0);
+    };
+    if (r.chobs_out) rich_write_chobs<OUT64>(r.chobs_out, bN, N, A, tid, THREADS, chv);
+    if (p.state_out && !r.plain_state) {
+      // the reward column is read back from rew_out (written in P2 by this workgroup, two
+      // barriers ago; the host dispatches here only with rew_out set when the column exists):
+      // 2 KB of LDS for it would cost the third workgroup per CU at N = 256
+      rich_write_state<OUT64>(
+          r, p.flags, N, A, K, p.L, p.state_out, bN, tid, THREADS, [&](int u) { return s_act[u]; }, chv,
+          [&](int u, int bin) {
+            const unsigned int n = s_cnt[u];
+            const unsigned int h = (s_hist[u * KP + (bin >> 1)] >> (16 * (bin & 1))) & 0xffffu;
+            return n ? (double)h / (double)n : 0.0;
+          },
+          [&](int u) {
+            if constexpr (OUT64) return static_cast<const double*>(p.rew_out)[bN + u];
+            else return (double)static_cast<const float*>(p.rew_out)[bN + u];
+          },
+          [&](int u) { return s_npx[u]; }, [&](int) { return 0.0; }, [&](int u) { return r.vel[bN + u]; });
+    }
+    // plain state vector next to the channel observation: the vectorised writer below
+    if (!(p.state_out && r.plain_state)) { DIRAL_WSTAMP(7); return; }
   }
   const int S = A + K;
   if constexpr (OUT64) {

@@ -99,8 +99,8 @@ class DriverLoop:
     def bootstrap(self, action=None) -> torch.Tensor:
         action = self.env.sample() if action is None else action
         obs, rews = self.env.my_step(action, 0)
+        state = self._t(self.env.obtain_state(obs, action, rews)).clone()
         self._rews0 = self._t(rews).clone()
-        state = self._t(self.env.obtain_state(obs, action, self._rews0)).clone()
         return state
 
     # main_test.py:99-114 (the stored reward is the stale bootstrap `rews`, :110-112)
@@ -124,6 +124,7 @@ class DriverLoop:
             obs, reward = env.my_step_ch(action, time_step)                  # :144
         else:
             obs, reward = env.my_step(action, time_step)                     # :146
+        reward_ret = reward                      # as returned: what main_test.py:164 hands to obtain_state
         reward = self._t(reward).clone()
         raw = reward.clone()
         out: Dict[str, Any] = {}
@@ -141,7 +142,9 @@ class DriverLoop:
         if fused_state is not None:
             next_state = fused_state.clone()
         else:
-            next_state = self._t(env.obtain_state(obs, action, reward, self.episode, self.eps)).clone()   # :164
+            # (the returned tensors, unmodified: VecV2VEnv then serves the state its fused launch
+            # already built instead of a second launch)
+            next_state = self._t(env.obtain_state(obs, action, reward_ret, self.episode, self.eps)).clone()   # :164
         sum_r = np_sum_lastdim(reward)                                       # :171 (NumPy's summation order)
         collision = self.A - sum_r                                           # :178
         a = self._actions(action).to(reward.device)

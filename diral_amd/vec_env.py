@@ -17,8 +17,8 @@ from typing import Any, Dict, Mapping, Optional, Tuple, Union
 import torch
 
 from . import _lib
-from .config import (DT_F32, DT_F64, ERR_HIP, M_COLUMNS, OK, STEP_DESIGN, STEP_MY_STEP,
-                     STEP_MY_STEP_CH, ConfigError, EnvConfig)
+from .config import (DT_F32, DT_F64, ERR_HIP, M_COLUMNS, OK, OPT_ENV_OFFSET, OPT_KERNEL_PATH, PATH_AUTO,
+                     PATH_GENERAL, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, ConfigError, EnvConfig)
 
 _MODES = {"my_step": STEP_MY_STEP, "my_step_ch": STEP_MY_STEP_CH, "my_step_design": STEP_DESIGN,
           STEP_MY_STEP: STEP_MY_STEP, STEP_MY_STEP_CH: STEP_MY_STEP_CH, STEP_DESIGN: STEP_DESIGN}
@@ -53,11 +53,23 @@ class VecV2VEnv:
         always float64 (like the reference); float32 is a final cast.
     step_mode : "my_step" | "my_step_ch" | "my_step_design"
         which reference step function ``step()`` stands for.
+    env_offset : int
+        global index of this handle's env 0 when a batch is sharded over several
+        handles / GPUs: device RNG draws are a function of (seed, global env index),
+        so shards reproduce the unsharded batch (``DIRAL_OPT_ENV_OFFSET``).
+    speculate_state : bool
+        the reference's per-slot pair ``obs, rews = env.my_step(a, t)`` /
+        ``env.obtain_state(obs, a, rews, ...)`` (main_test.py:144-164) as ONE fused
+        launch: ``my_step*`` also builds the state vector, and ``obtain_state``
+        returns it when it is called with exactly what ``my_step*`` returned and
+        nothing changed the env in between (otherwise it launches
+        ``diral_env_observe`` as before).
     """
 
     def __init__(self, cfg: Union[EnvConfig, Mapping[str, Any]], batch: int = 1,
                  device: Union[str, int, torch.device] = "cuda:0",
-                 out_dtype: torch.dtype = torch.float32, step_mode: Union[str, int] = "my_step"):
+                 out_dtype: torch.dtype = torch.float32, step_mode: Union[str, int] = "my_step",
+                 env_offset: int = 0, speculate_state: bool = True):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_dict(cfg)
         cfg.validate()
@@ -98,6 +110,12 @@ class VecV2VEnv:
             self._done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
             self._chobs: Optional[torch.Tensor] = None
         self.t = 0
+        self.env_offset = 0
+        if env_offset:
+            self.set_env_offset(env_offset)
+        self.speculate_state = bool(speculate_state)
+        self._spec: Optional[tuple] = None      # what the speculative state of the last my_step* is valid for
+        self._vel_calls = 0                     # default-seed counter of update_velocity()
 
     # ---- lifetime -------------------------------------------------------------
     def close(self) -> None:
@@ -141,6 +159,20 @@ class VecV2VEnv:
     def hbm_bytes(self) -> int:
         return int(self.lib.diral_env_hbm_bytes(self._h))
 
+    def set_env_offset(self, offset: int) -> None:
+        """Global index of env 0 (sharded batches, see the class docstring)."""
+        self._ok(self.lib.diral_env_set_option(self._h, OPT_ENV_OFFSET, int(offset)), "diral_env_set_option")
+        self.env_offset = int(offset)
+
+    def force_general_kernel(self, on: bool = True) -> None:
+        """Tests / A-B timing: run every step on the general kernel (csrc/step_kernel.hpp)."""
+        self._ok(self.lib.diral_env_set_option(self._h, OPT_KERNEL_PATH, PATH_GENERAL if on else PATH_AUTO),
+                 "diral_env_set_option")
+
+    def last_kernel(self) -> int:
+        """config.KERNEL_* code of the kernel the last step / observe call launched."""
+        return int(self.lib.diral_env_last_kernel(self._h))
+
     # ---- reference getters (test_env.py:486-496) ----------------------------
     def get_total_users(self) -> int:
         return self.N
@@ -165,6 +197,7 @@ class VecV2VEnv:
         self._ok(self.lib.diral_env_reset(self._h, _ptr(x0), _ptr(y0), _ptr(v0), int(seed) & (2**64 - 1),
                                           self._stream()), "diral_env_reset")
         self.t = 0
+        self._spec = None
 
     def reset(self, x0=None, y0=None, v0=None, seed: int = 0, actions=None) -> torch.Tensor:
         """``reset() -> obs``.  The reference has no reset(); its driver
@@ -203,6 +236,7 @@ class VecV2VEnv:
               want_chobs: bool = False, want_obs: bool = True):
         if want_chobs and self._chobs is None:
             self._chobs = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+        self._spec = None
         st = self.lib.diral_env_step(self._h, mode, _ptr(actions), int(t),
                                      _ptr(self._obs) if (want_obs and self.S > 0) else None,
                                      _ptr(self._rew), _ptr(self._done),
@@ -232,26 +266,68 @@ class VecV2VEnv:
     # reference-named batched variants: return (chobs[B,N,A], rews[B,N]) like
     # `obs, rews = env.my_step(actions, timestep)` and leave the state vector
     # to obtain_state(), so a main_test-style loop reads the same.
-    def my_step(self, actions, timestep: int = 0):
+    def _ref_step(self, mode: int, actions, t: int):
         a = self._actions(actions)
         self._last_actions = a
-        self._step(STEP_MY_STEP, a, timestep, want_chobs=True, want_obs=False)
+        self._step(mode, a, t, want_chobs=True, want_obs=self.speculate_state)
+        if self.speculate_state and self.S > 0:
+            # the state vector built in the same launch is what obtain_state(chobs, actions, rew)
+            # would build now; remember what it is valid for (tensor identity + version counters)
+            self._spec = (actions if isinstance(actions, torch.Tensor) else None, a, a._version,
+                          self._chobs._version, self._rew._version)
         return self._chobs, self._rew
+
+    def my_step(self, actions, timestep: int = 0):
+        return self._ref_step(STEP_MY_STEP, actions, timestep)
 
     def my_step_ch(self, actions, time_step: int = 0):
-        a = self._actions(actions)
-        self._last_actions = a
-        self._step(STEP_MY_STEP_CH, a, time_step, want_chobs=True, want_obs=False)
-        return self._chobs, self._rew
+        return self._ref_step(STEP_MY_STEP_CH, actions, time_step)
 
     def my_step_design(self, actions, timestep: int = 0):
-        a = self._actions(actions)
-        self._last_actions = a
-        self._step(STEP_DESIGN, a, timestep, want_chobs=True, want_obs=False)
-        return self._chobs, self._rew
+        return self._ref_step(STEP_DESIGN, actions, timestep)
+
+    def _spec_state_for(self, obs, acts, rewards, episode: float, eps: float) -> Optional[torch.Tensor]:
+        """The speculative state of the last my_step* if `obtain_state(obs, acts, rewards)` asks
+        for exactly that: the tensors my_step* returned, unmodified, and the actions it was given."""
+        sp = self._spec
+        if sp is None:
+            return None
+        given, a, a_ver, c_ver, r_ver = sp
+        st = self.cfg.State
+        # `obs` / `rewards` only matter to the state through their own sections (test_env.py:540, 563)
+        if st.add_channel_obs and (obs is not self._chobs or self._chobs._version != c_ver):
+            return None
+        if st.add_reward and (rewards is not self._rew or self._rew._version != r_ver):
+            return None
+        if a._version != a_ver:
+            return None
+        if not (acts is a or (given is not None and acts is given)):
+            t = torch.as_tensor(acts, device=self.device)
+            if t.shape != a.shape and t.dim() == 1:
+                t = t.unsqueeze(0).expand(self.B, self.N)
+            if t.shape != a.shape or not bool(torch.equal(t.to(torch.int32), a)):
+                return None
+        if self.cfg.enable_fingerprint:
+            # (episode, eps) columns: test_env.py:577-579 - the only part of the state that
+            # obtain_state's extra arguments decide
+            self._write_fingerprint(float(episode), float(eps))
+        return self._obs
+
+    def _fp_offset(self) -> int:
+        # section order of obtain_state (test_env.py:527-583): ... velocity, fingerprint last
+        return self.S - 2
+
+    def _write_fingerprint(self, episode: float, eps: float) -> None:
+        o = self._fp_offset()
+        self._obs[:, :, o] = episode
+        self._obs[:, :, o + 1] = eps
 
     def obtain_state(self, obs, acts, rewards, episode_number: float = 0, epsilon: float = 1) -> torch.Tensor:
         """test_env.py:527-583 on the current tables/positions; [B, N, S]."""
+        hit = self._spec_state_for(obs, acts, rewards, episode_number, epsilon)
+        if hit is not None:
+            return hit
+        self._spec = None
         a = self._actions(acts)
         chobs = None if obs is None else self._f64(obs, (self.B, self.N, self.A))
         rew = None if rewards is None else self._f64(rewards, (self.B, self.N))
@@ -266,7 +342,11 @@ class VecV2VEnv:
         if draws is not None:
             d = torch.as_tensor(draws, dtype=torch.uint8, device=self.device).expand(self.B, self.N).contiguous()
         if seed is None:
-            seed = self.t * 2654435761 + 12345
+            # a fresh draw per call (network.py:208-223 draws from the global RNG every episode):
+            # the default seed counts update_velocity() calls, not env steps
+            self._vel_calls += 1
+            seed = self._vel_calls * 2654435761 + 12345
+        self._spec = None
         self._ok(self.lib.diral_env_update_velocity(self._h, _ptr(d), int(seed) & (2**64 - 1), self._stream()),
                  "diral_env_update_velocity")
 
@@ -278,6 +358,7 @@ class VecV2VEnv:
         argument the config's `load_file_pos` is used when `load_positions` is set."""
         if x_positions is None and self.cfg.load_positions:
             x_positions = self.cfg.extra.get("load_file_pos")
+        self._spec = None
         if x_positions is None:
             self._ok(self.lib.diral_env_set_trace(self._h, None, 0, 0, self._stream()), "diral_env_set_trace")
             return
@@ -321,6 +402,7 @@ class VecV2VEnv:
         B, N = self.B, self.N
         def ti(a):
             return None if a is None else torch.as_tensor(a, dtype=torch.int32, device=self.device).expand(B, N, N).contiguous()
+        self._spec = None
         px, py, v = self._f64(pos_x, (B, N)), self._f64(pos_y, (B, N)), self._f64(vel, (B, N))
         s, a, xx, l = ti(seq), ti(age), self._f64(x, (B, N, N)), ti(la)
         self._ok(self.lib.diral_env_import_state(self._h, _ptr(px), _ptr(py), _ptr(v), _ptr(s), _ptr(a), _ptr(xx),

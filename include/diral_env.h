@@ -13,7 +13,12 @@
  *    DEVICE pointer (HBM) unless its name ends in `_host`.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
  *    entry points that take a stream only ENQUEUE work on it (no host sync, no
- *    allocation) - safe inside hipGraph capture.
+ *    allocation) - safe inside hipGraph capture.  Exceptions, which SYNCHRONISE
+ *    the stream: diral_env_check, diral_env_set_trace, and diral_env_reset /
+ *    diral_env_import_state when they are given y positions (the host keeps an
+ *    "every y == 0" flag that selects the kernel instantiation).
+ *  - every entry point runs with the handle's device current and restores the
+ *    caller's current device before it returns.
  *  - B = parallel envs (independent episodes), N = num_users, A = num_channels,
  *    S = state_space.  Batched arrays are row-major [B][N], [B][N][A], [B][N][S].
  *  - return value: 0 = DIRAL_OK, <0 = DiralStatus error; diral_env_strerror().
@@ -28,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 1
+#define DIRAL_ABI_VERSION 2
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -148,6 +153,35 @@ int diral_env_destroy(DiralEnv* env);
 
 /* bytes of HBM the handle owns (for sizing batches against 288 GB) */
 int64_t diral_env_hbm_bytes(const DiralEnv* env);
+
+/* ---- handle options ---------------------------------------------------------- */
+typedef enum DiralOption {
+  /* global index of this handle's env 0.  The reference draws topology, actions and
+   * velocity changes from unseeded global RNGs (network.py:103-110, 214;
+   * test_env.py:121); here every device draw is a pure function of (seed, global
+   * env index, vehicle), so a batch sharded over several handles / GPUs (shard g
+   * owning envs [offset_g, offset_g + B_g)) draws exactly what one handle holding
+   * the whole batch draws with the same seed. */
+  DIRAL_OPT_ENV_OFFSET = 1,
+  /* DIRAL_PATH_AUTO (default): configurations the specialised kernels serve run on
+   * them; DIRAL_PATH_GENERAL: always the general kernel (tests compare the two). */
+  DIRAL_OPT_KERNEL_PATH = 2
+} DiralOption;
+enum { DIRAL_PATH_AUTO = 0, DIRAL_PATH_GENERAL = 1 };
+int diral_env_set_option(DiralEnv* env, int option, int64_t value);
+
+/* which kernel the last diral_env_step / diral_env_observe call launched:
+ * DIRAL_KERNEL_GENERAL, or DIRAL_KERNEL_FAST64 / DIRAL_KERNEL_WIDE or'ed with the
+ * instantiation bits; negative before the first call. */
+enum {
+  DIRAL_KERNEL_GENERAL = 0,   /* csrc/step_kernel.hpp  */
+  DIRAL_KERNEL_FAST64  = 1,   /* csrc/step_fast64.hpp, N <= 64       */
+  DIRAL_KERNEL_WIDE    = 2,   /* csrc/step_wide.hpp,  64 < N <= 256  */
+  DIRAL_KERNEL_RICH    = 16,  /* channel-obs output / cheap State flags (csrc/rich_out.hpp) */
+  DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
+  DIRAL_KERNEL_CH      = 64   /* my_step_ch */
+};
+int diral_env_last_kernel(const DiralEnv* env);
 
 /* ---- topology / reset ------------------------------------------------------- */
 

@@ -15,6 +15,8 @@ Reference entry points exercised (all under /root/reference/envs):
   Network.update_velocity    network.py:208-223
   Network.get_information_age network.py:560-574
 
+  SemiPersistentScheduling   algorithms/v2x_sps.py:8-104   (`sps` fixtures)
+
 Usage:  python tests/golden/gen_golden.py        (rewrites tests/golden/*.npz)
 """
 import contextlib
@@ -450,12 +452,99 @@ def main_driver():
                     ia_penalty_enable=True, ia_penalty_threshold=2)
 
 
+def run_sps_case(name, n_agents, A, T, threshold, seed, level_lo, level_hi, tie_step):
+    """The reference's SPS agent (algorithms/v2x_sps.py) itself, one object per agent, fed
+    recorded selection windows; its three global-RNG calls are mocked with recorded draws:
+      random.randint(a, b)  -> the recorded counter / initial values
+      random.random()       -> the recorded keep draw
+      random.choice(sB)     -> sB[draw % len(sB)] with the recorded draw
+    Recorded: initial (prev_action, counter), per step and agent the window (as integer
+    codes: window = code * tie_step, exact in float64), the three draws, and the decisions
+    (action, reselection_counter, prev_action after the step) plus how often the threshold
+    was raised (len of the while loop, v2x_sps.py:41-50) for the fixture's own statistics."""
+    sys.path.insert(0, "/root/reference/algorithms")
+    import v2x_sps as ref_sps
+    rng = np.random.default_rng(seed)
+    cur = {}
+    ref_sps.random = mock.MagicMock()
+
+    def fake_randint(a, b):
+        if (a, b) == (5, 16):
+            return int(cur["counter"])
+        raise AssertionError((a, b))
+    ref_sps.random.randint.side_effect = fake_randint
+    ref_sps.random.random.side_effect = lambda: float(cur["keep"])
+    ref_sps.random.choice.side_effect = lambda seq: seq[int(cur["choice"]) % len(seq)]
+
+    init_prev = rng.integers(0, A, size=n_agents)           # randint(0, selection_window) with window = A - 1
+    init_cnt = rng.integers(5, 16, size=n_agents)            # randint(5, 15)
+    agents = []
+    for u in range(n_agents):
+        draws = [int(init_prev[u]), int(init_cnt[u])]
+        ref_sps.random.randint.side_effect = lambda a, b, d=draws: d.pop(0)
+        ag = ref_sps.SemiPersistentScheduling(u, A - 1, threshold)
+        assert ag.prev_action == init_prev[u] and ag.reselection_counter == init_cnt[u]
+        agents.append(ag)
+    ref_sps.random.randint.side_effect = fake_randint
+
+    codes = np.zeros((T, n_agents, A), np.int16)
+    d_counter = rng.integers(5, 17, size=(T, n_agents)).astype(np.int32)
+    d_keep = rng.random((T, n_agents))
+    d_choice = rng.integers(0, 1 << 20, size=(T, n_agents)).astype(np.int32)
+    actions = np.zeros((T, n_agents), np.int32)
+    counters = np.zeros((T, n_agents), np.int32)
+    prevs = np.zeros((T, n_agents), np.int32)
+    for t in range(T):
+        for u, ag in enumerate(agents):
+            # windows: mostly a busy band around the threshold (ties by quantisation), sometimes
+            # everything far above it (several 3 dB raises), sometimes nearly all free
+            r = rng.random()
+            if r < 0.2:
+                c = rng.integers(level_hi, level_hi + 40, size=A)
+            elif r < 0.35:
+                c = rng.integers(level_lo - 60, level_lo, size=A)
+            else:
+                c = rng.integers(level_lo, level_hi, size=A)
+            codes[t, u] = c
+            win = [float(v) * tie_step for v in c]
+            cur.update(counter=d_counter[t, u], keep=d_keep[t, u], choice=d_choice[t, u])
+            actions[t, u] = ag.step(win)
+            counters[t, u] = ag.reselection_counter
+            prevs[t, u] = ag.prev_action
+    n_resel = ref_sps.random.choice.call_count
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, A=np.int64(A), threshold=np.float64(threshold), tie_step=np.float64(tie_step),
+                        init_prev=init_prev.astype(np.int32), init_counter=init_cnt.astype(np.int32),
+                        codes=codes, draw_counter=d_counter, draw_keep=d_keep, draw_choice=d_choice,
+                        actions=actions, counters=counters, prev_actions=prevs, reselections=np.int64(n_resel))
+    print("%-28s agents=%-3d A=%-2d steps=%-3d reselections=%d  %7.1f KB" % (
+        name, n_agents, A, T, n_resel, os.path.getsize(path) / 1024))
+
+
+def main_sps():
+    # ---- S: the SPS baseline (SURVEY section 8f rank 3), recorded from algorithms/v2x_sps.py ----
+    # integer-dB windows around an integer threshold: ties, threshold raises
+    run_sps_case("s1_sps_int_threshold", n_agents=40, A=12, T=140, threshold=-110.0, seed=81,
+                 level_lo=-125, level_hi=-95, tie_step=1.0)
+    # non-integer threshold and quarter-dB windows: `tmp_threshold += 3` accumulates roundings
+    # ((thr + 3) - 3 != thr), boundary subframes sit within an ulp of the threshold sequence
+    run_sps_case("s2_sps_frac_threshold", n_agents=40, A=20, T=140, threshold=-110.3, seed=82,
+                 level_lo=-500, level_hi=-380, tie_step=0.25)
+    # tiny window (A = 3: min_sA = 0.6) and A = 1 (the only subframe is the previous action:
+    # sA stays empty while len(sA) < 0.2 ... the reference loops forever there, so A >= 2)
+    run_sps_case("s3_sps_small_window", n_agents=24, A=3, T=200, threshold=-110.0, seed=83,
+                 level_lo=-120, level_hi=-100, tie_step=0.5)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "driver":
         main_driver()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sps":
+        main_sps()
     elif len(sys.argv) > 1 and sys.argv[1] == "trace":
         main_trace()
     else:
         main()
         main_trace()
         main_driver()
+        main_sps()

@@ -1,0 +1,210 @@
+"""GPU parity, the cases round 1 left to argument:
+
+* G7: histogram values exactly on / one ulp around every bin edge on the HIP
+  path - the kernels estimate the bin with a reciprocal multiply and correct it against the
+  np.linspace edges (csrc/step_fast64.hpp, step_wide.hpp, step_kernel.hpp hist_bin); NumPy
+  (np.histogram, network.py:500) and the oracle are the references;
+* the device-RNG branch of update_velocity (network.py:208-223): a fresh draw per call;
+* shard invariance of every device draw (DIRAL_OPT_ENV_OFFSET) and one C4-shard-sized run
+  (BASELINE.json configs[3]: 32768 envs per GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_WIDE, STEP_MY_STEP, bench_config
+from tests.test_gpu_parity import make_env
+
+pytestmark = pytest.mark.gpu
+
+
+def edge_candidates(K, rb, rng, count):
+    """`count` histogram values: every edge and its two neighbours first, then random
+    multiples of ulps around random edges, +-0, and values just inside +-Rb."""
+    edges = np.linspace(-rb, rb, K + 1)
+    c = []
+    for e in edges:
+        c += [e, np.nextafter(e, -np.inf), np.nextafter(e, np.inf)]
+    c += [0.0, -0.0, np.nextafter(rb, 0.0), -np.nextafter(rb, 0.0), 5e-324, -5e-324, 1e-300, -1e-300]
+    c = np.array(c)
+    extra = []
+    while len(c) + len(extra) < count:
+        e = edges[rng.integers(0, K + 1)]
+        v = e
+        for _ in range(int(rng.integers(0, 6))):
+            v = np.nextafter(v, np.inf if rng.random() < 0.5 else -np.inf)
+        extra.append(v if rng.random() < 0.7 else rng.uniform(-rb, rb))
+    return np.concatenate([c, np.array(extra)])[:count] if len(c) < count else c[:count]
+
+
+@pytest.mark.parametrize("K,rb", [(10, 500.0), (20, 500.0), (40, 500.0), (20, 123.456), (7, 250.0)])
+@pytest.mark.parametrize("N,path", [(64, "fast64"), (40, "fast64"), (64, "fast64_y"), (64, "general"),
+                                    (65, "wide"), (128, "wide"), (256, "wide"), (200, "wide"), (130, "general")])
+def test_histogram_bin_edges_sweep_on_the_hip_path(K, rb, N, path):
+    """Every vehicle sits at x = L - v, so its post-move position is exactly 0 and the
+    histogram value of a table entry is the entry's xpos itself (no rounding between the
+    candidate and the kernel's bin search); communication_range 0: nobody hears anybody, the
+    imported tables reach the observation untouched (only stamped / aged).  Compared with the
+    oracle (full state, bit for bit, f64 and f32 outputs) and with np.histogram directly."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    A, L, v = 4, 100000.0, 1.0
+    cfg = bench_config(N, A, L, bin_range=rb, communication_range=0.0, State=dict(num_bins=K))
+    B = 3
+    rng = np.random.default_rng(70000 + K * 1000 + N + int(rb))
+    ylane = 1.0 if path == "fast64_y" else 0.0          # all on one lane off y = 0: the non-FLAT instantiation
+    pos_x = np.full((B, N), L - v)
+    pos_y = np.full((B, N), ylane)
+    vel = np.full((B, N), v)
+    cand = edge_candidates(K, rb, rng, B * N * N).reshape(B, N, N)
+    for b in range(B):                                  # shuffle so every kernel column sees edge cases
+        cand[b] = rng.permutation(cand[b].ravel()).reshape(N, N)
+    seq = np.ones((B, N, N), np.int32)
+    age = rng.integers(0, 20, size=(B, N, N)).astype(np.int32)      # 19 -> 20 after the stamp: invalid
+    x = cand.copy()
+    for u in range(N):                                  # own entries: what a run would hold
+        x[:, u, u] = L - v
+        age[:, u, u] = 0
+    envs = {dt: make_env(cfg, B, dtype=dt) for dt in (torch.float64, torch.float32)}
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=4)
+    orc.reset(pos_x, pos_y, vel)
+    orc.import_state(seq=seq, age=age, x=x, y=np.where(seq > 0, ylane, 0.0) * np.ones((B, N, N)))
+    acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+    o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, 0)
+    o_state = orc.obtain_state(acts, o_chobs, o_rew)
+    want_kernel = {"fast64": KERNEL_FAST64, "fast64_y": KERNEL_FAST64, "wide": KERNEL_WIDE, "general": KERNEL_GENERAL}[path]
+    for dt, env in envs.items():
+        env.reset_topology(pos_x, pos_y, vel)
+        env.import_state(pos_x, pos_y, vel, seq=seq, age=age, x=x)
+        env.force_general_kernel(path == "general")
+        obs, rew, _ = env.step(acts, 0)
+        torch.cuda.synchronize()
+        assert env.last_kernel() == want_kernel
+        assert np.array_equal(env.export_state()["pos_x"].cpu().numpy(), np.zeros((B, N)))   # post-move x == 0
+        got = obs.cpu().numpy()
+        assert np.array_equal(got, o_state if dt == torch.float64 else o_state.astype(np.float32)), (K, rb, N, path)
+        env.check()
+    # ... and against NumPy itself (network.py:500) for every viewer
+    hist = envs[torch.float64]._obs.cpu().numpy()[:, :, A:]
+    for b in range(B):
+        for u in range(N):
+            dx = cand[b, u]                                        # x1 - x2 with x2 (own post-move x) == 0
+            d = np.sqrt(dx * dx)                                   # Network.dist (network.py:318-332): tiny dx underflow to 0
+            vals = [(d[k] if dx[k] > 0 else -d[k])                 # dist_piggy sign: +1 iff x1 - x2 > 0 (network.py:552-556)
+                    for k in range(N) if k != u and age[b, u, k] + 1 < 20 and d[k] < rb]
+            ref = np.histogram(sorted(vals), K, range=(-rb, rb))[0] / float(len(vals)) if vals else np.zeros(K)
+            assert np.array_equal(hist[b, u], ref), (K, rb, N, path, b, u)
+
+
+def test_update_velocity_default_draws_are_fresh_per_call_and_follow_the_reference():
+    """network.py:208-223: per episode and vehicle randrange(1,4): +0.55 (cap 2.77), -0.55
+    (floor 1.1) or keep.  Device draws (no `draws` given): every call draws anew - also when
+    the env never stepped in between (DriverLoop.end_episode, the TestEnv shim) - each outcome
+    has probability 1/3, and the same call sequence reproduces."""
+    cfg = bench_config(64, 32, 2000.0, mobility_vary=True)
+    B = 256
+
+    def run():
+        env = make_env(cfg, B)
+        env.reset_topology(seed=21)
+        vs = [env.export_state(tables=False)["vel"].clone()]
+        for _ in range(6):
+            env.update_velocity()
+            vs.append(env.export_state(tables=False)["vel"].clone())
+        return vs
+    vs, again = run(), run()
+    for a, b in zip(vs, again):
+        assert torch.equal(a, b)                                    # deterministic
+    assert torch.all(vs[0] == 1.7)                                  # mobility_vary start (network.py:105-108)
+    d1 = (vs[1] - vs[0])
+    frac = [float((d1 > 0.5).double().mean()), float((d1 < -0.5).double().mean()), float((d1 == 0).double().mean())]
+    assert all(abs(f - 1 / 3) < 0.02 for f in frac), frac
+    up1, up2 = (vs[1] - vs[0]) > 0.5, (vs[2] - vs[1]) > 0.5
+    # independent draws: P(up twice) = 1/9, not 1/3 (the round-1 bug repeated the first draw forever)
+    both = float((up1 & up2).double().mean())
+    assert abs(both - 1 / 9) < 0.02, both
+    for v in vs:
+        assert float(v.min()) >= 1.1 and float(v.max()) <= 2.77
+    assert len({float(v.double().mean()) for v in vs}) == len(vs)
+
+
+def test_device_draws_are_shard_invariant():
+    """DIRAL_OPT_ENV_OFFSET: two half-batches with offsets 0 and B/2 == one full batch, bit
+    for bit - topology, sampled actions, velocity draws, and therefore every output of a
+    rollout.  This is what makes the 8-GPU sharding of BASELINE.json configs[3] checkable
+    against a single-GPU run."""
+    cfg = bench_config(64, 32, 2000.0, mobility_vary=True)
+    B = 48
+    full = make_env(cfg, B)
+    lo = make_env(cfg, B // 2)
+    hi = make_env(cfg, B // 2)
+    hi.set_env_offset(B // 2)
+    for e in (full, lo, hi):
+        e.reset_topology(seed=77)
+
+    def cat(f):
+        return torch.cat([f(lo), f(hi)], dim=0)
+    x_init = full.export_state(tables=False)["pos_x"].clone()
+    assert torch.equal(full.export_state(tables=False)["pos_x"], cat(lambda e: e.export_state(tables=False)["pos_x"]))
+    assert torch.equal(full.export_state(tables=False)["vel"], cat(lambda e: e.export_state(tables=False)["vel"]))
+    for t in range(30):
+        a_full = full.sample(seed=1000 + t)
+        a_lo, a_hi = lo.sample(seed=1000 + t), hi.sample(seed=1000 + t)
+        assert torch.equal(a_full, torch.cat([a_lo, a_hi]))
+        o, r, d = full.step(a_full, t)
+        ol, rl, _ = lo.step(a_lo, t)
+        oh, rh, _ = hi.step(a_hi, t)
+        assert torch.equal(o, torch.cat([ol, oh])) and torch.equal(r, torch.cat([rl, rh])), t
+        if t % 10 == 9:
+            for e in (full, lo, hi):
+                e.update_velocity(seed=5 + t)
+    sf, sl, sh = full.export_state(), lo.export_state(), hi.export_state()
+    for k in ("pos_x", "vel", "seq", "age", "x"):
+        assert torch.equal(sf[k], torch.cat([sl[k], sh[k]])), k
+    assert torch.equal(full.metrics(), torch.cat([lo.metrics(), hi.metrics()]))
+    # a different offset is a different window on the same global sequence of envs
+    other = make_env(cfg, B // 2)
+    other.set_env_offset(7)
+    other.reset_topology(seed=77)
+    assert torch.equal(other.export_state(tables=False)["pos_x"], x_init[7:7 + B // 2])
+    assert not torch.equal(other.export_state(tables=False)["pos_x"], x_init[:B // 2])
+
+
+def test_c4_shard_sized_run_properties_and_sampled_oracle():
+    """BASELINE.json configs[3] is 262144 envs over 8 GPUs = 32768 envs per GPU.  One shard
+    (env offset of rank 5) on this GPU: size-independent properties on every env after 60
+    slots, and envs sampled across the batch bit-exact against the oracle fed the same device
+    draws."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(64, 32, 2000.0)
+    B, N, A, K = 32768, 64, 32, 20
+    env = make_env(cfg, B, dtype=torch.float32)
+    env.set_env_offset(5 * B)
+    env.reset_topology(seed=1234)
+    pick = np.array([0, 1, 777, 4095, 4096, 16383, 20000, 32767])
+    st0 = env.export_state(tables=False)
+    x0, v0 = st0["pos_x"].cpu().numpy()[pick], st0["vel"].cpu().numpy()[pick]
+    orc = Oracle(cfg, batch=len(pick), sq_mode=SQ_IEEE, threads=4)
+    orc.reset(x0, np.zeros_like(x0), v0)
+    T = 60
+    for t in range(T):
+        a = env.sample(seed=9000 + t)
+        obs, rew, done = env.step(a, t)
+        an = a.cpu().numpy()[pick]
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, an, t)
+        o_state = orc.obtain_state(an, o_chobs, o_rew)
+        if t % 7 == 0 or t == T - 1:
+            assert np.array_equal(obs[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_state.astype(np.float32)), t
+            assert np.array_equal(rew[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_rew.astype(np.float32)), t
+    assert env.last_kernel() == KERNEL_FAST64
+    # properties on all 32768 envs of the last slot
+    onehot = obs[:, :, :A]
+    assert torch.equal(onehot.argmax(-1).to(torch.int32), a) and torch.all(onehot.sum(-1) == 1)
+    hs = obs[:, :, A:].double().sum(-1)
+    assert torch.all((hs == 0) | ((hs - 1).abs() < 1e-6))
+    cnt = torch.zeros((B, A), dtype=torch.int32, device=a.device).scatter_add_(1, a.long(), torch.ones_like(a))
+    c = cnt.gather(1, a.long())
+    assert torch.all((rew == 1) == (c == 1))                   # alone on the resource <=> reward 1 (rd 2)
+    assert torch.all(rew[c > 2] == -c[c > 2].float())           # test_env.py:176-183
+    m = env.metrics()
+    assert torch.all(m[:, 0] == T) and torch.all(m[:, 2] + m[:, 3] == T * N)
+    assert bool(done.all()) == ((T - 1) % cfg.episode_interval == cfg.episode_interval - 1)
+    env.check()

@@ -6,7 +6,8 @@ the specialised kernels with configurations nobody wrote a dedicated test for.""
 import numpy as np
 import pytest
 
-from diral_amd.config import EnvConfig, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, bench_config
+from diral_amd.config import (ConfigError, EnvConfig, KERNEL_FAST64, KERNEL_GENERAL, KERNEL_WIDE, STEP_DESIGN,
+                              STEP_MY_STEP, STEP_MY_STEP_CH, bench_config)
 from tests.test_gpu_parity import random_rollout
 
 pytestmark = pytest.mark.gpu
@@ -41,12 +42,25 @@ def draw_case(i):
 @pytest.mark.parametrize("i", range(96))
 def test_random_configuration_vs_oracle(i):
     cfg, mode, sticky, vel_every = draw_case(i)
-    try:
-        cfg.validate()
-    except Exception:
-        pytest.skip("configuration rejected by validate() (the reference cannot run it either)")
+    if not (cfg.mobility or cfg.enable_design_topology):
+        # the ONLY rejection this generator can draw: no vehicles are built without mobility or the
+        # design topology (network.py:54-60).  Anything else validate() raises is a regression.
+        with pytest.raises(ConfigError, match="mobility"):
+            cfg.validate()
+        pytest.skip("no-mobility configuration: the reference builds no vehicles (network.py:54-60)")
+    cfg.validate()
     B = 4 if cfg.num_users > 64 else 12
-    random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8)
+    # the general kernel (PRR tracking in my_step, a build extension, keeps the run there) ...
+    random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
+                   expect_kernel=KERNEL_GENERAL)
+    # ... and whatever the dispatch picks without it: the RICH instantiations of step_fast64 /
+    # step_wide for the type-2 histogram observation with any cheap State flag and A <= 64
+    st = cfg.State
+    special = (st.add_positional_dist_piggy and st.add_positional_dist_type == 2 and not st.add_positional_dist
+               and not cfg.proportional_fair and cfg.num_channels <= 64)
+    want = (KERNEL_FAST64 if cfg.num_users <= 64 else KERNEL_WIDE) if special else KERNEL_GENERAL
+    random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
+                   track_prr=False, expect_kernel=want)
 
 
 def draw_fast_case(i):
@@ -107,3 +121,95 @@ def test_random_default_flag_configuration_on_the_specialised_kernels(i):
     assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
     assert np.array_equal(st["pos_x"].cpu().numpy(), oe["pos_x"])
     env.check()
+
+
+def draw_rich_case(i):
+    rng = np.random.default_rng(11000 + i)
+    N = int(rng.choice([1, 2, 7, 33, 63, 64, 65, 100, 128, 129, 200, 256]))
+    A = int(rng.choice([1, 3, 8, 31, 32, 33, 64]))
+    K = int(rng.choice([1, 2, 9, 20, 40, 64]))
+    if N > 128 and K > 40:
+        K = 40              # N > 128 with 64 bins exceeds the general kernel's 160 KB LDS budget (DIRAL_ERR_UNSUPPORTED)
+    mode = int(rng.choice([STEP_MY_STEP, STEP_MY_STEP, STEP_MY_STEP_CH, STEP_DESIGN]))
+    rd = int(rng.choice([2, 3, 4])) if mode == STEP_MY_STEP_CH else int(rng.integers(1, 6))
+    L = float(rng.choice([6.0, 15.0, 40.0]) * N + rng.integers(20, 300))
+    state = dict(type=int(rng.choice([1, 2])), add_reward=bool(rng.random() < 0.5), add_action=bool(rng.random() < 0.8),
+                 add_index=bool(rng.random() < 0.5), add_velocity=bool(rng.random() < 0.5),
+                 action_index=str(rng.choice(["binary", "real"])), add_position=bool(rng.random() < 0.5),
+                 add_channel_obs=bool(rng.random() < 0.6), num_bins=K)
+    cfg = bench_config(N, A, L, reward_design=rd, State=state, mobility_vary=bool(rng.random() < 0.5),
+                       enable_fingerprint=bool(rng.random() < 0.5), congestion_test=bool(rng.random() < 0.15),
+                       communication_range=float(rng.choice([40.0, 150.0, 250.0])),
+                       bin_range=float(rng.choice([200.0, 500.0])),
+                       track_arrival=bool(rng.random() < 0.3))
+    return cfg, mode, float(rng.choice([0.0, 0.7])), bool(rng.random() < 0.5), bool(N <= 64 and rng.random() < 0.3)
+
+
+@pytest.mark.parametrize("i", range(72))
+def test_random_rich_configuration_on_the_specialised_kernels(i):
+    """The RICH instantiations (csrc/rich_out.hpp): random cheap State flags (test_env.py:527-583),
+    State.type 1 / 2, every step kind, both output dtypes, vehicles on or off the y = 0 lane,
+    arrival stamps on or off - through BOTH call patterns: the fused `_step` with the channel
+    observation requested, and the reference's `obs, rews = env.my_step*(a, t)` +
+    `env.obtain_state(obs, a, rews, episode, eps)` (main_test.py:144-164), which must be served by
+    the same single launch.  State, channel observation and rewards against the oracle, bit for
+    bit (exp() rewards within the documented tolerance)."""
+    import torch
+    from oracle.oracle import Oracle, SQ_IEEE
+    from tests.test_gpu_parity import EXP_ATOL, make_env
+    cfg, mode, sticky, f64, offlane = draw_rich_case(i)
+    cfg.validate()
+    N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
+    B = 3 if N > 64 else 8
+    rng = np.random.default_rng(600 + i)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    y0 = rng.integers(0, 3, size=(B, N)).astype(np.float64) if offlane else np.zeros((B, N))
+    v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
+    dt = torch.float64 if f64 else torch.float32
+    fused, two = make_env(cfg, B, dtype=dt), make_env(cfg, B, dtype=dt)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    for e in (fused, two):
+        e.reset_topology(x0, y0, v0)
+    orc.reset(x0, y0, v0)
+    acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+    exp_rew = cfg.reward_design in (3, 4) and mode != STEP_DESIGN
+    fam = KERNEL_FAST64 if N <= 64 else KERNEL_WIDE
+    call = {STEP_MY_STEP: two.my_step, STEP_MY_STEP_CH: two.my_step_ch, STEP_DESIGN: two.my_step_design}[mode]
+
+    def same(got, want, exp_tol):
+        want = want if f64 else want.astype(np.float32)
+        if exp_tol:
+            return bool(np.all(np.abs(got.astype(np.float64) - want) <= (EXP_ATOL if f64 else 1e-6)))
+        return np.array_equal(got, want)
+
+    for t in range(24):
+        new = rng.integers(0, A, size=(B, N))
+        acts = np.where(rng.random((B, N)) < sticky, acts, new).astype(np.int32)
+        ep, eps = float(t // 5), 0.99 ** t
+        a_dev = fused._actions(acts)
+        obs, rew, _ = fused._step(mode, a_dev, t, ep, eps, want_chobs=True)
+        assert (fused.last_kernel() & 15) == fam, fused.last_kernel()
+        chobs2, rew2 = call(a_dev, t)
+        k2 = two.last_kernel()
+        st2 = two.obtain_state(chobs2, a_dev, rew2, ep, eps)
+        assert two.last_kernel() == k2 and (k2 & 15) == fam             # no second launch
+        o_rew, o_chobs = orc.step(mode, acts, t)
+        o_state = orc.obtain_state(acts, o_chobs, o_rew, ep, eps)
+        torch.cuda.synchronize()
+        assert same(rew.cpu().numpy(), o_rew, exp_rew) and same(rew2.cpu().numpy(), o_rew, exp_rew), t
+        assert same(fused._chobs.cpu().numpy(), o_chobs, False) and same(chobs2.cpu().numpy(), o_chobs, False), t
+        tol = exp_rew and cfg.State.add_reward
+        assert same(obs.cpu().numpy(), o_state, tol), (t, np.argwhere(obs.cpu().numpy() != (o_state if f64 else o_state.astype(np.float32)))[:5])
+        assert same(st2.cpu().numpy(), o_state, tol), t
+        if t % 9 == 8:
+            d = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
+            for e in (fused, two, orc):
+                e.update_velocity(d)
+    st, oe = fused.export_state(), orc.export()
+    assert np.array_equal(st["seq"].cpu().numpy(), oe["seq"])
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    assert np.array_equal(st["pos_x"].cpu().numpy(), oe["pos_x"])
+    if cfg.track_arrival:
+        assert np.array_equal(st["la"].cpu().numpy().astype(np.int64), oe["la"])
+    fused.check()
+    two.check()

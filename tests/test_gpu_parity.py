@@ -115,14 +115,17 @@ def test_golden_replay_on_gpu(name):
     env.check()
 
 
-def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8):
+def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8, track_prr=True,
+                   expect_kernel=None):
     """GPU vs oracle (IEEE squares) on B different random envs, T slots; returns
     the number of compared slots.  Everything must match bit for bit (exp()
-    rewards within EXP_ATOL)."""
+    rewards within EXP_ATOL).  track_prr (PRR metrics also in my_step, a build extension)
+    keeps the run on the general kernel; without it the specialised kernels serve every
+    configuration they can (`expect_kernel`: assert which family ran)."""
     from oracle.oracle import Oracle, SQ_IEEE
     rng = np.random.default_rng(seed)
     N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
-    cfg = cfg.replace(track_arrival=True, track_prr=True)
+    cfg = cfg.replace(track_arrival=True, track_prr=track_prr)
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
     y0 = np.zeros((B, N))
     v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
@@ -135,6 +138,8 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
         new = rng.integers(0, A, size=(B, N))
         acts = np.where(rng.random((B, N)) < sticky, acts, new).astype(np.int32)
         obs, rew, chobs, _ = gpu_step(env, mode, acts, t)
+        if expect_kernel is not None:
+            assert (env.last_kernel() & 15) == expect_kernel, env.last_kernel()
         o_rew, o_chobs = orc.step(mode, acts, t)
         o_state = orc.obtain_state(acts, o_chobs, o_rew)
         if uses_exp(cfg, mode):
@@ -161,12 +166,15 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
     assert np.array_equal(st["la"].astype(np.int64), oe["la"])
     assert np.array_equal(env.info_age(T - 1).cpu().numpy(), orc.info_age(T - 1))
     m, om = env.metrics().cpu().numpy(), orc.metrics()
-    assert np.array_equal(m[:, [0, 2, 3, 5]], om[:, [0, 2, 3, 5]])          # counts: exact
-    assert np.allclose(m[:, [1, 4]], om[:, [1, 4]], rtol=1e-12, atol=1e-9)  # float sums: order differs
-    # PRR parity (north_star: within 1e-6)
-    prr = m[:, 4] / np.maximum(m[:, 5], 1)
-    oprr = om[:, 4] / np.maximum(om[:, 5], 1)
-    assert np.max(np.abs(prr - oprr)) < 1e-6
+    assert np.array_equal(m[:, [0, 2, 3]], om[:, [0, 2, 3]])                # counts: exact
+    assert np.allclose(m[:, 1], om[:, 1], rtol=1e-12, atol=1e-9)            # float sums: order differs
+    if track_prr or mode == STEP_MY_STEP_CH:
+        assert np.array_equal(m[:, 5], om[:, 5])
+        assert np.allclose(m[:, 4], om[:, 4], rtol=1e-12, atol=1e-9)
+        # PRR parity (north_star: within 1e-6)
+        prr = m[:, 4] / np.maximum(m[:, 5], 1)
+        oprr = om[:, 4] / np.maximum(om[:, 5], 1)
+        assert np.max(np.abs(prr - oprr)) < 1e-6
     env.check()
     return T
 
@@ -367,19 +375,9 @@ def test_replica_envs_are_identical_at_scale():
 def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
     """The headline-config kernel (csrc/step_fast64.hpp, f32 and f64 outputs,
     default State flags) against the general kernel (f64 outputs, forced with
-    DIRAL_NO_FAST64) and the oracle: f64 states identical, f32 states equal to
+    DIRAL_OPT_KERNEL_PATH) and the oracle: f64 states identical, f32 states equal to
     their cast, rewards, positions and every table plane identical."""
-    import contextlib
-    import os
     from oracle.oracle import Oracle, SQ_IEEE
-
-    @contextlib.contextmanager
-    def general_kernel():
-        os.environ["DIRAL_NO_FAST64"] = "1"      # read at every launch (csrc/diral_env.hip)
-        try:
-            yield
-        finally:
-            del os.environ["DIRAL_NO_FAST64"]
 
     L = 100.0 if toy else 30.0 * N + 100
     cfg = bench_config(N, A, L, reward_design=rd, congestion_test=toy, State=dict(num_bins=K),
@@ -399,7 +397,7 @@ def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         of, rf, df = fast.step(a, t)
         o6, r6, d6 = fast64.step(a, t)
-        with general_kernel():
+        with _general_kernel(gen):
             og, rg, dg = gen.step(a, t)
         o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
         o_state = orc.obtain_state(a, o_chobs, o_rew)
@@ -505,35 +503,56 @@ def test_secondary_observation_modes_vs_oracle(N, A, full, ptype):
     random_rollout(cfg, B=5, T=26, seed=500 + N + ptype)
 
 
-def test_sps_policy_matches_scalar_restatement():
-    """the SPS baseline (algorithms/v2x_sps.py) on the device,
-    decision for decision against a scalar restatement fed the same draws."""
+@pytest.mark.parametrize("name", ["s1_sps_int_threshold", "s2_sps_frac_threshold", "s3_sps_small_window"])
+def test_sps_policy_matches_the_reference_fixtures(name):
+    """the SPS baseline on the device against fixtures recorded from the
+    reference's own algorithms/v2x_sps.py (tests/golden/gen_golden.py `sps`: one
+    SemiPersistentScheduling object per agent, its random.randint / random.random /
+    random.choice calls mocked with the recorded draws): action, reselection counter and
+    prev_action after every step, incl. stable-sort ties, repeated 3 dB threshold raises
+    and a non-integer threshold."""
+    import os
     from diral_amd.sps import SpsPolicy
-    from tests.sps_ref import SpsRef
-    B, N, A = 6, 20, 32
-    rng = np.random.default_rng(17)
-    pol = SpsPolicy(B, N, A, rssi_threshold=-110.0, seed=5)
-    torch.cuda.synchronize()
-    assert pol.prev_action.min() >= 0 and pol.prev_action.max() <= A - 1
-    assert pol.counter.min() >= 5 and pol.counter.max() <= 15
-    pa, cn = pol.prev_action.cpu().numpy().copy(), pol.counter.cpu().numpy().copy()
-    refs = [[SpsRef(pa[b, u], cn[b, u], -110.0) for u in range(N)] for b in range(B)]
-    changed = 0
-    for t in range(60):
-        # quantised RSSI so ties (stable sort) and threshold raises both occur
-        win = np.round(rng.uniform(-130, -95, size=(B, N, A)) / 2.0) * 2.0
-        dc = rng.integers(5, 17, size=(B, N)).astype(np.int32)
-        dk = rng.random((B, N))
-        dch = rng.integers(0, 1000, size=(B, N)).astype(np.int32)
-        got = pol.step(torch.as_tensor(win), dc, dk, dch).cpu().numpy()
-        for b in range(B):
-            for u in range(N):
-                before = refs[b][u].prev_action
-                want = refs[b][u].step(list(win[b, u]), int(dc[b, u]), float(dk[b, u]), int(dch[b, u]))
-                assert got[b, u] == want, (t, b, u)
-                changed += int(want != before)
-    assert changed > 10                                   # reselections really happened
-    assert np.array_equal(pol.counter.cpu().numpy(), [[r.reselection_counter for r in row] for row in refs])
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    A = int(g["A"])
+    T, n = g["actions"].shape
+    assert T * n >= 200 and int(g["reselections"]) >= 50
+    pol = SpsPolicy(1, n, A, rssi_threshold=float(g["threshold"]), seed=5)
+    pol.prev_action.copy_(torch.as_tensor(g["init_prev"]).view(1, n))
+    pol.counter.copy_(torch.as_tensor(g["init_counter"]).view(1, n))
+    step = float(g["tie_step"])
+    for t in range(T):
+        win = torch.as_tensor(g["codes"][t].astype(np.float64) * step).view(1, n, A)
+        got = pol.step(win, g["draw_counter"][t], g["draw_keep"][t], g["draw_choice"][t]).cpu().numpy()[0]
+        assert np.array_equal(got, g["actions"][t]), (t, np.argwhere(got != g["actions"][t])[:4])
+        assert np.array_equal(pol.counter.cpu().numpy()[0], g["counters"][t]), t
+        assert np.array_equal(pol.prev_action.cpu().numpy()[0], g["prev_actions"][t]), t
+
+
+def test_sps_device_draws_follow_the_reference_distributions():
+    """The un-injected branches of diral_sps_init / diral_sps_step (device RNG): initial
+    prev_action in [0, window], counters in [5, 15], new counters in [5, 16], keep
+    probability 0.8 (v2x_sps.py:14-15, 91-93)."""
+    from diral_amd.sps import SpsPolicy
+    B, N, A = 64, 64, 16
+    pol = SpsPolicy(B, N, A, rssi_threshold=-110.0, seed=11)
+    pa, cn = pol.prev_action.cpu().numpy(), pol.counter.cpu().numpy()
+    assert pa.min() == 0 and pa.max() == A - 1 and cn.min() == 5 and cn.max() == 15
+    assert abs(cn.mean() - 10.0) < 0.2
+    win = torch.full((B, N, A), -150.0, dtype=torch.float64, device="cuda:0")   # everything free
+    resel = expired = 0
+    seen = set()
+    for t in range(40):
+        before_c, before_a = pol.counter.clone(), pol.prev_action.clone()
+        pol.step(win)
+        exp = (before_c == 0)
+        expired += int(exp.sum())
+        resel += int((exp & (pol.prev_action != before_a)).sum())
+        seen |= set(pol.counter[exp].cpu().numpy().tolist())
+    assert expired > 5000 and seen == set(range(5, 17))
+    # a re-selection picks among max(1, ceil(min(A/5, len(sA)))) = 4 best of 15 others: it differs from
+    # the previous action always (prev is excluded), so the changed fraction IS the 20 %
+    assert abs(resel / expired - 0.2) < 0.03, resel / expired
 
 
 def test_sps_policy_drives_the_env():
@@ -725,21 +744,18 @@ def test_example_rollout_script_runs():
         assert "collision fraction" in out.stdout
 
 
-def _general_kernel():
-    """Context manager: force the general step_kernel (csrc/diral_env.hip reads the
-    variables at every launch)."""
+def _general_kernel(env):
+    """Context manager: this env's steps run on the general step_kernel
+    (DIRAL_OPT_KERNEL_PATH, include/diral_env.h)."""
     import contextlib
-    import os
 
     @contextlib.contextmanager
     def cm():
-        os.environ["DIRAL_NO_FAST64"] = "1"
-        os.environ["DIRAL_NO_WIDE"] = "1"
+        env.force_general_kernel(True)
         try:
             yield
         finally:
-            del os.environ["DIRAL_NO_FAST64"]
-            del os.environ["DIRAL_NO_WIDE"]
+            env.force_general_kernel(False)
     return cm()
 
 
@@ -769,7 +785,7 @@ def test_wide_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         o3, r3, d3 = w32.step(a, t)
         o6, r6, d6 = w64.step(a, t)
-        with _general_kernel():
+        with _general_kernel(gen):
             og, rg, dg = gen.step(a, t)
         o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
         o_state = orc.obtain_state(a, o_chobs, o_rew)
@@ -869,7 +885,7 @@ def test_fast_paths_run_my_step_ch_like_the_general_kernel_and_the_oracle(N, A, 
         prev = a
         o3, r3, _ = f32.step(a, t)
         o6, r6, d6 = f64.step(a, t)
-        with _general_kernel():
+        with _general_kernel(gen):
             og, rg, dg = gen.step(a, t)
         o_rew, o_chobs = orc.step(STEP_MY_STEP_CH, a, t)
         o_state = orc.obtain_state(a, o_chobs, o_rew)
@@ -957,7 +973,7 @@ def test_specialised_kernels_run_my_step_design_like_the_general_kernel_and_the_
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         o3, r3, _ = f32.step(a, t)
         o6, r6, d6 = f64.step(a, t)
-        with _general_kernel():
+        with _general_kernel(gen):
             og, rg, dg = gen.step(a, t)
         o_rew, o_chobs = orc.step(STEP_DESIGN, a, t)
         o_state = orc.obtain_state(a, o_chobs, o_rew)
@@ -998,7 +1014,7 @@ def test_arrival_stamps_and_information_age_on_the_specialised_kernels(N, A, mod
     for t in range(20):
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         obs, rew, _ = env.step(a, t)
-        with _general_kernel():
+        with _general_kernel(gen):
             og, rg, _ = gen.step(a, t)
         o_rew, o_chobs = orc.step(mode, a, t)
         ia, iag, oia = env.info_age(t), gen.info_age(t), orc.info_age(t)
@@ -1067,28 +1083,88 @@ def test_reference_fixtures_replayed_on_the_specialised_kernels(name):
     env.check()
 
 
-@pytest.mark.parametrize("N,A,B", [(64, 32, 2048), (256, 64, 2048), (128, 64, 4096)])
-def test_default_flag_configurations_are_served_by_the_specialised_kernels(N, A, B):
-    """Dispatch guard: with the toy YAML's State flags `step` must run on step_fast64 /
-    step_wide.  They are 2x+ faster than the general kernel, so a silent fall-back shows
-    as a missing gap between the normal path and the forced general path."""
+@pytest.mark.parametrize("N,A", [(64, 32), (256, 64), (128, 64), (40, 7), (200, 33)])
+def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A):
+    """Dispatch guard (exact: `diral_env_last_kernel`).  step_fast64 / step_wide must serve
+    * `step` with the toy YAML's State flags on the PLAIN instantiation,
+    * the reference's own call pattern `obs, rews = env.my_step*(a, t)` (channel observation
+      requested) and every cheap State flag on a RICH instantiation,
+    and the obtain_state that follows my_step* must not launch anything."""
+    from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RICH, KERNEL_WIDE)
+    fam = KERNEL_FAST64 if N <= 64 else KERNEL_WIDE
+    L = 2000.0 if N <= 64 else 4000.0
+    B = 16
+    cfg = bench_config(N, A, L)
+    env = make_env(cfg, B, dtype=torch.float32)
+    env.reset_topology(seed=3)
+    a = env.sample(seed=1)
+    env.step(a, 0)
+    assert env.last_kernel() == fam                                     # plain
+    chobs, rew = env.my_step(a, 1)
+    assert env.last_kernel() == fam | KERNEL_RICH
+    k = env.last_kernel()
+    st = env.obtain_state(chobs, a, rew)                                  # served by the fused launch
+    assert env.last_kernel() == k and st is env._obs
+    env.my_step_ch(a, 2)
+    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_CH
+    env.my_step_design(a, 0)
+    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_EXTRA
+    env.force_general_kernel(True)
+    env.step(a, 3)
+    assert env.last_kernel() == KERNEL_GENERAL
+    env.check()
+    # every cheap State flag at once (the g1_flags_all shape) + State.type 1 + arrival stamps
+    flags = dict(add_reward=True, add_index=True, add_velocity=True, add_position=True, add_channel_obs=True)
+    for state, extra, want in ((flags, dict(enable_fingerprint=True), fam | KERNEL_RICH),
+                               (dict(action_index="real", add_channel_obs=True), {}, fam | KERNEL_RICH),
+                               (dict(add_action=False), {}, fam | KERNEL_RICH),
+                               (flags, dict(track_arrival=True), fam | KERNEL_RICH | KERNEL_EXTRA)):
+        c2 = bench_config(N, A, L, State=state, **extra)
+        e2 = make_env(c2, B, dtype=torch.float64)
+        e2.reset_topology(seed=4)
+        e2.step(e2.sample(seed=2), 0)
+        assert e2.last_kernel() == want, (state, extra, e2.last_kernel())
+        e2.check()
+    # what stays on the general kernel
+    for state, extra in ((dict(add_positional_dist=True), {}), (dict(add_positional_dist_type=1), {}),
+                         ({}, dict(proportional_fair=True)), (dict(add_positional_dist_piggy=False), {})):
+        c3 = bench_config(N, A, L, State=state, **extra)
+        e3 = make_env(c3, 4, dtype=torch.float64)
+        e3.reset_topology(seed=5)
+        e3.step(e3.sample(seed=2), 0)
+        assert e3.last_kernel() == KERNEL_GENERAL, (state, extra)
+
+
+@pytest.mark.parametrize("N,A,B", [(64, 32, 2048), (256, 64, 1024), (128, 64, 2048)])
+def test_specialised_kernels_are_faster_than_the_general_kernel(N, A, B):
+    """The point of the dispatch: plain `step` and the reference call pattern (my_step with the
+    channel observation + obtain_state) both run well ahead of the general kernel."""
     import time
     cfg = bench_config(N, A, 2000.0 if N <= 64 else 4000.0)
 
-    def run(force_general):
+    def run(force_general, two_call):
         env = make_env(cfg, B, dtype=torch.float32)
         env.reset_topology(seed=3)
+        env.force_general_kernel(force_general)
         acts = [env.sample(seed=i) for i in range(4)]
-        ctx = _general_kernel() if force_general else __import__("contextlib").nullcontext()
-        with ctx:
-            for t in range(40):
-                env.step(acts[t % 4], t)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for t in range(40, 140):
-                env.step(acts[t % 4], t)
-            torch.cuda.synchronize()
-            return time.perf_counter() - t0
 
-    fast, general = min(run(False), run(False)), min(run(True), run(True))
+        def slot(t):
+            if two_call:
+                chobs, rew = env.my_step(acts[t % 4], t)
+                env.obtain_state(chobs, acts[t % 4], rew)
+            else:
+                env.step(acts[t % 4], t)
+        for t in range(40):
+            slot(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(40, 140):
+            slot(t)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    fast, general = min(run(False, False), run(False, False)), min(run(True, False), run(True, False))
     assert general > 1.4 * fast, (fast, general)
+    fast2, general2 = min(run(False, True), run(False, True)), min(run(True, True), run(True, True))
+    assert general2 > 1.4 * fast2, (fast2, general2)
+    assert fast2 < 1.35 * fast, (fast, fast2)       # the channel-observation output costs little
