@@ -14,9 +14,10 @@ One process per GPU; envs are independent so ranks share nothing on the step
 path (weak scaling: B per GPU fixed); RCCL is used once, to all-reduce the
 episode metrics.  Rank 0 prints ONE JSON line.
 
-Timed region: after the reset every run first plays PREROLL untimed slots (SURVEY
-8d: >= 50, past the ghost-entry / table-filling phase of the first 19 slots, Q4),
-then the W warm-up slots it was asked for, then exactly K timed slots between
+Timed region: after the reset every run first plays untimed pre-roll slots (at least
+PREROLL = 60, SURVEY 8d: >= 50, past the ghost-entry / table-filling phase of the first
+19 slots, Q4; and at least PREROLL_SECONDS, so that a GPU coming out of idle has reached
+its clocks), then the W warm-up slots it was asked for, then exactly K timed slots between
 barrier + synchronize pairs.  The kernel's own duration is measured with HIP events
 on the launch stream over the same K launches.
 """
@@ -52,6 +53,7 @@ WORKLOADS = {
     "c4shard": (64, 32, 2000.0, 32768, False),   # configs[3]: the per-GPU share of 262144 envs over 8 GPUs
 }
 PREROLL = 60      # untimed slots after every reset, before the requested warm-up (>= 50)
+PREROLL_SECONDS = 0.3   # ... and at least this long: a GPU coming out of idle needs tens of ms to reach its clocks
 GLOBAL_SEED = 1234
 
 
@@ -221,7 +223,14 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
             env.update_velocity(seed=t)      # main_test.py:226-233 (no-op unless mobility_vary)
 
     t = 0
-    for _ in range(PREROLL + warmup):
+    t_pre = time.perf_counter()
+    while t < PREROLL or time.perf_counter() - t_pre < PREROLL_SECONDS:
+        for _ in range(20):
+            one_step(t)
+            t += 1
+        torch.cuda.synchronize(device)
+    preroll = t
+    for _ in range(warmup):
         one_step(t)
         t += 1
     torch.cuda.synchronize(device)
@@ -259,6 +268,7 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         "algorithmic_bytes_per_launch": bytes_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
         "layout_bytes_per_launch": layout_launch,
         "layout_rate_GBps": layout_launch / (kernel_ms * 1e-3) / 1e9,
+        "preroll_slots": preroll,
     }
     return env, res
 
@@ -342,7 +352,7 @@ def main() -> int:
                                 cfg.State.num_bins, args.step_mode, " + channel observation" if emit else "",
                                 "iid-uniform" if args.sticky == 0 else "sticky(p=%.2f)" % args.sticky, args.out_dtype),
                 "batch_per_gpu": B, "num_users": N, "num_channels": A, "state_space": cfg.state_space,
-                "emit_chobs": emit, "preroll_slots": PREROLL,
+                "emit_chobs": emit, "preroll_slots": res["preroll_slots"],
                 "parallelism": "env-shard x%d (no data-path collective; one global seed, rank r = envs [r*B, (r+1)*B))" % world,
             },
             "roofline": {

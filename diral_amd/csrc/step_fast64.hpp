@@ -68,13 +68,13 @@ struct FastParams {
 };
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, total;
+  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, stage, total;
 };
-// row stride of the gather-source table in words: 64 viewers + 1, so that the output phase of
-// the RICH instantiations (lane -> (viewer, resource quad)) reads it without bank conflicts;
-// the merge (lane = viewer) is conflict-free at any stride
-constexpr int kFastMtabStride = 65;
-__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich) {
+// row stride (elements) of the channel-observation staging array [vehicle][resource] of the RICH
+// instantiations: odd, so that both the column writes of P1 (lane = vehicle) and the row reads of
+// the write-out (lane = (vehicle, resource quad)) are free of bank conflicts
+__host__ __device__ constexpr int fast_stage_stride(int A) { return (A <= 32 ? 32 : 64) + 1; }
+__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64) {
   FastLds l;
   uint32_t o = 0;
   const uint32_t a32 = A <= 32 ? 32u : 64u;
@@ -84,15 +84,18 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich) {
   l.act = o;   o += 4u * 64;
   l.hist = o;  o += 4u * (K | 1) * 64;
   l.cnt = o;   o += 4u * 64;
-  l.mtab = o;  o += 4u * kFastMtabStride * a32;   // [resource][vehicle] gather source lane * 4 (bpermute address)
+  // [resource][vehicle] gather source lane * 4 (bpermute address): words, or bytes (<= 252) in the
+  // RICH instantiations, which need the room for the staging array
+  l.mtab = o;  o += (rich ? 1u : 4u) * 64 * a32;
   l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
   l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
-  l.px = l.py = l.npx = l.rew = o;
+  l.px = l.py = l.npx = l.rew = l.stage = o;
   if (rich) {                               // RICH output tail (rich_out.hpp): per-vehicle values by index
     l.px = o;  o += 8u * 64;
     l.py = o;  o += 8u * 64;
     l.npx = o; o += 8u * 64;
     l.rew = o; o += 8u * 64;
+    l.stage = o; o += (out64 ? 8u : 4u) * 64 * fast_stage_stride(A);   // channel observation [vehicle][resource]
   }
   l.total = align_up(o, 16);
   return l;
@@ -216,21 +219,25 @@ __device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided
 template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const FastLds lay = fast_lds_layout(p.K, p.A, RICH);
+  const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
   int* s_act = reinterpret_cast<int*>(smem + lay.act);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
-  int* s_mtab = reinterpret_cast<int*>(smem + lay.mtab);
+  typedef typename std::conditional<RICH, unsigned char, int>::type mtab_t;
+  typedef typename std::conditional<OUT64, double, float>::type out_t;
+  mtab_t* s_mtab = reinterpret_cast<mtab_t*>(smem + lay.mtab);
+  out_t* s_stage = reinterpret_cast<out_t*>(smem + lay.stage);   // RICH only
   double* s_rtx = reinterpret_cast<double*>(smem + lay.rtx);
   int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
   double* s_px = reinterpret_cast<double*>(smem + lay.px);       // RICH only
   double* s_py = reinterpret_cast<double*>(smem + lay.py);
   double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
   double* s_rew = reinterpret_cast<double*>(smem + lay.rew);
-  constexpr int MT = kFastMtabStride;
+  constexpr int MT = 64;                                         // gather-source table row stride (elements)
+  const int SA = fast_stage_stride(p.A);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 
   // ---- P1: per owned resource i = wave + 4*s: transmitter set, closest in-range
   // transmitter per vehicle, gather sources, collision reward ----------------------
+  const bool dist_obs = RICH && !CH && !(EXTRA && p.design) && r.state_type == 2;
 #pragma unroll 1
   for (int i = wave; i < A; i += 4) {
     const unsigned long long mk = __ballot(myact == i);     // tx set (test_env.py:153-157)
@@ -320,6 +328,17 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
+    if constexpr (RICH) {
+      if (r.chobs_out) {
+        // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432): 0 on the own
+        // resource or an unused one; my_step with State.type 2: the distance to the closest in-range
+        // transmitter, 100000 (network.py:385) when none is in range; otherwise the constant 1.
+        // Straight from the registers of the search into the staging array (lane = row); rows leave
+        // coalesced after the barrier.
+        const double ob = (myact == i || c == 0) ? 0.0 : (dist_obs ? best : 1.0);
+        s_stage[lane * SA + i] = (out_t)ob;
+      }
+    }
     if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
     if (CH) {
       if (c > 1) {
@@ -396,6 +415,31 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
     }
     if (live) p.pos_x[bN + lane] = mynpx;
+  }
+  if constexpr (RICH) {
+    if (r.chobs_out) {
+      // channel observation [N][A] of this env, 16 bytes per lane, consecutive lanes on consecutive
+      // pieces of a row (streaming: nothing on the chip reads it back); overlaps P3 of the other waves
+      constexpr int CV = OUT64 ? 2 : 4;
+      out_t* const co = static_cast<out_t*>(r.chobs_out) + bN * A;
+      if ((A % CV) == 0) {
+        const int qpr = A / CV, total = N * qpr;
+        const int du = 256 / qpr, dq = 256 - du * qpr;
+        int u = tid / qpr, qr = tid - u * qpr;
+        for (int q = tid; q < total; q += 256) {
+          const out_t* src = s_stage + u * SA + qr * CV;
+          if constexpr (OUT64) stream_store2(co + 2 * q, make_double2(src[0], src[1]));
+          else stream_store4(co + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
+          u += du; qr += dq;
+          if (qr >= qpr) { qr -= qpr; u += 1; }
+        }
+      } else {
+        for (int e = tid; e < N * A; e += 256) {
+          const int u = e / A;
+          stream_store(co + e, s_stage[u * SA + (e - u * A)]);
+        }
+      }
+    }
   }
   DIRAL_FSTAMP(3);
 
@@ -562,11 +606,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
   // divided by the neighbour count) or float32 (= the float32 cast of that value).
   if constexpr (RICH) {
-    // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432), rebuilt
-    // from the gather sources: 0 on the own resource or an unused one; my_step with State.type 2:
-    // the distance to the closest in-range transmitter (the same expression P1 evaluated), 100000
-    // (network.py:385) when none is in range; every other step kind / State.type 1: the constant 1
-    const bool dist_obs = !CH && !(EXTRA && p.design) && r.state_type == 2;
+    // the channel-observation SECTION of the state vector (State.add_channel_obs): the same
+    // values P1 stored to chobs_out, rebuilt from the gather sources (the same distance
+    // expression P1 evaluated)
     auto chv = [&](int u, int i) -> double {
       if (s_act[u] == i || s_mask[i] == 0ull) return 0.0;
       if (!dist_obs) return 1.0;
@@ -574,7 +616,6 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (src == u) return 100000.0;
       return fast_dist<FLAT>(s_px[src], FLAT ? 0.0 : s_py[src], s_px[u], FLAT ? 0.0 : s_py[u]);
     };
-    if (r.chobs_out) rich_write_chobs<OUT64>(r.chobs_out, bN, N, A, tid, 256, chv);
     if (p.state_out && !r.plain_state) {
       rich_write_state<OUT64>(
           r, p.flags, N, A, K, p.L, p.state_out, bN, tid, 256, [&](int u) { return s_act[u]; }, chv,

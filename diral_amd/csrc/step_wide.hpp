@@ -737,17 +737,40 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   if constexpr (RICH) {
     // `obs[user][i]` of the reference step, rebuilt from the gather sources (see step_fast64.hpp)
     const bool dist_obs = !CH && !(EXTRA && p.design) && r.state_type == 2;
-    auto chv = [&](int u, int i) -> double {
-      unsigned long long any = 0ull;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) any |= s_mask[i * VPL + j];
-      if (s_act[u] == i || any == 0ull) return 0.0;
+    // (`actw`: the wave-uniform word of resources with a transmitter, built before P3)
+    auto chv_row = [&](int u, int a, double xu, int i) -> double {
+      if (a == i || ((actw >> i) & 1ull) == 0ull) return 0.0;
       if (!dist_obs) return 1.0;
       const int src = (int)(((unsigned int)s_mtab[i * MT + (u & 63)] >> (8 * (u >> 6))) & 255u);
       if (src == u) return 100000.0;                                          // network.py:385
-      return fast_dist<true>(s_px[src], 0.0, s_px[u], 0.0);
+      return fast_dist<true>(s_px[src], 0.0, xu, 0.0);
     };
-    if (r.chobs_out) rich_write_chobs<OUT64>(r.chobs_out, bN, N, A, tid, THREADS, chv);
+    auto chv = [&](int u, int i) -> double { return chv_row(u, s_act[u], s_px[u], i); };
+    if (r.chobs_out) {
+      // 16 bytes per lane, consecutive lanes on consecutive pieces of a row; the per-row values
+      // (action, position) are loaded once per piece
+      constexpr int CV = OUT64 ? 2 : 4;
+      typedef typename std::conditional<OUT64, double, float>::type out_t;
+      out_t* const co = static_cast<out_t*>(r.chobs_out) + bN * A;
+      if ((A % CV) == 0) {
+        const int qpr = A / CV, total = N * qpr;
+        for (int q = tid; q < total; q += THREADS) {
+          const int u = q / qpr, i0 = (q - u * qpr) * CV;
+          const int a = s_act[u];
+          const double xu = s_px[u];
+          if constexpr (OUT64)
+            stream_store2(co + 2 * q, make_double2(chv_row(u, a, xu, i0), chv_row(u, a, xu, i0 + 1)));
+          else
+            stream_store4(co + 4 * q, make_float4((float)chv_row(u, a, xu, i0), (float)chv_row(u, a, xu, i0 + 1),
+                                                  (float)chv_row(u, a, xu, i0 + 2), (float)chv_row(u, a, xu, i0 + 3)));
+        }
+      } else {
+        for (int e = tid; e < N * A; e += THREADS) {
+          const int u = e / A;
+          stream_store(co + e, (out_t)chv(u, e - u * A));
+        }
+      }
+    }
     if (p.state_out && !r.plain_state) {
       // the reward column is read back from rew_out (written in P2 by this workgroup, two
       // barriers ago; the host dispatches here only with rew_out set when the column exists):
