@@ -87,20 +87,60 @@ __device__ inline void max_u8x16(unsigned int (&a)[4], const unsigned int (&b)[4
 #undef DIRAL_SDWA_MAX
 }
 
-// byte j of the packed gather-source word, times 4 (the LDS byte address of that
-// viewer's rank word), one SDWA shift each instead of extract + shift
-template <int VPL>
-__device__ inline void unpack_src_x4(unsigned int mw, unsigned int (&a)[VPL]) {
+// ... and of eight packed words (32 ranks)
+__device__ inline void max_u8x32(unsigned int (&a)[8], const unsigned int (&b)[8]) {
+#define DIRAL_SDWA_MAX8(B)                                                                                          \
+  "v_max_u32_sdwa %0, %0, %8 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %1, %1, %9 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %2, %2, %10 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %3, %3, %11 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %4, %4, %12 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %5, %5, %13 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %6, %6, %14 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t" \
+  "v_max_u32_sdwa %7, %7, %15 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:BYTE_" #B "\n\t"
+  asm(DIRAL_SDWA_MAX8(0) DIRAL_SDWA_MAX8(1) DIRAL_SDWA_MAX8(2) DIRAL_SDWA_MAX8(3) "s_nop 0"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+      : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+#undef DIRAL_SDWA_MAX8
+}
+template <int NK>
+__device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&b)[NK]) {
+  if constexpr (NK == 4) max_u8x16(a, b);
+  else max_u8x32(a, b);
+}
+
+// LDS byte address of a __shared__ object (what M0-relative DS instructions take)
+__device__ inline unsigned int lds_addr(const void* p) {
+  return (unsigned int)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// Four lane-linear words (word q to base + 256 q + 4 lane) with ds_write_addtid_b32: the address
+// comes from M0 + immediate + 4 * lane, so no address VGPR travels to the LDS - 2 cycles per
+// wave-instruction against 4 of ds_write_b32 (MI355X_MICROARCH.md, LDS).  M0 is saved and
+// restored inside the statement (compiler-reserved); the stores are ordered behind earlier DS
+// operations of the wave like any other (in-order LDS queue).
+__device__ inline void lds_store4_lane_linear(unsigned int base, const unsigned int (&w)[4]) {
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+               "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
+               "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "s"(base) : "memory");
+}
+
+// byte j of the packed gather-source word, shifted left by SH (the LDS byte offset of that
+// viewer's rank words), one SDWA shift each instead of extract + shift
+template <int VPL, unsigned int SH>
+__device__ inline void unpack_src(unsigned int mw, unsigned int (&a)[VPL]) {
   if constexpr (VPL == 4) {
     asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
         "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
         "v_lshlrev_b32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
         "v_lshlrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "s"(2u), "v"(mw));
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "s"(SH), "v"(mw));
   } else {
     asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
         "v_lshlrev_b32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
-        : "=&v"(a[0]), "=&v"(a[1]) : "s"(2u), "v"(mw));
+        : "=&v"(a[0]), "=&v"(a[1]) : "s"(SH), "v"(mw));
   }
 }
 
@@ -188,6 +228,24 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #ifndef DIRAL_WIDE_FIN_UNROLL2
 #define DIRAL_WIDE_FIN_UNROLL2 8         // finalize column loop, N <= 128 (8 columns per pass): fully unrolled
 #endif
+#ifndef DIRAL_WIDE_ADDTID
+#define DIRAL_WIDE_ADDTID 1              // lane-linear write-back of the merge words with ds_write_addtid_b32 (no address VGPR: half the LDS store cycles)
+#endif
+#ifndef DIRAL_WIDE_PC2
+#define DIRAL_WIDE_PC2 8                 // subject columns per merge pass, N <= 128
+#endif
+#ifndef DIRAL_WIDE_PC4
+#define DIRAL_WIDE_PC4 4                 // subject columns per merge pass, N <= 256
+#endif
+#ifndef DIRAL_WIDE_RELOAD2
+#define DIRAL_WIDE_RELOAD2 0             // N <= 128: see DIRAL_WIDE_RELOAD4
+#endif
+#ifndef DIRAL_WIDE_RELOAD4
+#define DIRAL_WIDE_RELOAD4 0             // finalize re-reads the table word (L2 / Infinity Cache) instead of carrying old rank + age through the merge in registers
+#endif
+#ifndef DIRAL_WIDE_VEC2
+#define DIRAL_WIDE_VEC2 1                // N <= 128 at 8 columns per pass: one 8-byte gather per slot instead of two 4-byte ones (C5 -2 %)
+#endif
 #ifndef DIRAL_WIDE_FIN_UNROLL4
 #define DIRAL_WIDE_FIN_UNROLL4 2         // N <= 256 (4 columns per pass): by two (64-VGPR budget; measured 3.42 / 3.60 / 4.00 ms for 2 / 1 / 4)
 #endif
@@ -201,8 +259,14 @@ template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p, const RichParams r) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
-  constexpr int PC = 16 / VPL;                 // subject columns per pass
-  constexpr int NW = PC / 4;                   // packed rank words per viewer slot; NW * VPL == 4
+  constexpr int PC = VPL == 2 ? DIRAL_WIDE_PC2 : DIRAL_WIDE_PC4;   // subject columns per pass
+  constexpr int NW = PC / 4;                   // packed rank words (4 columns each) per viewer slot
+  constexpr int NK = NW * VPL;                 // ... per lane
+  // merge words in LDS: plane layout [word][viewer] with 4-byte gathers (NK == 4 only), or one
+  // NW-word vector per viewer gathered with ONE 8/16-byte read
+  constexpr bool VEC = (NK != 4) || (VPL == 2 ? (DIRAL_WIDE_VEC2 != 0) : false);
+  constexpr bool RELOAD = VPL == 2 ? (DIRAL_WIDE_RELOAD2 != 0) : (DIRAL_WIDE_RELOAD4 != 0);
+  static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= 2048, "a pass's rank words fill at most the wave's 2 KB of scratch");
   constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
   constexpr int MT = wide_mtab_stride(VPL);    // gather-source table row stride (elements)
   // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
@@ -418,6 +482,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // ---- P3: stamp + gossip merge + xpos + histogram over this wave's 16 columns ---
   unsigned int* const sw = reinterpret_cast<unsigned int*>(smem + lay.scratch + 2048u * wave);   // merge words
   double* const xt = reinterpret_cast<double*>(sw);                                             // rank -> xpos
+  const unsigned int sw_lds = __builtin_amdgcn_readfirstlane(lds_addr(sw));
   const double inv_w = p.inv_w;
 
   // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
@@ -476,10 +541,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (diral_env_create) - and is masked.
   const unsigned int ul = (unsigned int)lane;
   // byte c of the packed per-slot words (c wave-uniform, possibly dynamic)
-  auto pick = [&](const unsigned int (&arr)[4], int j, int c) -> unsigned int {
-    unsigned int w = arr[j];
-    if constexpr (NW == 2) w = (c & 4) ? arr[VPL + j] : w;
-    return (w >> (8 * (c & 3))) & 255u;
+  // (the column loops below are nests word w (static) x column cc within the word)
+  auto pick = [&](const unsigned int (&arr)[NK], int j, int w, int cc) -> unsigned int {
+    return (arr[w * VPL + j] >> (8 * cc)) & 255u;
   };
 
   bool ovf = false;
@@ -492,27 +556,32 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     DIRAL_WCLOCK(tc0);
     // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
     //    own fresh sequence number
-    unsigned int wraw[PC * VPL];
+    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 ranks each; ages, same packing
 #pragma unroll
-    for (int c = 0; c < PC; ++c) {
-      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c) * NV);   // rows are padded to 16: in bounds
+    for (int q = 0; q < NK; ++q) { kp[q] = 0u; agew[q] = 0u; }
+    unsigned int tkov = 0u;                      // lane c: column c's fresh sequence number of its subject
+    bool bad = false;
+    // (16 table words in flight at a time: LC columns x VPL slots)
+    constexpr int LC = 16 / VPL;
+#pragma unroll
+    for (int c0 = 0; c0 < PC; c0 += LC) {
+    unsigned int wraw[LC * VPL];
+#pragma unroll
+    for (int c = 0; c < LC; ++c) {
+      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c0 + c) * NV);   // rows are padded to 16: in bounds
 #pragma unroll
       for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
     }
     __builtin_amdgcn_sched_barrier(0);
-    unsigned int kp[4] = {0u, 0u, 0u, 0u};       // [word * VPL + slot]: 4 ranks each
-    unsigned int agew[4] = {0u, 0u, 0u, 0u};     // ages, same packing
-    unsigned int tkov = 0u;                      // lane c: column c's fresh sequence number of its subject
-    bool bad = false;
 #pragma unroll
-    for (int c = 0; c < PC; ++c) {
+    for (int c = c0; c < c0 + LC; ++c) {
       const int k = kbase + c;
       const bool kval = FULL || k < N;
       unsigned int seq[VPL], age[VPL];
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
         const int u = lane + 64 * j;
-        const unsigned int w = (FULL || (kval && u < N)) ? wraw[c * VPL + j] : 0u;
+        const unsigned int w = (FULL || (kval && u < N)) ? wraw[(c - c0) * VPL + j] : 0u;
         seq[j] = w >> 8;
         const unsigned int a0 = w & 255u;
         age[j] = a0 + (a0 < 255u ? 1u : 0u);
@@ -536,47 +605,93 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         bad = bad || (lag >= 255u && seq[j] != 0u);
         const unsigned int rank = lag < 255u ? 255u - lag : 0u;
         kp[(c >> 2) * VPL + j] |= rank << (8 * (c & 3));
-        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
+        if constexpr (!RELOAD) agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     }
     const bool packed_ok = (__ballot(bad) == 0ull);
     DIRAL_WCLOCK(tc1);
 
     if (packed_ok) {
-      unsigned int kp0[4];                       // the ranks before the merge
+      unsigned int kp0[NK];                      // the ranks before the merge
 #pragma unroll
-      for (int q = 0; q < 4; ++q) kp0[q] = kp[q];
+      for (int q = 0; q < NK; ++q) kp0[q] = RELOAD ? 0u : kp[q];
       // -- Vehicle.received_update for every (resource, rx), resources ascending:
-      //    rank[u] = max(rank[u], rank[m_i(u)]) for 4 columns per word
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
-      wave_lds_order();
-      unsigned long long rem = actw;
-      unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-      while (rem) {
-        rem &= rem - 1;
-        const unsigned int mw = m_next;
-        if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-        unsigned int v[4], sa[VPL];
-        unpack_src_x4<VPL>(mw, sa);
-        const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-#pragma unroll
-          for (int w = 0; w < NW; ++w)
-            v[w * VPL + j] = *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
-        }
-        // a transmitter's words are not written during its own resource, so all
-        // gathers of a step may precede all its writes
-        wave_lds_order();
-        max_u8x16(kp, v);
+      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
+      if constexpr (!VEC) {
+        // plane layout sw[word][viewer]: one 4-byte gather per word and slot
 #pragma unroll
         for (int w = 0; w < NW; ++w)
 #pragma unroll
           for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
         wave_lds_order();
+        unsigned long long rem = actw;
+        unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+        while (rem) {
+          rem &= rem - 1;
+          const unsigned int mw = m_next;
+          if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+          unsigned int v[NK], sa[VPL];
+          unpack_src<VPL, 2u>(mw, sa);
+          const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+              v[w * VPL + j] = *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
+          }
+          // a transmitter's words are not written during its own resource, so all
+          // gathers of a step may precede all its writes
+          wave_lds_order();
+          max_u8_words<NK>(kp, v);
+#if DIRAL_WIDE_ADDTID
+          lds_store4_lane_linear(sw_lds, kp);     // sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
+#else
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+#endif
+          wave_lds_order();
+        }
+      } else {
+        // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
+        // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
+        // wider pass halves the number of chains a wave walks per column.
+        typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
+        uvec* const sv = reinterpret_cast<uvec*>(sw);
+        auto put = [&]() {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            uvec t;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
+            sv[lane + 64 * j] = t;
+          }
+        };
+        put();
+        wave_lds_order();
+        unsigned long long rem = actw;
+        unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+        while (rem) {
+          rem &= rem - 1;
+          const unsigned int mw = m_next;
+          if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+          unsigned int v[NK], sa[VPL];
+          unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
+          const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const uvec g = *reinterpret_cast<const uvec*>(swb + sa[j]);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
+          }
+          wave_lds_order();
+          max_u8_words<NK>(kp, v);
+          put();
+          wave_lds_order();
+        }
       }
       DIRAL_WCLOCK(tc2);
 
@@ -589,8 +704,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
         for (int j = 0; j < VPL; ++j) x_next[j] = txrow0[ul + 64u * j];
       }
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
 #pragma unroll FIN_UNROLL
-      for (int c = 0; c < PC; ++c) {
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * w + cc;
         const int k = kbase + c;
         const bool kvalid = FULL || k < N;
         const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
@@ -600,7 +718,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         if constexpr (XPRE) {
 #pragma unroll
           for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
-          if (c + 1 < PC) {                                      // static: the column loop is fully unrolled
+          if (w + 1 < NW || cc < 3) {                            // static where the column loop is fully unrolled
             const global_ptr<const double> txn = uniform_ptr<const double>(p.tx, (bR + k + 1) * NV);
 #pragma unroll
             for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
@@ -610,23 +728,44 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           for (int j = 0; j < VPL; ++j) x_cur[j] = txrow[ul + 64u * j];
         }
         const double pxk = s_px[kvalid ? k : 0];
-        unsigned int rank0[VPL];
+        unsigned int rank0[VPL], age0[VPL];
+        if constexpr (RELOAD) {
+          // old rank and age of the entry from the table word itself (re-read: L2 / Infinity Cache)
+          unsigned int wr[VPL];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) wr[j] = tkrow[ul + 64u * j];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            const unsigned int wv = (FULL || (kvalid && u < N)) ? wr[j] : 0u;
+            unsigned int sq = wv >> 8;
+            const unsigned int a0 = wv & 255u;
+            age0[j] = a0 + (a0 < 255u ? 1u : 0u);
+            if (j == (k >> 6)) {
+              const bool own = kvalid && (lane == (k & 63));
+              sq += own ? 1u : 0u;
+              age0[j] = own ? 0u : age0[j];
+            }
+            const unsigned int lag = tk_own - sq;
+            rank0[j] = lag < 255u ? 255u - lag : 0u;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
-          rank0[j] = pick(kp0, j, c);
+          if constexpr (!RELOAD) rank0[j] = pick(kp0, j, w, cc);
           if (j == (k >> 6)) x_cur[j] = (lane == (k & 63)) ? pxk : x_cur[j];   // own stamp (vehicle.py:63), uniform slot
           if (FULL || u < N) xt[rank0[j]] = x_cur[j];
         }
         wave_lds_order();
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-          const unsigned int rf = pick(kp, j, c);
+          const unsigned int rf = pick(kp, j, w, cc);
           const double xr = xt[rf];
           const bool upd = rf != rank0[j];
           const double xg = upd ? xr : x_cur[j];
           const unsigned int seqf = rf ? tk_own - 255u + rf : 0u;
-          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, c));
+          const unsigned int wn = (seqf << 8) | (upd ? 0u : (RELOAD ? age0[j] : pick(agew, j, w, cc)));
           emit(k, kvalid, j, upd, wn, xg, tkrow, txrow);
         }
         wave_lds_order();
