@@ -168,3 +168,33 @@ def test_oracle_under_sanitizers():
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
     assert "san_check ok" in out.stdout
+
+
+def test_fixtures_carry_the_keys_the_generator_writes():
+    """tests/golden/gen_golden.py and the committed .npz files stay in step: every env
+    fixture has the full key set of run_case / run_driver_case, every SPS fixture that of
+    run_sps_case (recorded from algorithms/v2x_sps.py)."""
+    import glob
+    import os
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    case_keys = {"cfg", "x0", "y0", "v0", "modes", "actions", "tsteps", "vel_update_steps", "vel_update_draws",
+                 "episode_eps", "state_space", "table_sha", "trace", "trace_after", "rews", "chobs", "state", "pos_x",
+                 "vel", "ia", "tab_step", "tab_seq", "tab_age", "tab_x", "tab_y", "tab_la"}
+    sps_keys = {"A", "threshold", "tie_step", "init_prev", "init_counter", "codes", "draw_counter", "draw_keep",
+                "draw_choice", "actions", "counters", "prev_actions", "reselections"}
+    names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(gdir, "*.npz")))
+    assert len([n for n in names if n[0] == "g"]) == 33 and len([n for n in names if n[0] == "s"]) == 3
+    for n in names:
+        keys = set(np.load(os.path.join(gdir, n + ".npz")).files)
+        if n[0] == "g":
+            assert keys == case_keys, (n, keys ^ case_keys)
+        elif n[0] == "s":
+            assert keys == sps_keys, (n, keys ^ sps_keys)
+            g = np.load(os.path.join(gdir, n + ".npz"))
+            A = int(g["A"])
+            assert g["actions"].min() >= 0 and g["actions"].max() < A and g["counters"].min() >= 0
+            assert g["counters"].max() <= 16 and int(g["reselections"]) >= 50
+            # a kept resource repeats the previous action (v2x_sps.py:85-96)
+            same = g["actions"][1:] == g["prev_actions"][:-1]
+            changed = g["prev_actions"][1:] != g["prev_actions"][:-1]
+            assert np.all(same | changed)
