@@ -22,6 +22,7 @@ SYMBOLS = [
     "diral_env_sample", "diral_env_info_age", "diral_env_export_state", "diral_env_import_state",
     "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error", "diral_sps_step", "diral_sps_init",
     "diral_env_set_trace", "diral_env_set_option", "diral_env_last_kernel",
+    "diral_sps_window_from_chobs", "diral_sps_step_chobs",
 ]
 
 _lib = None
@@ -75,6 +76,8 @@ def load() -> ctypes.CDLL:
         "diral_env_set_trace": (I, [P, P, I, I, P]),
         "diral_env_set_option": (I, [P, I, I64]),
         "diral_env_last_kernel": (I, [P]),
+        "diral_sps_window_from_chobs": (I, [I, I, P, I, P, P, P]),
+        "diral_sps_step_chobs": (I, [I, I, P, I, P, P, P, D, D, D, P, P, P, U64, P, P]),
     }
     for name in SYMBOLS:
         try:

@@ -128,9 +128,51 @@ __global__ void sps_init_kernel(int agents, int window, uint64_t seed, int32_t* 
   counter[i] = 5 + (int32_t)(rng_u64(seed, 6, (uint64_t)i) % 11ull);                     // randint(5, 15)
 }
 
-// SemiPersistentScheduling.step + choose_new_resource (algorithms/v2x_sps.py:76-104,
-// 24-74); one thread per agent.  Reselection is rare (counter expiry x 20 %), so
-// the O(A^2) stable rank selection only runs for a few lanes.
+// SemiPersistentScheduling.choose_new_resource (algorithms/v2x_sps.py:24-74) for one agent;
+// `w(s)` is its selection window.  O(A^2) stable rank selection: re-selection is rare (counter
+// expiry x 20 %), so only a few lanes run it.
+template <typename W>
+__device__ inline int sps_choose(W w, int A, int prev, double threshold, double inc_db, unsigned int r) {
+  const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
+  double thr_next = threshold, thr = threshold;
+  int n_sa = 0;
+  for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
+    thr = thr_next;                                                // the threshold THIS sA is built with
+    n_sa = 0;
+    for (int s = 0; s < A; ++s) n_sa += (s != prev && w(s) < thr) ? 1 : 0;
+    thr_next = thr + inc_db;                                       // tmp_threshold += self.inc_dB
+    if (!((double)n_sa < min_sA)) break;
+  }
+  const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
+  int need = (int)min_len;
+  if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
+  if (need < 1) need = 1;
+  const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
+  int chosen = prev;
+  for (int s = 0; s < A; ++s) {                                    // sorted(sA.items(), key=value): stable
+    const double ws = w(s);
+    if (s == prev || !(ws < thr)) continue;
+    int rank = 0;
+    for (int q = 0; q < A; ++q) {
+      const double wq = w(q);
+      if (q == prev || !(wq < thr)) continue;
+      rank += (wq < ws || (wq == ws && q < s)) ? 1 : 0;
+    }
+    if (rank == pick) chosen = s;
+  }
+  return chosen;
+}
+
+// SemiPersistentScheduling.step (algorithms/v2x_sps.py:76-104); one thread per agent.
+// Returns true when the agent has to choose a new resource (then `cnt` is already redrawn).
+__device__ inline bool sps_advance(int i, int& cnt, double keep_prob, const int32_t* draw_counter,
+                                   const double* draw_keep, uint64_t seed) {
+  if (cnt != 0) { cnt -= 1; return false; }                        // v2x_sps.py:85-89
+  cnt = draw_counter ? draw_counter[i] : 5 + (int)(rng_u64(seed, 7, (uint64_t)i) % 12ull);   // randint(5, 16)
+  const double u = draw_keep ? draw_keep[i] : rng_unit(rng_u64(seed, 8, (uint64_t)i));
+  return !(u < keep_prob);                                         // v2x_sps.py:93-98
+}
+
 __global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* prev_action, int32_t* counter,
                                 double threshold, double inc_db, double keep_prob, const int32_t* draw_counter,
                                 const double* draw_keep, const int32_t* draw_choice, uint64_t seed,
@@ -139,44 +181,59 @@ __global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* p
   if (i >= agents) return;
   int action = prev_action[i];
   int cnt = counter[i];
-  if (cnt != 0) {                                                      // v2x_sps.py:85-89
-    cnt -= 1;
-  } else {
-    cnt = draw_counter ? draw_counter[i] : 5 + (int)(rng_u64(seed, 7, (uint64_t)i) % 12ull);   // randint(5, 16)
-    const double u = draw_keep ? draw_keep[i] : rng_unit(rng_u64(seed, 8, (uint64_t)i));
-    if (!(u < keep_prob)) {                                            // v2x_sps.py:93-98
-      const double* w = win + (size_t)i * A;
-      const int prev = action;
-      const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
-      double thr_next = threshold, thr = threshold;
-      int n_sa = 0;
-      for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
-        thr = thr_next;                                                // the threshold THIS sA is built with
-        n_sa = 0;
-        for (int s = 0; s < A; ++s) n_sa += (s != prev && w[s] < thr) ? 1 : 0;
-        thr_next = thr + inc_db;                                       // tmp_threshold += self.inc_dB
-        if (!((double)n_sa < min_sA)) break;
-      }
-      const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
-      int need = (int)min_len;
-      if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
-      if (need < 1) need = 1;
-      const unsigned int r = draw_choice ? (unsigned int)draw_choice[i]
-                                         : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
-      const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
-      int chosen = prev;
-      for (int s = 0; s < A; ++s) {                                    // sorted(sA.items(), key=value): stable
-        if (s == prev || !(w[s] < thr)) continue;
-        int rank = 0;
-        for (int q = 0; q < A; ++q) {
-          if (q == prev || !(w[q] < thr)) continue;
-          rank += (w[q] < w[s] || (w[q] == w[s] && q < s)) ? 1 : 0;
-        }
-        if (rank == pick) chosen = s;
-      }
-      action = chosen;
-      prev_action[i] = action;                                         // v2x_sps.py:98
-    }
+  if (sps_advance(i, cnt, keep_prob, draw_counter, draw_keep, seed)) {
+    const double* w = win + (size_t)i * A;
+    const unsigned int r = draw_choice ? (unsigned int)draw_choice[i]
+                                       : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
+    action = sps_choose([&](int s) { return w[s]; }, A, action, threshold, inc_db, r);
+    prev_action[i] = action;                                           // v2x_sps.py:98
+  }
+  counter[i] = cnt;
+  actions_out[i] = action;
+}
+
+// Build extension (the reference never wires SPS to the toy env): an RSSI-like selection window
+// from the toy env's type-2 channel observation `obs[user][i]` (test_env.py:206, 240,
+// network.py:385): distance d to the nearest in-range transmitter -> log-distance path loss
+// -40 - 30 log10(max(d, 1)) dB; 100000 (busy, nobody in range) -> -160; 0 (idle) -> -200; the
+// agent's own resource reads as busy (-60).  Lower = quieter.
+__device__ inline double sps_rssi_from_chobs(double d, bool own) {
+  if (own) return -60.0;
+  if (d >= 100000.0) return -160.0;
+  if (d > 0.0) return -40.0 - 30.0 * log10(d < 1.0 ? 1.0 : d);
+  return -200.0;
+}
+
+template <typename T>
+__global__ void sps_window_kernel(size_t total, int A, const T* chobs, const int32_t* actions, double* win) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t i = e / A;
+  win[e] = sps_rssi_from_chobs((double)chobs[e], (int)(e - i * A) == actions[i]);
+}
+
+constexpr int kSpsFusedMaxA = 64;
+
+// The two steps above in one launch: the window is only built (in private memory) by the few agents
+// that re-select this slot - no [agents][A] float64 array, no log10 for everybody.
+template <typename T>
+__global__ void sps_step_chobs_kernel(int agents, int A, const T* chobs, const int32_t* actions_in,
+                                      int32_t* prev_action, int32_t* counter, double threshold, double inc_db,
+                                      double keep_prob, const int32_t* draw_counter, const double* draw_keep,
+                                      const int32_t* draw_choice, uint64_t seed, int32_t* actions_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= agents) return;
+  int action = prev_action[i];
+  int cnt = counter[i];
+  if (sps_advance(i, cnt, keep_prob, draw_counter, draw_keep, seed)) {
+    double wl[kSpsFusedMaxA];
+    const T* row = chobs + (size_t)i * A;
+    const int own = actions_in[i];
+    for (int s = 0; s < A; ++s) wl[s] = sps_rssi_from_chobs((double)row[s], s == own);
+    const unsigned int r = draw_choice ? (unsigned int)draw_choice[i]
+                                       : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
+    action = sps_choose([&](int s) { return wl[s]; }, A, action, threshold, inc_db, r);
+    prev_action[i] = action;
   }
   counter[i] = cnt;
   actions_out[i] = action;

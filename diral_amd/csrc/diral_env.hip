@@ -610,6 +610,40 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 
+int diral_sps_window_from_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype,
+                                const int32_t* actions, double* window_out, void* stream) {
+  if (agents < 1 || num_channels < 1 || !chobs || !actions || !window_out) return DIRAL_ERR_BAD_ARG;
+  if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  const size_t total = (size_t)agents * num_channels;
+  if (chobs_dtype == DIRAL_F64)
+    hipLaunchKernelGGL(sps_window_kernel<double>, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       num_channels, static_cast<const double*>(chobs), actions, window_out);
+  else
+    hipLaunchKernelGGL(sps_window_kernel<float>, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       num_channels, static_cast<const float*>(chobs), actions, window_out);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
+int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
+                         int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
+                         double keep_prob, const int32_t* draw_counter, const double* draw_keep,
+                         const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream) {
+  if (agents < 1 || num_channels < 1 || !chobs || !actions || !prev_action || !counter || !actions_out)
+    return DIRAL_ERR_BAD_ARG;
+  if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  if (num_channels > kSpsFusedMaxA) return DIRAL_ERR_UNSUPPORTED;   // use window_from_chobs + sps_step
+  const dim3 g(blocks((size_t)agents, 128)), t(128);
+  if (chobs_dtype == DIRAL_F64)
+    hipLaunchKernelGGL(sps_step_chobs_kernel<double>, g, t, 0, (hipStream_t)stream, agents, num_channels,
+                       static_cast<const double*>(chobs), actions, prev_action, counter, rssi_threshold, inc_db,
+                       keep_prob, draw_counter, draw_keep, draw_choice, seed, actions_out);
+  else
+    hipLaunchKernelGGL(sps_step_chobs_kernel<float>, g, t, 0, (hipStream_t)stream, agents, num_channels,
+                       static_cast<const float*>(chobs), actions, prev_action, counter, rssi_threshold, inc_db,
+                       keep_prob, draw_counter, draw_keep, draw_choice, seed, actions_out);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
 int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32_t* counter, uint64_t seed,
                    void* stream) {
   if (agents < 1 || selection_window < 0 || !prev_action || !counter) return DIRAL_ERR_BAD_ARG;

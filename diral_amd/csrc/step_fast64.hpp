@@ -71,10 +71,12 @@ struct FastLds {
   uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, stage, total;
 };
 // row stride (elements) of the channel-observation staging array [vehicle][resource] of the RICH
-// instantiations: odd, so that both the column writes of P1 (lane = vehicle) and the row reads of
-// the write-out (lane = (vehicle, resource quad)) are free of bank conflicts
-__host__ __device__ constexpr int fast_stage_stride(int A) { return (A <= 32 ? 32 : 64) + 1; }
-__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64) {
+// instantiations: a multiple of 4 elements, so that the write-out reads a 16-byte piece of a row
+// with ONE ds_read_b128 (f32) / ds_read_b128 of two doubles; the 4 extra elements skew the rows
+// over the banks (the column writes of P1, lane = vehicle, then conflict 4-way: 8 cheap writes
+// per wave)
+__host__ __device__ constexpr int fast_stage_stride(int A) { return (A <= 32 ? 32 : 64) + 4; }
+__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64, bool flat) {
   FastLds l;
   uint32_t o = 0;
   const uint32_t a32 = A <= 32 ? 32u : 64u;
@@ -92,9 +94,10 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
   l.px = l.py = l.npx = l.rew = l.stage = o;
   if (rich) {                               // RICH output tail (rich_out.hpp): per-vehicle values by index
     l.px = o;  o += 8u * 64;
-    l.py = o;  o += 8u * 64;
+    l.py = o;  o += flat ? 0u : 8u * 64;    // every pos_y == 0: not staged (keeps 8 workgroups per CU at A <= 32)
     l.npx = o; o += 8u * 64;
     l.rew = o; o += 8u * 64;
+    o = align_up(o, 16);
     l.stage = o; o += (out64 ? 8u : 4u) * 64 * fast_stage_stride(A);   // channel observation [vehicle][resource]
   }
   l.total = align_up(o, 16);
@@ -219,7 +222,7 @@ __device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided
 template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64);
+  const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64, FLAT);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
@@ -286,7 +289,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   }
   if (wave == 0) {
     s_act[lane] = myact; s_cnt[lane] = 0u;
-    if constexpr (RICH) { s_px[lane] = mypx; s_py[lane] = mypy; s_npx[lane] = mynpx; s_rew[lane] = 0.0; }
+    if constexpr (RICH) {
+      s_px[lane] = mypx; s_npx[lane] = mynpx; s_rew[lane] = 0.0;
+      if constexpr (!FLAT) s_py[lane] = mypy;
+    }
   }
   for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = my_edge;                 // K <= 64 < 256 threads
@@ -427,9 +433,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const int du = 256 / qpr, dq = 256 - du * qpr;
         int u = tid / qpr, qr = tid - u * qpr;
         for (int q = tid; q < total; q += 256) {
-          const out_t* src = s_stage + u * SA + qr * CV;
-          if constexpr (OUT64) stream_store2(co + 2 * q, make_double2(src[0], src[1]));
-          else stream_store4(co + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
+          const out_t* src = s_stage + u * SA + qr * CV;        // 16-byte aligned: SA % 4 == 0
+          if constexpr (OUT64) stream_store2(co + 2 * q, *reinterpret_cast<const double2*>(src));
+          else stream_store4(co + 4 * q, *reinterpret_cast<const float4*>(src));
           u += du; qr += dq;
           if (qr >= qpr) { qr -= qpr; u += 1; }
         }

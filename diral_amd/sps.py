@@ -70,12 +70,55 @@ class SpsPolicy:
         return out
 
 
+    def _draws(self, draw_counter, draw_keep, draw_choice):
+        def opt(t, dt):
+            return None if t is None else torch.as_tensor(t, dtype=dt, device=self.device).reshape(self.B, self.N).contiguous()
+        return opt(draw_counter, torch.int32), opt(draw_keep, torch.float64), opt(draw_choice, torch.int32)
+
+    def window_from_chobs(self, chobs: torch.Tensor, actions: torch.Tensor) -> torch.Tensor:
+        """`diral_sps_window_from_chobs`: the RSSI-like window [B, N, A] float64 from the env's channel
+        observation (float32 or float64) and the actions that produced it (build extension, see
+        include/diral_env.h)."""
+        c = chobs.contiguous()
+        a = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((self.B, self.N, self.A), dtype=torch.float64, device=self.device)
+        st = self.lib.diral_sps_window_from_chobs(self.B * self.N, self.A, _ptr(c), 1 if c.dtype == torch.float64 else 0,
+                                                  _ptr(a), _ptr(out), self._stream())
+        if st != 0:
+            raise DiralError(st, "diral_sps_window_from_chobs")
+        return out
+
+    def step_from_chobs(self, chobs: torch.Tensor, actions: torch.Tensor, draw_counter=None, draw_keep=None,
+                        draw_choice=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One SPS step straight from the env's channel observation [B, N, A] (float32 / float64) and
+        the actions of the slot that produced it: `window_from_chobs` + `step` in ONE launch, with the
+        window built only by the agents that re-select (`diral_sps_step_chobs`).  A <= 64."""
+        if chobs.dtype not in (torch.float32, torch.float64) or tuple(chobs.shape) != (self.B, self.N, self.A):
+            raise ValueError("chobs must be float32/float64 [B, N, A]")
+        c = chobs.contiguous()
+        a = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
+        dc, dk, dch = self._draws(draw_counter, draw_keep, draw_choice)
+        self._t += 1
+        st = self.lib.diral_sps_step_chobs(self.B * self.N, self.A, _ptr(c), 1 if c.dtype == torch.float64 else 0, _ptr(a),
+                                           _ptr(self.prev_action), _ptr(self.counter), self.threshold, self.inc_db,
+                                           self.keep_prob, _ptr(dc), _ptr(dk), _ptr(dch),
+                                           (int(self.seed) * 1000003 + self._t) & (2**64 - 1), _ptr(out), self._stream())
+        if st != 0:
+            raise DiralError(st, "diral_sps_step_chobs")
+        self._keep = (c, a, dc, dk, dch)
+        return out
+
+
 def rssi_from_channel_obs(chobs: torch.Tensor, actions: torch.Tensor) -> torch.Tensor:
     """Build extension: an RSSI-like selection window from the toy env's type-2
     channel observation (`obs[user][i]` = distance to the nearest in-range
     transmitter, 100000 if all are out of range, 0 if nobody transmitted or the
     agent transmitted there itself; test_env.py:206, 240, network.py:385).
-    Log-distance path loss, lower = quieter; the agent's own resource reads as busy."""
+    Log-distance path loss, lower = quieter; the agent's own resource reads as busy.
+    (Plain-torch statement of `diral_sps_window_from_chobs`; `SpsPolicy.step_from_chobs` is the
+    fused device path.)"""
     d = chobs.to(torch.float64)
     rssi = torch.full_like(d, -200.0)                                   # idle resource
     heard = (d > 0) & (d < 100000.0)

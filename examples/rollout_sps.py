@@ -19,7 +19,7 @@ from diral_amd import c2_config  # noqa: E402
 from diral_amd.driver import DriverLoop  # noqa: E402
 from diral_amd.metrics import gather_metrics  # noqa: E402
 from diral_amd.shard import make_sharded_env, rank_world  # noqa: E402
-from diral_amd.sps import SpsPolicy, rssi_from_channel_obs  # noqa: E402
+from diral_amd.sps import SpsPolicy  # noqa: E402
 
 
 def main():
@@ -47,7 +47,7 @@ def main():
         out = loop.slot(actions, t)                   # one fused env launch + reward shaping
         state = out["next_state"]                     # what a learning agent would consume
         if args.policy == "sps":
-            actions = pol.step(rssi_from_channel_obs(env._chobs, actions))
+            actions = pol.step_from_chobs(env._chobs, actions)      # window + SPS decision in one launch
         else:
             actions = env.sample(seed=t)
         if out["episode_end"]:

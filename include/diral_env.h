@@ -289,6 +289,24 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
                    const int32_t* draw_counter, const double* draw_keep, const int32_t* draw_choice,
                    uint64_t seed, int32_t* actions_out, void* stream);
 
+/* Build extension - the reference never wires its SPS agent to the toy env, so the map from
+ * the env's channel observation to the "averaged RSSI" window SPS consumes is this build's:
+ * window[a][i] = -60 on the agent's own resource (actions[a] == i); else from
+ * d = chobs[a][i] (test_env.py:206, 240; network.py:385): d >= 100000 (busy, nobody in
+ * range) -> -160; d > 0 -> -40 - 30 log10(max(d, 1)) (log-distance path loss, dB);
+ * d == 0 (idle) -> -200.  chobs [agents][A] of `chobs_dtype`, window_out [agents][A] f64. */
+int diral_sps_window_from_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype,
+                                const int32_t* actions, double* window_out, void* stream);
+
+/* diral_sps_window_from_chobs + diral_sps_step in ONE launch (same decisions, bit for bit):
+ * only the agents that re-select this slot build their window, in private memory.
+ * num_channels <= 64, else DIRAL_ERR_UNSUPPORTED (use the two calls). */
+int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype,
+                         const int32_t* actions, int32_t* prev_action, int32_t* counter,
+                         double rssi_threshold, double inc_db, double keep_prob,
+                         const int32_t* draw_counter, const double* draw_keep,
+                         const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream);
+
 /* Replaces SemiPersistentScheduling.__init__ (v2x_sps.py:8-22): prev_action =
  * randint(0, selection_window) (inclusive, as in the reference), counter =
  * randint(5, 15); device RNG from `seed`. */

@@ -5,7 +5,7 @@ TAG=${1:-t}; shift || true
 R=$PWD; OUT=$R/gpurun_out/traffic_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o $c -- \
-    python $R/bench.py --steps 10 --warmup 30 --no-cpu-baseline "$@" > $OUT/$c.log 2>&1
+    python $R/bench.py --steps 40 --warmup 0 --lean "$@" > $OUT/$c.log 2>&1
 done
 cd $R
 python - "$OUT" <<'PY'

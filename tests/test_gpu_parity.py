@@ -555,6 +555,40 @@ def test_sps_device_draws_follow_the_reference_distributions():
     assert abs(resel / expired - 0.2) < 0.03, resel / expired
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_sps_from_channel_obs_fused_equals_two_step_path(dtype):
+    """`diral_sps_step_chobs` (window + decision in one launch, window built only by re-selecting
+    agents) == `diral_sps_window_from_chobs` + `diral_sps_step` with the same draws, decision for
+    decision; and the device window is the documented formula (rssi_from_channel_obs in torch)."""
+    from diral_amd.sps import SpsPolicy, rssi_from_channel_obs
+    cfg = bench_config(64, 32, 2000.0)
+    B, N, A = 16, 64, 32
+    env = make_env(cfg, B, dtype=dtype)
+    env.reset_topology(seed=12)
+    fused, two = SpsPolicy(B, N, A, seed=4), SpsPolicy(B, N, A, seed=4)
+    assert torch.equal(fused.prev_action, two.prev_action) and torch.equal(fused.counter, two.counter)
+    acts = fused.prev_action.clone()
+    rng = np.random.default_rng(5)
+    nres = 0
+    for t in range(120):
+        chobs, _ = env.my_step(acts, t)
+        win = two.window_from_chobs(chobs, acts)
+        ref = rssi_from_channel_obs(chobs, acts)
+        assert torch.allclose(win, ref, rtol=0, atol=1e-9), t
+        assert torch.equal(win == -60.0, ref == -60.0) and torch.equal(win == -200.0, ref == -200.0)
+        dc = rng.integers(5, 17, size=(B, N)).astype(np.int32)
+        dk = rng.random((B, N))
+        dch = rng.integers(0, 1 << 20, size=(B, N)).astype(np.int32)
+        a1 = fused.step_from_chobs(chobs, acts, dc, dk, dch)
+        a2 = two.step(win, dc, dk, dch)
+        assert torch.equal(a1, a2), t
+        assert torch.equal(fused.counter, two.counter) and torch.equal(fused.prev_action, two.prev_action), t
+        nres += int((a1 != acts).sum())
+        acts = a1
+    assert nres > 200                                    # re-selections really happened
+    env.check()
+
+
 def test_sps_policy_drives_the_env():
     """SPS closes the loop on the device: env channel obs -> RSSI-like window ->
     actions, no host round trip; collisions drop well below the uniform-random level."""
@@ -567,7 +601,7 @@ def test_sps_policy_drives_the_env():
     acts = pol.prev_action.clone()
     for t in range(150):
         env._step(STEP_MY_STEP, acts, t, want_chobs=True)
-        acts = pol.step(rssi_from_channel_obs(env._chobs, acts))
+        acts = pol.step_from_chobs(env._chobs, acts)
         if t == 99:
             env.metrics(clear=True)
     m = env.metrics().sum(0)
