@@ -330,7 +330,9 @@ def main() -> int:
 
     if rank == 0:
         N, A, B, L = res["N"], res["A"], res["B"], res["L"]
-        tr = load_traffic(args.workload if args.batch in (0, WORKLOADS[args.workload][3]) else "")
+        tkey = args.workload + ("" if emit else "_nochobs")
+        tr = load_traffic(tkey if (args.batch in (0, WORKLOADS[args.workload][3]) and args.out_dtype == "f32"
+                                   and args.step_mode == "my_step" and args.sticky == 0) else "")
         traffic = tr.get("hbm_bytes_per_launch") if tr else None
         line = {
             "metric": "agent-steps/sec (envs x vehicles), %d-UE/%d-res batched env" % (N, A),

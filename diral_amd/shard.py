@@ -35,5 +35,9 @@ def make_sharded_env(cfg, total_envs: int, **kw):
     from .vec_env import VecV2VEnv
     rank, local_rank, world = rank_world()
     start, count = env_shard(total_envs, rank, world)
+    # the shard's global env offset: device draws (topology, sample, velocity) are a function of
+    # (seed, global env index), so every rank can use the SAME seed and the job draws what one
+    # handle holding all `total_envs` envs would draw
+    kw.setdefault("env_offset", start)
     env = VecV2VEnv(cfg, batch=count, device=torch.device("cuda", local_rank), **kw)
     return env, start

@@ -35,7 +35,7 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cfg = c2_config()
     env, start = make_sharded_env(cfg, args.envs, out_dtype=torch.float32)
-    env.reset_topology(seed=1234 + start)
+    env.reset_topology(seed=1234)                     # one global seed: the shard offset selects the envs
     loop = DriverLoop(env, global_reward_avg=True, episode_interval=cfg.episode_interval,
                       fused=args.fused and args.policy == "random")
     pol = SpsPolicy(env.B, env.N, env.A, device=env.device, seed=start)
