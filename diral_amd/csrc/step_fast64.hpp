@@ -47,6 +47,7 @@ struct FastParams {
   uint32_t flags;
   int reward_design, age_limit, episode_interval;
   int design;                    // 1: my_step_design (test_env.py:269-349) - runtime switch of the non-CH instantiation
+  int done_now;                  // t % episode_interval == episode_interval - 1 (main_test.py:226), evaluated on the host
   double L, Rc, Rb, inv_w;
   long long t;
   const int32_t* actions;
@@ -66,6 +67,32 @@ struct FastParams {
   uint8_t* done_out;
   unsigned long long* dbg;
 };
+
+// Late-bound kernel arguments.  The compiler hoists the scalar loads of EVERY by-value kernel
+// argument to the kernel entry and then keeps (or spills, through v_writelane / v_readlane - VALU
+// instructions inside the hot loops) the SGPRs of values only the last phases use: output
+// pointers, section offsets.  Reading such fields through the kernarg segment pointer behind an
+// opaque asm pins their s_load to the point of use instead (measured on the RICH instantiation:
+// 63 -> see profiles/r02/resource_usage.txt SGPR spills).
+struct RichParams;
+typedef const __attribute__((address_space(4))) FastParams* LateFastArgs;
+__device__ inline unsigned long long late_kernarg_base() {
+  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return a;
+}
+// byte offset of the second kernel argument (RichParams) in the kernarg segment
+constexpr unsigned long long kRichArgOffset = (sizeof(FastParams) + alignof(RichParams) - 1) / alignof(RichParams) * alignof(RichParams);
+typedef const __attribute__((address_space(4))) RichParams* LateRichArgs;
+__device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
+  const LateRichArgs a = (LateRichArgs)(kernarg_base + kRichArgOffset);
+  RichParams r;
+  r.chobs_out = a->chobs_out; r.S = a->S; r.state_type = a->state_type; r.plain_state = a->plain_state;
+  r.off_act = a->off_act; r.off_chobs = a->off_chobs; r.off_hist = a->off_hist; r.off_rew = a->off_rew;
+  r.off_idx = a->off_idx; r.off_pos = a->off_pos; r.off_vel = a->off_vel; r.off_fp = a->off_fp;
+  r.H = a->H; r.episode = a->episode; r.eps = a->eps; r.vel = a->vel; r.pos_y = a->pos_y;
+  return r;
+}
 
 struct FastLds {
   uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, stage, total;
@@ -385,6 +412,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 
   // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
   if (wave == 0) {
+    const LateFastArgs lp = (LateFastArgs)late_kernarg_base();     // rew_out, metrics, done_out: used here only
     double rw = 0.0;
     int sole = 0, coll = 0;
     double prr = 0.0;
@@ -396,9 +424,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
-      if (p.rew_out) {
-        if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + lane] = rw;
-        else static_cast<float*>(p.rew_out)[bN + lane] = (float)rw;
+      void* const rew_out = lp->rew_out;
+      if (rew_out) {
+        if constexpr (OUT64) static_cast<double*>(rew_out)[bN + lane] = rw;
+        else static_cast<float*>(rew_out)[bN + lane] = (float)rw;
       }
       if constexpr (RICH) s_rew[lane] = rw;
     }
@@ -412,13 +441,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       vc += __shfl_down(vc, off);
     }
     if (lane == 0) {
-      double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+      double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;
       mt[DIRAL_M_SLOTS] += 1.0;
       mt[DIRAL_M_SUM_REWARD] += vr;
       mt[DIRAL_M_TX_SOLE] += (double)vs;
       mt[DIRAL_M_TX_COLLIDED] += (double)vc;
       if (CH) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
-      if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+      uint8_t* const done_out = lp->done_out;
+      if (done_out) done_out[b] = (uint8_t)lp->done_now;
     }
     if (live) p.pos_x[bN + lane] = mynpx;
   }
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     // sequence-number overflow: no entry exceeds its subject's own number, so the largest
     // word seen reaches the limit exactly when some own stamp does
-    if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(p.err, kErrSeq);
+    if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
   }
   // Vehicle.received_update for every (resource, rx), resources ascending:
   // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
@@ -611,7 +641,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // ---- P4: state = [one-hot(action) (A) | histogram (K)] ---------------------------
   // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
   // divided by the neighbour count) or float32 (= the float32 cast of that value).
+  const unsigned long long late = late_kernarg_base();             // state_out and the RICH section layout: from here on
+  void* const state_out = ((LateFastArgs)late)->state_out;
   if constexpr (RICH) {
+    const RichParams rr = load_rich_args(late);
     // the channel-observation SECTION of the state vector (State.add_channel_obs): the same
     // values P1 stored to chobs_out, rebuilt from the gather sources (the same distance
     // expression P1 evaluated)
@@ -622,23 +655,23 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (src == u) return 100000.0;
       return fast_dist<FLAT>(s_px[src], FLAT ? 0.0 : s_py[src], s_px[u], FLAT ? 0.0 : s_py[u]);
     };
-    if (p.state_out && !r.plain_state) {
+    if (state_out && !rr.plain_state) {
       rich_write_state<OUT64>(
-          r, p.flags, N, A, K, p.L, p.state_out, bN, tid, 256, [&](int u) { return s_act[u]; }, chv,
+          rr, p.flags, N, A, K, p.L, state_out, bN, tid, 256, [&](int u) { return s_act[u]; }, chv,
           [&](int u, int bin) {
             const unsigned int n = s_cnt[u];
             return n ? (double)s_hist[u * KP + bin] / (double)n : 0.0;
           },
           [&](int u) { return s_rew[u]; }, [&](int u) { return s_npx[u]; },
-          [&](int u) { return FLAT ? 0.0 : s_py[u]; }, [&](int u) { return r.vel[bN + u]; });
+          [&](int u) { return FLAT ? 0.0 : s_py[u]; }, [&](int u) { return rr.vel[bN + u]; });
     }
     // the reference's call pattern on the toy YAML's flags (my_step* with `obs` + obtain_state):
     // channel observation above, the plain state vector by the vectorised writer below
-    if (!(p.state_out && r.plain_state)) { DIRAL_FSTAMP(7); return; }
+    if (!(state_out && rr.plain_state)) { DIRAL_FSTAMP(7); return; }
   }
   const int S = A + K;
   if constexpr (OUT64) {
-    double* out = static_cast<double*>(p.state_out) + bN * S;
+    double* out = static_cast<double*>(state_out) + bN * S;
     if (((A | K) & 1) == 0) {
       const int q_per_row = S >> 1, total = N * q_per_row;
       const int du = 256 / q_per_row, dq = 256 - du * q_per_row;
@@ -672,7 +705,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
     }
   } else {
-  float* out = static_cast<float*>(p.state_out) + bN * S;
+  float* out = static_cast<float*>(state_out) + bN * S;
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
     // (row, quad) advance incrementally: one integer division per thread instead of one per store
