@@ -41,6 +41,7 @@ struct DiralEnv {
   uint32_t* err = nullptr;
   double* edges = nullptr;
   double* edges1 = nullptr;
+  double* inv_tab = nullptr;   // [256] 1.0 / n (n = 0: 0): f32 histogram output, csrc/step_fast64.hpp
   double* trace = nullptr;    // handle-owned copy of the replay trace
   int trace_len = 0, trace_per_env = 0;   // np.linspace(-1, 1, K+1) for the type-1 histogram
   int64_t hbm_bytes = 0;
@@ -159,9 +160,10 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
     f.done_now = ((p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226
+    f.chobs_mode = (p.chobs_out ? 1 : 0) | ((p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ? 2 : 0);
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
-    f.metrics = p.metrics; f.err = p.err; f.edges = p.edges;
+    f.metrics = p.metrics; f.err = p.err; f.edges = p.edges; f.inv_tab = e->inv_tab;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
     f.trace = p.trace; f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
@@ -328,6 +330,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->yflag, 4));
   CREATE_TRY(alloc((void**)&e->edges, (size_t)(e->K + 1) * 8));
   CREATE_TRY(alloc((void**)&e->edges1, (size_t)(e->K + 1) * 8));
+  CREATE_TRY(alloc((void**)&e->inv_tab, 256 * 8));
   if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
   if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
 
@@ -338,6 +341,11 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(hipMemcpy(e->edges, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
   np_linspace(-1.0, 1.0, e->K + 1, edges);
   CREATE_TRY(hipMemcpy(e->edges1, edges.data(), edges.size() * 8, hipMemcpyHostToDevice));
+  {
+    std::vector<double> inv(256, 0.0);
+    for (int n = 1; n < 256; ++n) { volatile double d = (double)n; inv[n] = 1.0 / d; }
+    CREATE_TRY(hipMemcpy(e->inv_tab, inv.data(), 256 * 8, hipMemcpyHostToDevice));
+  }
   CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)posdist_lds_bytes(e->N, e->K)));
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
@@ -391,7 +399,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->trace, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;

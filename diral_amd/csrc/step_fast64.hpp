@@ -48,6 +48,9 @@ struct FastParams {
   int reward_design, age_limit, episode_interval;
   int design;                    // 1: my_step_design (test_env.py:269-349) - runtime switch of the non-CH instantiation
   int done_now;                  // t % episode_interval == episode_interval - 1 (main_test.py:226), evaluated on the host
+  int chobs_mode;                // RICH: bit 0 = chobs_out is set; bit 1 = the channel observation is the distance to the
+                                 // closest in-range transmitter (my_step with State.type 2) instead of the constant 1
+                                 // (my_step_ch, my_step_design, State.type 1).  Host-folded: P1 touches no RichParams field
   double L, Rc, Rb, inv_w;
   long long t;
   const int32_t* actions;
@@ -62,6 +65,7 @@ struct FastParams {
   double* metrics;
   uint32_t* err;
   const double* edges;
+  const double* inv_tab;          // [256] 1.0 / n (0 for n = 0): the f32 histogram output multiplies instead of dividing
   void* state_out;                // float* or double* (OUT64)
   void* rew_out;
   uint8_t* done_out;
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 
   // ---- P1: per owned resource i = wave + 4*s: transmitter set, closest in-range
   // transmitter per vehicle, gather sources, collision reward ----------------------
-  const bool dist_obs = RICH && !CH && !(EXTRA && p.design) && r.state_type == 2;
+  const bool dist_obs = RICH && (p.chobs_mode & 2) != 0;
+  const bool emit_chobs = RICH && (p.chobs_mode & 1) != 0;
 #pragma unroll 1
   for (int i = wave; i < A; i += 4) {
     const unsigned long long mk = __ballot(myact == i);     // tx set (test_env.py:153-157)
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
     if constexpr (RICH) {
-      if (r.chobs_out) {
+      if (emit_chobs) {
         // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432): 0 on the own
         // resource or an unused one; my_step with State.type 2: the distance to the closest in-range
         // transmitter, 100000 (network.py:385) when none is in range; otherwise the constant 1.
@@ -453,11 +458,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (live) p.pos_x[bN + lane] = mynpx;
   }
   if constexpr (RICH) {
-    if (r.chobs_out) {
+    if (emit_chobs) {
+      void* const chobs_out = ((LateRichArgs)(late_kernarg_base() + kRichArgOffset))->chobs_out;
       // channel observation [N][A] of this env, 16 bytes per lane, consecutive lanes on consecutive
       // pieces of a row (streaming: nothing on the chip reads it back); overlaps P3 of the other waves
       constexpr int CV = OUT64 ? 2 : 4;
-      out_t* const co = static_cast<out_t*>(r.chobs_out) + bN * A;
+      out_t* const co = static_cast<out_t*>(chobs_out) + bN * A;
       if ((A % CV) == 0) {
         const int qpr = A / CV, total = N * qpr;
         const int du = 256 / qpr, dq = 256 - du * qpr;
@@ -532,14 +538,17 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     packed_ok = (__ballot(bad) == 0ull);
   }
+  // resources with at least one transmitter, as a wave-uniform bit word: the merge visits only those
+  const unsigned long long actw = __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
   if (packed_ok) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    int m_next = s_mtab[lane];
+    unsigned long long rem = actw;
+    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
 #pragma unroll 1
-    for (int i = 0; i < A; ++i) {
+    while (rem) {
+      rem &= rem - 1;
       const int m4 = m_next;
-      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * MT + lane];
-      if (__ballot(myact == i) == 0ull) continue;
+      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kp[j]);
@@ -564,12 +573,13 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (!packed_ok) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) key[c] = (w1[c] & ~255u) | (unsigned int)lane;
-    int m_next = s_mtab[lane];
+    unsigned long long rem = actw;
+    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
 #pragma unroll 1
-    for (int i = 0; i < A; ++i) {
+    while (rem) {
+      rem &= rem - 1;
       const int m4 = m_next;
-      m_next = s_mtab[((i + 1 < A) ? i + 1 : i) * MT + lane];
-      if (__ballot(myact == i) == 0ull) continue;
+      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
@@ -706,6 +716,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
   } else {
   float* out = static_cast<float*>(state_out) + bN * S;
+  const double* const inv_tab = ((LateFastArgs)late)->inv_tab;
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
     // (row, quad) advance incrementally: one integer division per thread instead of one per store
@@ -720,11 +731,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       } else {
         const unsigned int n = s_cnt[u];
         const unsigned int* h = s_hist + u * KP + (s0 - A);
-        // exact w.r.t. (float)((double)h/(double)n): see step_kernel.hpp
-        const float fn = (float)n;
-        v = n ? make_float4(__fdiv_rn((float)h[0], fn), __fdiv_rn((float)h[1], fn),
-                            __fdiv_rn((float)h[2], fn), __fdiv_rn((float)h[3], fn))
-              : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (float)((double)h * fl(1.0 / n)) == (float)((double)h / (double)n) == the correctly rounded float
+        // quotient for every 0 <= h <= n <= 255 (checked exhaustively; the quotient of two small integers
+        // is never within 2^-50 of a float rounding boundary): one table load instead of four IEEE divisions
+        const double inv = inv_tab[n];
+        v = make_float4((float)((double)h[0] * inv), (float)((double)h[1] * inv), (float)((double)h[2] * inv),
+                        (float)((double)h[3] * inv));
       }
       stream_store4(out + 4 * q, v);
       u += du; qr += dq;

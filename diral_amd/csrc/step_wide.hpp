@@ -460,11 +460,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     }
     // (RICH: also for a vehicle whose action was rejected - the output phase reads the
     // reward column of the state back from rew_out, which therefore must be defined)
-    if (u < N && (RICH || a >= 0) && p.rew_out) {
-      if constexpr (OUT64) static_cast<double*>(p.rew_out)[bN + u] = rw;
-      else static_cast<float*>(p.rew_out)[bN + u] = (float)rw;
+    const LateFastArgs lp2 = (LateFastArgs)late_kernarg_base();   // late-bound arguments: see step_fast64.hpp
+    void* const rew_out2 = lp2->rew_out;
+    if (u < N && (RICH || a >= 0) && rew_out2) {
+      if constexpr (OUT64) static_cast<double*>(rew_out2)[bN + u] = rw;
+      else static_cast<float*>(rew_out2)[bN + u] = (float)rw;
     }
-    if (u < N) p.pos_x[bN + u] = s_npx[u];
+    if (u < N) lp2->pos_x[bN + u] = s_npx[u];
     double vr = rw, vp = prr;
     int vs = sole, vc = coll;
 #pragma unroll
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
 #endif
   }
-  if (ovf) atomicOr(p.err, kErrSeq);
+  if (ovf) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
 #ifdef DIRAL_TIMING
   if (lane == 0 && p.dbg) {      // synthetic stamps: accumulated load / merge / finalize time of all passes
     unsigned long long* d = p.dbg + ((size_t)b * WAVES + wave) * 8;
@@ -862,11 +864,15 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   }
 
   // ---- P4: metrics, done flag, state = [one-hot(action) (A) | histogram (K)] ------
+  const unsigned long long late = late_kernarg_base();             // outputs and the RICH section layout: from here on
+  const LateFastArgs lp = (LateFastArgs)late;
+  void* const state_out = lp->state_out;
   if (tid == 0) {
-    if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+    uint8_t* const done_out = lp->done_out;
+    if (done_out) done_out[b] = (uint8_t)lp->done_now;
     double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
     for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
-    double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+    double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;
     mt[DIRAL_M_SLOTS] += 1.0;
     mt[DIRAL_M_SUM_REWARD] += sr;
     mt[DIRAL_M_TX_SOLE] += ss;
@@ -874,8 +880,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     if (CH) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
   }
   if constexpr (RICH) {
+    const RichParams rr = load_rich_args(late);
     // `obs[user][i]` of the reference step, rebuilt from the gather sources (see step_fast64.hpp)
-    const bool dist_obs = !CH && !(EXTRA && p.design) && r.state_type == 2;
+    const bool dist_obs = !CH && !(EXTRA && p.design) && rr.state_type == 2;
     // (`actw`: the wave-uniform word of resources with a transmitter, built before P3)
     auto chv_row = [&](int u, int a, double xu, int i) -> double {
       if (a == i || ((actw >> i) & 1ull) == 0ull) return 0.0;
@@ -885,12 +892,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       return fast_dist<true>(s_px[src], 0.0, xu, 0.0);
     };
     auto chv = [&](int u, int i) -> double { return chv_row(u, s_act[u], s_px[u], i); };
-    if (r.chobs_out) {
+    if (rr.chobs_out) {
       // 16 bytes per lane, consecutive lanes on consecutive pieces of a row; the per-row values
       // (action, position) are loaded once per piece
       constexpr int CV = OUT64 ? 2 : 4;
       typedef typename std::conditional<OUT64, double, float>::type out_t;
-      out_t* const co = static_cast<out_t*>(r.chobs_out) + bN * A;
+      out_t* const co = static_cast<out_t*>(rr.chobs_out) + bN * A;
       if ((A % CV) == 0) {
         const int qpr = A / CV, total = N * qpr;
         for (int q = tid; q < total; q += THREADS) {
@@ -910,29 +917,29 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
       }
     }
-    if (p.state_out && !r.plain_state) {
+    if (state_out && !rr.plain_state) {
       // the reward column is read back from rew_out (written in P2 by this workgroup, two
       // barriers ago; the host dispatches here only with rew_out set when the column exists):
       // 2 KB of LDS for it would cost the third workgroup per CU at N = 256
       rich_write_state<OUT64>(
-          r, p.flags, N, A, K, p.L, p.state_out, bN, tid, THREADS, [&](int u) { return s_act[u]; }, chv,
+          rr, p.flags, N, A, K, p.L, state_out, bN, tid, THREADS, [&](int u) { return s_act[u]; }, chv,
           [&](int u, int bin) {
             const unsigned int n = s_cnt[u];
             const unsigned int h = (s_hist[u * KP + (bin >> 1)] >> (16 * (bin & 1))) & 0xffffu;
             return n ? (double)h / (double)n : 0.0;
           },
           [&](int u) {
-            if constexpr (OUT64) return static_cast<const double*>(p.rew_out)[bN + u];
-            else return (double)static_cast<const float*>(p.rew_out)[bN + u];
+            if constexpr (OUT64) return static_cast<const double*>(lp->rew_out)[bN + u];
+            else return (double)static_cast<const float*>(lp->rew_out)[bN + u];
           },
-          [&](int u) { return s_npx[u]; }, [&](int) { return 0.0; }, [&](int u) { return r.vel[bN + u]; });
+          [&](int u) { return s_npx[u]; }, [&](int) { return 0.0; }, [&](int u) { return rr.vel[bN + u]; });
     }
     // plain state vector next to the channel observation: the vectorised writer below
-    if (!(p.state_out && r.plain_state)) { DIRAL_WSTAMP(7); return; }
+    if (!(state_out && rr.plain_state)) { DIRAL_WSTAMP(7); return; }
   }
   const int S = A + K;
   if constexpr (OUT64) {
-    double* out = static_cast<double*>(p.state_out) + bN * S;
+    double* out = static_cast<double*>(state_out) + bN * S;
     if (((A | K) & 1) == 0) {
       const int q_per_row = S >> 1, total = N * q_per_row;
       for (int q = tid; q < total; q += THREADS) {
@@ -962,7 +969,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
     }
   } else {
-    float* out = static_cast<float*>(p.state_out) + bN * S;
+    float* out = static_cast<float*>(state_out) + bN * S;
+    const double* const inv_tab = lp->inv_tab;
     if (((A | K) & 3) == 0) {
       const int q_per_row = S >> 2, total = N * q_per_row;
       for (int q = tid; q < total; q += THREADS) {
@@ -975,11 +983,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           const unsigned int n = s_cnt[u];
           const unsigned int* hw = s_hist + u * KP + ((s0 - A) >> 1);        // s0 - A is a multiple of 4: two words
           const unsigned int h01 = hw[0], h23 = hw[1];
-          // exact w.r.t. (float)((double)h/(double)n): see step_kernel.hpp
-          const float fn = (float)n;
-          v = n ? make_float4(__fdiv_rn((float)(h01 & 0xffffu), fn), __fdiv_rn((float)(h01 >> 16), fn),
-                              __fdiv_rn((float)(h23 & 0xffffu), fn), __fdiv_rn((float)(h23 >> 16), fn))
-                : make_float4(0.f, 0.f, 0.f, 0.f);
+          // one table load instead of four IEEE divisions: exact, see step_fast64.hpp
+          const double inv = inv_tab[n];
+          v = make_float4((float)((double)(h01 & 0xffffu) * inv), (float)((double)(h01 >> 16) * inv),
+                          (float)((double)(h23 & 0xffffu) * inv), (float)((double)(h23 >> 16) * inv));
         }
         reinterpret_cast<float4*>(out)[q] = v;
       }
