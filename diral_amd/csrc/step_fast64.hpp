@@ -169,7 +169,9 @@ template <bool FLAT>
 __device__ inline double fast_dist(double x1, double y1, double x2, double y2) {
   const double dx = x2 - x1;
   const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
-  const bool in_range = (hi - 0x20b00000u) <= (0x5f300000u - 0x20b00000u);
+  // (one-sided: beyond 2^500 the square overflows to inf in the reference while |dx| stays finite, but every
+  // use of the result compares it with a finite range first - `d < Rc`, `d < Rb`, `d > Rc` - and agrees)
+  const bool in_range = hi >= 0x20b00000u;
   if (FLAT) {
     if (in_range) return __hiloint2double((int)hi, __double2loint(dx));
     return dist_general(dx, 0.0);
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       v = xg - mynpx;
       const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
       d = __hiloint2double((int)vh, __double2loint(v));
-      if (!((vh - 0x20b00000u) <= (0x5f300000u - 0x20b00000u))) {   // |v| outside [2^-500, 2^500] or 0
+      if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
         d = dist_general(mynpx - xg, 0.0);
         v = (xg - mynpx > 0.0) ? d : -d;
       }

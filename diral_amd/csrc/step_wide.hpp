@@ -54,7 +54,11 @@ __host__ __device__ constexpr int wide_mtab_stride(int vpl) { return vpl == 4 ? 
 __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   const uint32_t npad = 64u * vpl;
   WideLds l;
-  uint32_t o = 0;
+  // The per-wave merge scratch sits at LDS offset 0: wave W's words start at the COMPILE-TIME
+  // address 2048 W, which the merge loop (one copy per wave index) folds into the immediate
+  // offset of its gathers instead of adding a base register to every gather address.
+  l.scratch = 0;
+  uint32_t o = 2048u * wide_waves(vpl);        // 2 KB per wave: merge words, then the rank -> xpos table
   l.px = o;    o += 8u * npad;
   l.npx = o;   o += 8u * npad;
   l.rv = o;    o += 8u * A;
@@ -65,8 +69,6 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   l.cnt = o;   o += 4u * npad;
   l.hist = o;  o += 4u * wide_hist_stride(K) * npad;   // [viewer][stride]: two bins per word
   l.mtab = o;  o += (uint32_t)A * wide_mtab_stride(vpl) * vpl;   // [resource][lane][slot]: gather source viewer (bytes)
-  l.scratch = align_up(o, 16);
-  o = l.scratch + 2048u * wide_waves(vpl);     // 2 KB per wave: merge words, then the rank -> xpos table
   l.total = align_up(o, 16);
   return l;
 }
@@ -107,6 +109,38 @@ template <int NK>
 __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&b)[NK]) {
   if constexpr (NK == 4) max_u8x16(a, b);
   else max_u8x32(a, b);
+}
+
+#ifndef DIRAL_WIDE_WAVECONST
+#define DIRAL_WIDE_WAVECONST 1           // one copy of the merge loop per wave index: scratch base as an immediate offset
+#endif
+// run f(std::integral_constant<int, wave>) - a copy of f per wave index (wave-uniform switch) -
+// or f(-1) when the switch is compiled out
+#if DIRAL_WIDE_WAVECONST
+#define DIRAL_WIDE_DISPATCH_WAVE(f)                                      \
+  do {                                                                   \
+    if (!lds_base_is_zero) { f(std::integral_constant<int, -1>{}); break; } \
+    switch (wave) {                                                      \
+      case 0: f(std::integral_constant<int, 0>{}); break;                \
+      case 1: f(std::integral_constant<int, 1>{}); break;                \
+      case 2: f(std::integral_constant<int, 2>{}); break;                \
+      case 3: f(std::integral_constant<int, 3>{}); break;                \
+      case 4: f(std::integral_constant<int, 4>{}); break;                \
+      case 5: f(std::integral_constant<int, 5>{}); break;                \
+      case 6: f(std::integral_constant<int, 6>{}); break;                \
+      default: f(std::integral_constant<int, 7>{}); break;               \
+    }                                                                    \
+  } while (0)
+#else
+#define DIRAL_WIDE_DISPATCH_WAVE(f) f(std::integral_constant<int, -1>{})
+#endif
+
+// An LDS object by its absolute byte address (register + compile-time constant: the constant goes
+// into the DS instruction's immediate offset; going through the `extern __shared__` symbol instead
+// leaves a relocated `+ 0` add in front of every access)
+template <typename T>
+__device__ inline const __attribute__((address_space(3))) T* lds_at(unsigned int byte_addr) {
+  return (const __attribute__((address_space(3))) T*)(size_t)byte_addr;
 }
 
 // LDS byte address of a __shared__ object (what M0-relative DS instructions take)
@@ -485,6 +519,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   unsigned int* const sw = reinterpret_cast<unsigned int*>(smem + lay.scratch + 2048u * wave);   // merge words
   double* const xt = reinterpret_cast<double*>(sw);                                             // rank -> xpos
   const unsigned int sw_lds = __builtin_amdgcn_readfirstlane(lds_addr(sw));
+  // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
+  const bool lds_base_is_zero = __builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u;
   const double inv_w = p.inv_w;
 
   // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
@@ -522,7 +558,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     double v = xg - s_npx[u];
     const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
     double d = __hiloint2double((int)vh, __double2loint(v));
-    if (!((vh - 0x20b00000u) <= (0x5f300000u - 0x20b00000u))) {     // |v| outside [2^-500, 2^500] or 0
+    if (vh < 0x20b00000u) {                                         // |v| below 2^-500 (its square underflows) or 0
       d = dist_general(s_npx[u] - xg, 0.0);
       v = (xg - s_npx[u] > 0.0) ? d : -d;
     }
@@ -628,35 +664,40 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
           for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
         wave_lds_order();
-        unsigned long long rem = actw;
-        unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-        while (rem) {
-          rem &= rem - 1;
-          const unsigned int mw = m_next;
-          if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-          unsigned int v[NK], sa[VPL];
-          unpack_src<VPL, 2u>(mw, sa);
-          const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
+        auto merge_loop = [&](auto wtag) {
+          constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, 2u>(mw, sa);
 #pragma unroll
-          for (int j = 0; j < VPL; ++j) {
+            for (int j = 0; j < VPL; ++j) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-              v[w * VPL + j] = *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
-          }
-          // a transmitter's words are not written during its own resource, so all
-          // gathers of a step may precede all its writes
-          wave_lds_order();
-          max_u8_words<NK>(kp, v);
+              for (int w = 0; w < NW; ++w)
+                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(2048u * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
+                                      : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
+            }
+            // a transmitter's words are not written during its own resource, so all
+            // gathers of a step may precede all its writes
+            wave_lds_order();
+            max_u8_words<NK>(kp, v);
 #if DIRAL_WIDE_ADDTID
-          lds_store4_lane_linear(sw_lds, kp);     // sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
+            lds_store4_lane_linear(sw_lds, kp);     // sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
 #else
 #pragma unroll
-          for (int w = 0; w < NW; ++w)
+            for (int w = 0; w < NW; ++w)
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+              for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
 #endif
-          wave_lds_order();
-        }
+            wave_lds_order();
+          }
+        };
+        DIRAL_WIDE_DISPATCH_WAVE(merge_loop);
       } else {
         // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
         // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
@@ -674,26 +715,30 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         };
         put();
         wave_lds_order();
-        unsigned long long rem = actw;
-        unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-        while (rem) {
-          rem &= rem - 1;
-          const unsigned int mw = m_next;
-          if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-          unsigned int v[NK], sa[VPL];
-          unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
-          const unsigned char* swb = reinterpret_cast<const unsigned char*>(sw);
+        auto merge_loop = [&](auto wtag) {
+          constexpr int W = decltype(wtag)::value;
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
 #pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const uvec g = *reinterpret_cast<const uvec*>(swb + sa[j]);
+            for (int j = 0; j < VPL; ++j) {
+              const uvec g = W >= 0 ? *lds_at<uvec>(2048u * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
+              for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
+            }
+            wave_lds_order();
+            max_u8_words<NK>(kp, v);
+            put();
+            wave_lds_order();
           }
-          wave_lds_order();
-          max_u8_words<NK>(kp, v);
-          put();
-          wave_lds_order();
-        }
+        };
+        DIRAL_WIDE_DISPATCH_WAVE(merge_loop);
       }
       DIRAL_WCLOCK(tc2);
 
