@@ -257,7 +257,7 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #define DIRAL_WIDE_XPRE2 1
 #endif
 #ifndef DIRAL_WIDE_XPRE4
-#define DIRAL_WIDE_XPRE4 0
+#define DIRAL_WIDE_XPRE4 1
 #endif
 #ifndef DIRAL_WIDE_FIN_UNROLL2
 #define DIRAL_WIDE_FIN_UNROLL2 8         // finalize column loop, N <= 128 (8 columns per pass): fully unrolled
