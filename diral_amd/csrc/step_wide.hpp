@@ -253,6 +253,9 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #ifndef DIRAL_WIDE_REGCNT
 #define DIRAL_WIDE_REGCNT 1
 #endif
+#ifndef DIRAL_WIDE_REGCNT4
+#define DIRAL_WIDE_REGCNT4 0
+#endif
 #ifndef DIRAL_WIDE_XPRE2
 #define DIRAL_WIDE_XPRE2 1
 #endif
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
   // neighbour count per viewer: in registers where the VGPR budget has room (N <= 128: one
   // barrier and one pass over the histogram less), else the row sum of the histogram
-  constexpr bool REGCNT = (VPL == 2) && (DIRAL_WIDE_REGCNT != 0);
+  constexpr bool REGCNT = VPL == 2 ? (DIRAL_WIDE_REGCNT != 0) : (DIRAL_WIDE_REGCNT4 != 0);
   unsigned int mycnt[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
@@ -987,8 +990,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     double* out = static_cast<double*>(state_out) + bN * S;
     if (((A | K) & 1) == 0) {
       const int q_per_row = S >> 1, total = N * q_per_row;
-      for (int q = tid; q < total; q += THREADS) {
-        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 1;
+      // (row, piece) advance incrementally: one integer division per thread instead of one per store
+      const int du = THREADS / q_per_row, dq = THREADS - du * q_per_row;
+      int u = tid / q_per_row, qr = tid - u * q_per_row;
+      for (int q = tid; q < total; q += THREADS, u += du, qr += dq) {
+        if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
+        const int s0 = qr << 1;
         double2 v;
         if (s0 < A) {
           const int a = s_act[u] - s0;
@@ -1018,8 +1025,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     const double* const inv_tab = lp->inv_tab;
     if (((A | K) & 3) == 0) {
       const int q_per_row = S >> 2, total = N * q_per_row;
-      for (int q = tid; q < total; q += THREADS) {
-        const int u = q / q_per_row, s0 = (q - u * q_per_row) << 2;
+      const int du = THREADS / q_per_row, dq = THREADS - du * q_per_row;
+      int u = tid / q_per_row, qr = tid - u * q_per_row;
+      for (int q = tid; q < total; q += THREADS, u += du, qr += dq) {
+        if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
+        const int s0 = qr << 2;
         float4 v;
         if (s0 < A) {
           const int a = s_act[u] - s0;
