@@ -374,7 +374,8 @@ def main() -> int:
                 "layout_bytes_per_launch": res["layout_bytes_per_launch"],
                 "layout_rate_GBps": res["layout_rate_GBps"],
                 "layout_frac_of_peak": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
-                "limiter": "VALU issue (float64 compare/select work of the merge and the histogram), see profiles/README.md",
+                "limiter": "VALU issue (~87 % busy) with the HBM at ~0.85 of copy-kernel speed - two pipes near their "
+                           "practical limits at once, see profiles/README.md",
             },
             "episode_metrics": totals,
         }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "diral_env_sample", "diral_env_info_age", "diral_env_export_state", "diral_env_import_state",
     "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error", "diral_sps_step", "diral_sps_init",
     "diral_env_set_trace", "diral_env_set_option", "diral_env_last_kernel",
-    "diral_sps_window_from_chobs", "diral_sps_step_chobs",
+    "diral_sps_window_from_chobs", "diral_sps_step_chobs", "diral_driver_shape",
 ]
 
 _lib = None
@@ -78,6 +78,7 @@ def load() -> ctypes.CDLL:
         "diral_env_last_kernel": (I, [P]),
         "diral_sps_window_from_chobs": (I, [I, I, P, I, P, P, P]),
         "diral_sps_step_chobs": (I, [I, I, P, I, P, P, P, D, D, D, P, P, P, U64, P, P]),
+        "diral_driver_shape": (I, [I, I, I, P, I, P, P, P, P, P, I, I, D, P, P, P, P, P, P]),
     }
     for name in SYMBOLS:
         try:

@@ -148,17 +148,21 @@ __device__ inline int sps_choose(W w, int A, int prev, double threshold, double 
   if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
   if (need < 1) need = 1;
   const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
-  int chosen = prev;
-  for (int s = 0; s < A; ++s) {                                    // sorted(sA.items(), key=value): stable
-    const double ws = w(s);
-    if (s == prev || !(ws < thr)) continue;
-    int rank = 0;
-    for (int q = 0; q < A; ++q) {
-      const double wq = w(q);
-      if (q == prev || !(wq < thr)) continue;
-      rank += (wq < ws || (wq == ws && q < s)) ? 1 : 0;
+  // sB[pick]: the (pick + 1)-th entry of sorted(sA.items(), key=value) - a stable sort, i.e. ordered by
+  // (value, subframe).  pick < need <= A / 5 + 1, so pick + 1 minimum scans beat ranking every subframe.
+  int chosen = prev, last_s = -1;
+  double last_w = 0.0;
+  for (int k = 0; k <= pick; ++k) {
+    int best_s = -1;
+    double best_w = 0.0;
+    for (int s = 0; s < A; ++s) {
+      const double ws = w(s);
+      if (s == prev || !(ws < thr)) continue;
+      if (k > 0 && !(ws > last_w || (ws == last_w && s > last_s))) continue;      // at or before the previous pick
+      if (best_s < 0 || ws < best_w) { best_s = s; best_w = ws; }               // first minimum: lowest subframe wins ties
     }
-    if (rank == pick) chosen = s;
+    if (best_s < 0) break;                                       // cannot happen: need <= len(sA)
+    last_s = best_s; last_w = best_w; chosen = best_s;
   }
   return chosen;
 }
@@ -237,6 +241,94 @@ __global__ void sps_step_chobs_kernel(int agents, int A, const T* chobs, const i
   }
   counter[i] = cnt;
   actions_out[i] = action;
+}
+
+// np.sum over one row in NumPy's order (numpy/_core/src/umath/loops_utils.h pairwise_sum): fewer
+// than 8 elements sequentially; up to 128: eight running accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail; above: split at n/2 rounded down to a
+// multiple of 8, recursively.  Float addition is not associative: the driver's shaped rewards
+// (main_test.py:171, 205-206) are bit-identical only in this order.
+template <typename T>
+__device__ T np_pairwise_sum(const T* a, int n) {
+  if (n < 8) {
+    T res = (T)0;
+    for (int i = 0; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  if (n <= 128) {
+    T r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// The driver's per-slot reward post-processing (main_test.py:150-206), for `envs` envs in one
+// launch; 64 envs per 256-thread block: one thread per env sums and decides, then all threads
+// rewrite the block's rewards coalesced.
+//   ia_sum      = sum_i (i + 1) * ia[i] over bins with ia[i] > 0          (utils/misc.py:1-12)
+//   ia_penalty  = -1 / +1 / 0 as ia_sum rose / fell / stayed (ia_averaging, :153-160)
+//   sum_r       = np.sum(reward) (:171), collision = A - sum_r (:178)
+//   reward'     = reward + ia_penalty (:190-192); counter / threshold penalty (:194-203);
+//                 + sum_r / N (global_reward_avg, :205-206)
+constexpr int kShapeEnvsPerBlock = 64;
+template <typename T>
+__global__ void driver_shape_kernel(int envs, int N, int A, const T* reward_in, const int32_t* actions,
+                                    const int32_t* ia, long long* sum_ia_prev, int32_t* pen_counter,
+                                    int32_t* prev_actions, int flags, int pen_threshold, double pen_value,
+                                    T* reward_out, T* sum_r_out, T* collision_out, long long* ia_sum_out,
+                                    int32_t* ia_pen_out) {
+  __shared__ T s_sum[kShapeEnvsPerBlock];
+  __shared__ T s_pen[kShapeEnvsPerBlock];
+  const int e0 = blockIdx.x * kShapeEnvsPerBlock;
+  const int ne = min(kShapeEnvsPerBlock, envs - e0);
+  const bool global_avg = flags & 1, ia_avg = flags & 2, pen_enable = flags & 4;
+  if ((int)threadIdx.x < ne) {
+    const int b = e0 + threadIdx.x;
+    const T sr = np_pairwise_sum(reward_in + (size_t)b * N, N);
+    s_sum[threadIdx.x] = sr;
+    if (sum_r_out) sum_r_out[b] = sr;
+    if (collision_out) collision_out[b] = (T)A - sr;
+    T pen = (T)0;
+    if (ia) {
+      long long acc = 0;
+      for (int i = 0; i < 100; ++i) { const int v = ia[(size_t)b * 100 + i]; acc += v > 0 ? (long long)(i + 1) * v : 0; }
+      if (ia_sum_out) ia_sum_out[b] = acc;
+      if (ia_avg && sum_ia_prev) {
+        const long long prev = sum_ia_prev[b];
+        const int p = acc > prev ? -1 : (acc < prev ? 1 : 0);
+        sum_ia_prev[b] = acc;
+        if (ia_pen_out) ia_pen_out[b] = p;
+        pen = (T)p;
+      }
+    }
+    s_pen[threadIdx.x] = pen;
+  }
+  __syncthreads();
+  const int total = ne * N;
+  for (int j = threadIdx.x; j < total; j += blockDim.x) {
+    const int le = j / N;
+    const size_t g = (size_t)e0 * N + j;
+    T r = reward_in[g];
+    if (ia_avg) r = r + s_pen[le];
+    if (pen_enable) {
+      const int a = actions[g];
+      const bool stuck = (r < (T)1) && (a == prev_actions[g]);
+      const int c = stuck ? pen_counter[g] + 1 : 0;
+      pen_counter[g] = c;
+      if (c > pen_threshold) r = (T)pen_value;
+      prev_actions[g] = a;
+    }
+    if (global_avg) r = r + s_sum[le] / (T)N;
+    reward_out[g] = r;
+  }
 }
 
 __global__ void any_nonzero_kernel(int total, const double* v, uint32_t* flag) {

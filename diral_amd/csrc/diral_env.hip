@@ -619,6 +619,31 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 
+int diral_driver_shape(int envs, int num_users, int num_channels, const void* reward_in, int dtype,
+                       const int32_t* actions, const int32_t* ia, int64_t* sum_ia_prev, int32_t* pen_counter,
+                       int32_t* prev_actions, int flags, int ia_penalty_threshold, double ia_penalty_value,
+                       void* reward_out, void* sum_r_out, void* collision_out, int64_t* ia_sum_out,
+                       int32_t* ia_penalty_out, void* stream) {
+  if (envs < 1 || num_users < 1 || !reward_in || !reward_out) return DIRAL_ERR_BAD_ARG;
+  if (dtype != DIRAL_F32 && dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  if ((flags & 4) && (!actions || !pen_counter || !prev_actions)) return DIRAL_ERR_BAD_ARG;
+  if ((flags & 2) && (!ia || !sum_ia_prev)) return DIRAL_ERR_BAD_ARG;
+  const dim3 g(blocks((size_t)envs, kShapeEnvsPerBlock)), t(256);
+  if (dtype == DIRAL_F64)
+    hipLaunchKernelGGL(driver_shape_kernel<double>, g, t, 0, (hipStream_t)stream, envs, num_users, num_channels,
+                       static_cast<const double*>(reward_in), actions, ia, (long long*)sum_ia_prev, pen_counter, prev_actions,
+                       flags, ia_penalty_threshold, ia_penalty_value, static_cast<double*>(reward_out),
+                       static_cast<double*>(sum_r_out), static_cast<double*>(collision_out), (long long*)ia_sum_out,
+                       ia_penalty_out);
+  else
+    hipLaunchKernelGGL(driver_shape_kernel<float>, g, t, 0, (hipStream_t)stream, envs, num_users, num_channels,
+                       static_cast<const float*>(reward_in), actions, ia, (long long*)sum_ia_prev, pen_counter, prev_actions,
+                       flags, ia_penalty_threshold, ia_penalty_value, static_cast<float*>(reward_out),
+                       static_cast<float*>(sum_r_out), static_cast<float*>(collision_out), (long long*)ia_sum_out,
+                       ia_penalty_out);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
 int diral_sps_window_from_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype,
                                 const int32_t* actions, double* window_out, void* stream) {
   if (agents < 1 || num_channels < 1 || !chobs || !actions || !window_out) return DIRAL_ERR_BAD_ARG;

@@ -66,7 +66,7 @@ class DriverLoop:
                  ia_averaging: bool = False, ia_penalty_enable: bool = False, ia_penalty_threshold: int = 5,
                  ia_penalty_value: float = -10, episode_interval: int = 25,
                  eps_init: float = 0.99, eps_decay: float = 0.9992, eps_min: float = 0.001,
-                 fused: bool = False):
+                 fused: bool = False, device_shaping: Optional[bool] = None):
         self.env = env
         self.enable_channel = enable_channel                  # main_test.py:40
         self.global_reward_avg = global_reward_avg            # :38
@@ -79,6 +79,11 @@ class DriverLoop:
         # fused=True: my_step + obtain_state in ONE launch (VecV2VEnv.step semantics; same
         # values, but the channel observation `obs` is not materialised)
         self.fused = fused
+        # device_shaping: the reward post-processing of a slot as ONE launch of `diral_driver_shape`
+        # (include/diral_env.h) instead of ~70 small torch ops; None = whenever the env is the HIP one.
+        # The torch statement below stays: it is what runs on the CPU (oracle-backed tests) and what the
+        # kernel is tested against.
+        self.device_shaping = (hasattr(env, "lib") and hasattr(env, "_stream")) if device_shaping is None else device_shaping
         self.episode = 0
         self.N = env.get_total_users()
         self.A = env.get_action_space()
@@ -132,8 +137,10 @@ class DriverLoop:
         ia_penalty = None
         if need_ia:
             ia = self._t(env.info_age(time_step))                            # :150
+            out["ia"] = ia
+        if need_ia and not self.device_shaping:
             ia_sum = calculate_ia_penalty(ia)                                # :151
-            out["ia"], out["ia_sum"] = ia, ia_sum
+            out["ia_sum"] = ia_sum
             if self.ia_averaging:                                            # :153-160
                 prev = self._sum_ia_prev if self._sum_ia_prev is not None else torch.zeros_like(ia_sum)
                 ia_penalty = torch.where(ia_sum > prev, -1, torch.where(ia_sum < prev, 1, 0)).to(reward.dtype)
@@ -145,9 +152,19 @@ class DriverLoop:
             # (the returned tensors, unmodified: VecV2VEnv then serves the state its fused launch
             # already built instead of a second launch)
             next_state = self._t(env.obtain_state(obs, action, reward_ret, self.episode, self.eps)).clone()   # :164
+        a = self._actions(action).to(reward.device)
+        if self.device_shaping:
+            shaped, sum_r, collision, pen, ia_sum = self._shape_on_device(reward, a, out.get("ia"))
+            if ia_sum is not None:
+                out["ia_sum"] = ia_sum
+            if self.ia_averaging:
+                out["ia_penalty"] = pen
+            episode_end = (time_step % self.episode_interval) == self.episode_interval - 1   # :226
+            out.update(next_state=next_state, reward=shaped, raw_reward=raw, sum_r=sum_r, collision=collision,
+                       episode_end=episode_end, episode=self.episode, eps=self.eps)
+            return out
         sum_r = np_sum_lastdim(reward)                                       # :171 (NumPy's summation order)
         collision = self.A - sum_r                                           # :178
-        a = self._actions(action).to(reward.device)
         if ia_penalty is not None:
             reward = reward + ia_penalty.unsqueeze(-1)                       # :190-192
         if self.ia_penalty_enable:                                           # :194-203
@@ -161,11 +178,48 @@ class DriverLoop:
                                  reward)
             self._prev_actions = a.clone()
         if self.global_reward_avg:
-            reward = reward + (sum_r / self.N).unsqueeze(-1)                 # :205-206
+            # (tensor / tensor: a true IEEE division like Python's `sum_r / len(reward)`; tensor / Python scalar
+            # is computed on the GPU as a multiplication by the rounded reciprocal - one ulp off unless N is a
+            # power of two)
+            n_t = torch.as_tensor(float(self.N), dtype=reward.dtype, device=reward.device)
+            reward = reward + (sum_r / n_t).unsqueeze(-1)                    # :205-206
         episode_end = (time_step % self.episode_interval) == self.episode_interval - 1   # :226
         out.update(next_state=next_state, reward=reward, raw_reward=raw, sum_r=sum_r, collision=collision,
                    episode_end=episode_end, episode=self.episode, eps=self.eps)
         return out
+
+    def _shape_on_device(self, reward: torch.Tensor, a: torch.Tensor, ia: Optional[torch.Tensor]):
+        """main_test.py:171-206 through `diral_driver_shape` (one launch)."""
+        env = self.env
+        B, N = reward.shape
+        dev = reward.device
+        reward = reward.contiguous()
+        a32 = a.to(torch.int32).contiguous()
+        if self.ia_averaging and self._sum_ia_prev is None:
+            self._sum_ia_prev = torch.zeros((B,), dtype=torch.int64, device=dev)
+        if self.ia_penalty_enable and self._pen_counter is None:
+            self._pen_counter = torch.zeros((B, N), dtype=torch.int32, device=dev)
+            self._prev_actions = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+        shaped = torch.empty_like(reward)
+        sum_r = torch.empty((B,), dtype=reward.dtype, device=dev)
+        coll = torch.empty((B,), dtype=reward.dtype, device=dev)
+        pen = torch.zeros((B,), dtype=torch.int32, device=dev) if self.ia_averaging else None
+        ia32 = None if ia is None else ia.to(torch.int32).contiguous()
+        ia_sum = None if ia is None else torch.empty((B,), dtype=torch.int64, device=dev)
+        flags = (1 if self.global_reward_avg else 0) | (2 if self.ia_averaging else 0) | (4 if self.ia_penalty_enable else 0)
+
+        def p(t):
+            return None if t is None else t.data_ptr()
+        st = env.lib.diral_driver_shape(B, N, self.A, p(reward), 1 if reward.dtype == torch.float64 else 0, p(a32), p(ia32),
+                                        p(self._sum_ia_prev) if self.ia_averaging else None,
+                                        p(self._pen_counter) if self.ia_penalty_enable else None,
+                                        p(self._prev_actions) if self.ia_penalty_enable else None, flags,
+                                        int(self.ia_penalty_threshold), float(self.ia_penalty_value), p(shaped), p(sum_r),
+                                        p(coll), p(ia_sum), p(pen), env._stream())
+        if st != 0:
+            raise RuntimeError("diral_driver_shape failed with status %d" % st)
+        self._keep = (reward, a32, ia32)
+        return shaped, sum_r, coll, (pen.to(reward.dtype) if pen is not None else None), ia_sum
 
     # main_test.py:226-233: call when out["episode_end"]; `draws` are the
     # random.randrange(1,4) values of Network.update_velocity (None = device RNG)

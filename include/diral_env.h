@@ -271,6 +271,26 @@ int diral_env_metrics(DiralEnv* env, double* out, int clear, void* stream);
  * first error. */
 int diral_env_check(DiralEnv* env, void* stream);
 
+/* ---- the driver's reward post-processing (main_test.py:150-206) ----------------- */
+
+/* What `marl_test` does to the rewards of one slot between `env.my_step*` and
+ * `memory.add`, for `envs` envs in ONE launch (stateless: the caller owns the counters):
+ *   sum_r      = np.sum(reward) in NumPy's pairwise order (:171), collision = A - sum_r (:178)
+ *   ia_sum     = utils/misc.calculate_ia_penalty(ia) = sum (i+1)*ia[i]      (:151; ia [envs][100] or NULL)
+ *   ia_penalty = -1 / +1 / 0 as ia_sum rose / fell / stayed vs *sum_ia_prev  (:153-160; flags bit 1)
+ *   reward'    = reward + ia_penalty (:190-192); counter penalty: an agent that repeats an
+ *                unsuccessful action (reward' < 1) more than `ia_penalty_threshold` times gets
+ *                `ia_penalty_value` (:194-203; flags bit 2; pen_counter, prev_actions [envs][N] in/out);
+ *                + sum_r / N (global_reward_avg, :205-206; flags bit 0)
+ * reward_in / reward_out / sum_r_out / collision_out: `dtype` (arithmetic in that type, like the
+ * torch statement diral_amd/driver.py keeps for the CPU-backed tests; float64 = the reference's).
+ * Any output pointer may be NULL except reward_out. */
+int diral_driver_shape(int envs, int num_users, int num_channels, const void* reward_in, int dtype,
+                       const int32_t* actions, const int32_t* ia, int64_t* sum_ia_prev, int32_t* pen_counter,
+                       int32_t* prev_actions, int flags, int ia_penalty_threshold, double ia_penalty_value,
+                       void* reward_out, void* sum_r_out, void* collision_out, int64_t* ia_sum_out,
+                       int32_t* ia_penalty_out, void* stream);
+
 /* ---- SPS baseline policy (agent side, stateless entry points) ----------------- */
 
 /* Replaces SemiPersistentScheduling.step + choose_new_resource

@@ -96,3 +96,41 @@ def test_np_sum_order_matches_numpy():
         got = np_sum_lastdim(torch.as_tensor(a)).numpy()
         want = np.array([np.sum(row) for row in a])
         assert np.array_equal(got, want), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,dtype", [(4, torch.float64), (7, torch.float32), (16, torch.float64), (64, torch.float32),
+                                     (64, torch.float64), (129, torch.float64), (200, torch.float32), (256, torch.float64)])
+def test_device_reward_shaping_equals_the_torch_statement(N, dtype):
+    """`diral_driver_shape` (main_test.py:150-206 in one launch) against the torch statement of
+    DriverLoop.slot on the same env: shaped rewards, np.sum-ordered sum_r, collision metric,
+    information-age sum and penalty, stuck-action counters - bit for bit, float32 and float64,
+    every option on."""
+    from diral_amd.config import bench_config
+    from diral_amd.vec_env import VecV2VEnv
+    A = 8
+    cfg = bench_config(N, A, 30.0 * N + 50, reward_design=3, communication_range=120.0).replace(track_arrival=True)
+    B = 24
+    envs = [VecV2VEnv(cfg, batch=B, out_dtype=dtype) for _ in range(2)]
+    loops = [DriverLoop(e, enable_channel=True, global_reward_avg=True, ia_averaging=True, ia_penalty_enable=True,
+                        ia_penalty_threshold=2, ia_penalty_value=-10, device_shaping=ds) for e, ds in zip(envs, (True, False))]
+    assert loops[0].device_shaping and not loops[1].device_shaping
+    for e in envs:
+        e.reset_topology(seed=31)
+    rng = np.random.default_rng(N)
+    acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+    for lp in loops:
+        lp.bootstrap(torch.as_tensor(acts, device="cuda:0"))
+    for t in range(40):
+        new = rng.integers(0, A, size=(B, N))
+        acts = np.where(rng.random((B, N)) < 0.7, acts, new).astype(np.int32)       # sticky: the stuck counters fire
+        a = torch.as_tensor(acts, device="cuda:0")
+        o_dev, o_ref = loops[0].slot(a, t, want_ia=True), loops[1].slot(a, t, want_ia=True)
+        for k in ("reward", "raw_reward", "sum_r", "collision", "ia", "ia_sum", "ia_penalty", "next_state"):
+            assert torch.equal(o_dev[k].to(o_ref[k].dtype), o_ref[k]), (k, t)
+        assert o_dev["reward"].dtype == dtype and o_dev["sum_r"].dtype == dtype
+        if o_dev["episode_end"]:
+            for lp in loops:
+                lp.end_episode(np.full((B, N), 3, np.uint8))
+    assert torch.equal(loops[0]._pen_counter.long(), loops[1]._pen_counter.long())
+    assert int(loops[0]._pen_counter.max()) > 2          # the threshold penalty really fired
