@@ -128,20 +128,20 @@ constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | 
 
 // Configurations the specialised kernels (step_fast64 / step_wide) serve: the type-2
 // piggybacked histogram observation with any of the cheap State flags, every step kind, any
-// combination of outputs.  PF, PRR tracking in my_step, the secondary observation modes
-// (a15/a16) and static topologies stay on the general kernel.
+// combination of outputs, proportional fairness.  PRR tracking in my_step, the secondary
+// observation modes (a15/a16) and static topologies stay on the general kernel.
 bool is_specialised_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
-                          DIRAL_F_ADD_ACTION | kRichFlags;
+                          DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | kRichFlags;
   return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN);
 }
 // ... of which the PLAIN instantiations serve the toy YAML's State flags with the state vector
 // as the only observation output (the metric's configuration)
 bool is_plain_cfg(const StepParams& p) {
-  return (p.flags & kRichFlags) == 0 && (p.flags & DIRAL_F_ADD_ACTION) && p.state_out != nullptr &&
-         p.chobs_out == nullptr;
+  return (p.flags & (kRichFlags | DIRAL_F_PROPORTIONAL_FAIR)) == 0 && (p.flags & DIRAL_F_ADD_ACTION) &&
+         p.state_out != nullptr && p.chobs_out == nullptr;
 }
 
 hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
@@ -171,6 +171,8 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     RichParams r = e->rich;
     r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
     r.plain_state = ((p.flags & kRichFlags) == 0 && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
+    r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
+    r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
     k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in

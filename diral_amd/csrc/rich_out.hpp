@@ -11,7 +11,8 @@
 //   * the cheap State flags of TestEnv.obtain_state (test_env.py:527-583):
 //     action_index "real", add_channel_obs, add_reward, add_index, add_position,
 //     add_velocity, enable_fingerprint, and State.type 1 (channel observation 1
-//     instead of the distance, test_env.py:226-240).
+//     instead of the distance, test_env.py:226-240);
+//   * proportional fairness (test_env.py:211-222: the pf_counter penalty of my_step).
 // Nothing here feeds back into the step: the values are rebuilt in the output
 // phase from what the step left in LDS (gather sources, transmitter masks,
 // positions), so the hot loops of the plain instantiations are untouched.
@@ -31,6 +32,9 @@ struct RichParams {
   double episode, eps;     // fingerprint (test_env.py:577-579)
   const double* vel;       // [B][N] (add_velocity reads it in the output phase)
   const double* pos_y;     // [B][N]
+  int32_t* pf;             // [B][N] pf_counter (test_env.py:87-92) or null: proportional fairness off
+  int pf_threshold;        // 10  test_env.py:89
+  double pf_penalty;       // -10 test_env.py:90
 };
 
 template <bool OUT64>

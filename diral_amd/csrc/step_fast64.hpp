@@ -95,6 +95,7 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
   r.off_act = a->off_act; r.off_chobs = a->off_chobs; r.off_hist = a->off_hist; r.off_rew = a->off_rew;
   r.off_idx = a->off_idx; r.off_pos = a->off_pos; r.off_vel = a->off_vel; r.off_fp = a->off_fp;
   r.H = a->H; r.episode = a->episode; r.eps = a->eps; r.vel = a->vel; r.pos_y = a->pos_y;
+  r.pf = a->pf; r.pf_threshold = a->pf_threshold; r.pf_penalty = a->pf_penalty;
   return r;
 }
 
@@ -431,6 +432,21 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
+      if constexpr (RICH && !CH) {
+        // proportional fairness (test_env.py:215-222, my_step only): a transmitter that collided more than
+        // pf_threshold slots in a row is paid pf_penalty; a successful transmission resets its counter
+        const LateRichArgs lr = (LateRichArgs)((unsigned long long)lp + kRichArgOffset);
+        int32_t* const pf = lr->pf;
+        if (pf && !(EXTRA && p.design)) {
+          if (c > 1) {
+            const int pc = pf[bN + lane];
+            if (pc > lr->pf_threshold) rw = lr->pf_penalty;
+            pf[bN + lane] = pc + 1;
+          } else {
+            pf[bN + lane] = 0;
+          }
+        }
+      }
       void* const rew_out = lp->rew_out;
       if (rew_out) {
         if constexpr (OUT64) static_cast<double*>(rew_out)[bN + lane] = rw;

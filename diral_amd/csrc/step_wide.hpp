@@ -480,6 +480,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 
   // ---- P2 (first VPL waves): reward per transmitter, metric partials, positions --
   if (tid < NPAD) {
+    const unsigned long long late2 = late_kernarg_base();         // late-bound arguments: see step_fast64.hpp
     const int u = tid;
     double rw = 0.0, prr = 0.0;
     int sole = 0, coll = 0;
@@ -494,10 +495,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { rw = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
+      if constexpr (RICH && !CH) {                                             // proportional fairness, as in step_fast64.hpp
+        const LateRichArgs lr = (LateRichArgs)(late2 + kRichArgOffset);
+        int32_t* const pf = lr->pf;
+        if (pf && !(EXTRA && p.design)) {
+          if (c > 1) {
+            const int pc = pf[bN + u];
+            if (pc > lr->pf_threshold) rw = lr->pf_penalty;
+            pf[bN + u] = pc + 1;
+          } else {
+            pf[bN + u] = 0;
+          }
+        }
+      }
     }
     // (RICH: also for a vehicle whose action was rejected - the output phase reads the
     // reward column of the state back from rew_out, which therefore must be defined)
-    const LateFastArgs lp2 = (LateFastArgs)late_kernarg_base();   // late-bound arguments: see step_fast64.hpp
+    const LateFastArgs lp2 = (LateFastArgs)late2;
     void* const rew_out2 = lp2->rew_out;
     if (u < N && (RICH || a >= 0) && rew_out2) {
       if constexpr (OUT64) static_cast<double*>(rew_out2)[bN + u] = rw;

@@ -165,6 +165,8 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
     assert np.array_equal(st["y"], oe["y"])
     assert np.array_equal(st["la"].astype(np.int64), oe["la"])
     assert np.array_equal(env.info_age(T - 1).cpu().numpy(), orc.info_age(T - 1))
+    if cfg.proportional_fair and mode == STEP_MY_STEP and sticky >= 0.9 and T >= 40:
+        assert oe["pf"].max() > 10                    # the threshold was crossed: the penalty branch ran
     m, om = env.metrics().cpu().numpy(), orc.metrics()
     assert np.array_equal(m[:, [0, 2, 3]], om[:, [0, 2, 3]])                # counts: exact
     assert np.allclose(m[:, 1], om[:, 1], rtol=1e-12, atol=1e-9)            # float sums: order differs
@@ -214,6 +216,19 @@ def test_ragged_sizes_vs_oracle(N, A, L):
 
 def test_rd5_and_proportional_fair_vs_oracle():
     random_rollout(c2_config(reward_design=5, proportional_fair=True), B=16, T=40, seed=7, sticky=0.95)
+
+
+@pytest.mark.parametrize("N,A", [(64, 32), (20, 4), (128, 64), (256, 16), (90, 9)])
+@pytest.mark.parametrize("mode", [STEP_MY_STEP, STEP_MY_STEP_CH, STEP_DESIGN])
+def test_proportional_fairness_on_the_specialised_kernels(N, A, mode):
+    """test_env.py:215-222: a transmitter that collided more than pf_threshold (10) slots in a row
+    is paid pf_penalty (-10), a success resets its counter - only in my_step.  Sticky actions so the
+    counters pass the threshold; specialised kernels (RICH) vs the oracle, incl. the pf counters."""
+    from diral_amd.config import KERNEL_FAST64, KERNEL_WIDE
+    L = 12.0 * N + 100
+    cfg = bench_config(N, A, L, reward_design=2 if mode != STEP_MY_STEP else 1, proportional_fair=True)
+    random_rollout(cfg, B=6, T=45, seed=900 + N + mode, mode=mode, sticky=0.97, track_prr=False,
+                   expect_kernel=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE)
 
 
 def test_f32_output_is_cast_of_f64():
@@ -1150,6 +1165,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     # every cheap State flag at once (the g1_flags_all shape) + State.type 1 + arrival stamps
     flags = dict(add_reward=True, add_index=True, add_velocity=True, add_position=True, add_channel_obs=True)
     for state, extra, want in ((flags, dict(enable_fingerprint=True), fam | KERNEL_RICH),
+                               ({}, dict(proportional_fair=True), fam | KERNEL_RICH),
                                (dict(action_index="real", add_channel_obs=True), {}, fam | KERNEL_RICH),
                                (dict(add_action=False), {}, fam | KERNEL_RICH),
                                (flags, dict(track_arrival=True), fam | KERNEL_RICH | KERNEL_EXTRA)):
@@ -1161,7 +1177,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         e2.check()
     # what stays on the general kernel
     for state, extra in ((dict(add_positional_dist=True), {}), (dict(add_positional_dist_type=1), {}),
-                         ({}, dict(proportional_fair=True)), (dict(add_positional_dist_piggy=False), {})):
+                         ({}, dict(track_prr=True)), (dict(add_positional_dist_piggy=False), {})):
         c3 = bench_config(N, A, L, State=state, **extra)
         e3 = make_env(c3, 4, dtype=torch.float64)
         e3.reset_topology(seed=5)
