@@ -76,8 +76,8 @@ struct FastParams {
 // argument to the kernel entry and then keeps (or spills, through v_writelane / v_readlane - VALU
 // instructions inside the hot loops) the SGPRs of values only the last phases use: output
 // pointers, section offsets.  Reading such fields through the kernarg segment pointer behind an
-// opaque asm pins their s_load to the point of use instead (measured on the RICH instantiation:
-// 63 -> see profiles/r02/resource_usage.txt SGPR spills).
+// opaque asm pins their s_load to the point of use instead (SGPR spills of every instantiation:
+// profiles/r02/resource_usage.txt).
 struct RichParams;
 typedef const __attribute__((address_space(4))) FastParams* LateFastArgs;
 __device__ inline unsigned long long late_kernarg_base() {

@@ -16,7 +16,9 @@ from diral_amd.config import bench_config, STEP_MY_STEP, STEP_MY_STEP_CH
 pytestmark = pytest.mark.gpu
 
 
-def soak(N, A, L, B, T, mode, vary, rc=250.0, every=250):
+def soak(N, A, L, B, T, mode, vary, rc=250.0, every=250, rich=False):
+    """rich: the reference's two-call pattern (`obs, rews = env.my_step*(a, t)`; `env.obtain_state(obs, a,
+    rews)`) on the RICH instantiations, channel observation compared as well."""
     from diral_amd.vec_env import VecV2VEnv
     from oracle.oracle import Oracle, SQ_IEEE
     cfg = bench_config(N, A, L, mobility_vary=vary, communication_range=rc)
@@ -30,7 +32,12 @@ def soak(N, A, L, B, T, mode, vary, rc=250.0, every=250):
         a = rng.integers(0, A, size=(B, N)).astype(np.int32)
         if prev is not None and t % 2: a = np.where(rng.random((B, N)) < 0.8, prev, a)
         prev = a
-        obs, rew, done = env.step(a, t)
+        if rich:
+            a_dev = env._actions(a)
+            chobs, rew = (env.my_step_ch if mode == STEP_MY_STEP_CH else env.my_step)(a_dev, t)
+            obs = env.obtain_state(chobs, a_dev, rew)
+        else:
+            obs, rew, done = env.step(a, t)
         o_rew, o_ch = orc.step(mode, a, t)
         if t % 25 == 24:
             d = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
@@ -40,18 +47,22 @@ def soak(N, A, L, B, T, mode, vary, rc=250.0, every=250):
             torch.cuda.synchronize()
             assert np.array_equal(obs.cpu().numpy(), st), (N, t)
             assert np.array_equal(rew.cpu().numpy(), o_rew), (N, t)
+            if rich:
+                assert np.array_equal(chobs.cpu().numpy(), o_ch), (N, t)
     s, oe = env.export_state(), orc.export()
     assert np.array_equal(s["seq"].cpu().numpy(), oe["seq"]) and np.array_equal(s["x"].cpu().numpy(), oe["x"])
     assert np.array_equal(s["pos_x"].cpu().numpy(), oe["pos_x"]) and np.array_equal(s["age"].cpu().numpy(), np.minimum(oe["age"], 255))
     m, mo = env.metrics().cpu().numpy(), orc.metrics()
     assert np.array_equal(m[:, [0, 2, 3]], mo[:, [0, 2, 3]])
     env.check()
-    print("soak ok N=%d A=%d L=%g B=%d T=%d mode=%d vary=%s rc=%g  %.1fs" % (N, A, L, B, T, mode, vary, rc, time.time() - t0), flush=True)
+    print("soak ok N=%d A=%d L=%g B=%d T=%d mode=%d vary=%s rc=%g rich=%s  %.1fs" % (N, A, L, B, T, mode, vary, rc, rich, time.time() - t0), flush=True)
 
 SCHEDULES = [(64, 32, 2000.0, 8, 6000, STEP_MY_STEP, True, 250.0), (64, 32, 2000.0, 8, 3000, STEP_MY_STEP_CH, False, 250.0),
              (64, 32, 6000.0, 6, 3000, STEP_MY_STEP, True, 120.0), (256, 64, 4000.0, 3, 1200, STEP_MY_STEP, False, 250.0),
              (128, 64, 4000.0, 4, 2000, STEP_MY_STEP, True, 250.0), (128, 64, 9000.0, 3, 1500, STEP_MY_STEP_CH, True, 150.0),
              (200, 40, 12000.0, 2, 1200, STEP_MY_STEP, True, 140.0)]
+RICH_SCHEDULES = [(64, 32, 2000.0, 8, 3000, STEP_MY_STEP, True, 250.0), (48, 16, 1500.0, 6, 2000, STEP_MY_STEP_CH, False, 200.0),
+                  (128, 64, 4000.0, 4, 1500, STEP_MY_STEP, True, 250.0), (256, 64, 4000.0, 2, 800, STEP_MY_STEP, False, 250.0)]
 
 
 @pytest.mark.parametrize("N,A,L,B,T,mode,vary,rc", SCHEDULES)
@@ -59,7 +70,14 @@ def test_soak_vs_oracle(N, A, L, B, T, mode, vary, rc):
     soak(N, A, L, B, T, mode, vary, rc)
 
 
+@pytest.mark.parametrize("N,A,L,B,T,mode,vary,rc", RICH_SCHEDULES)
+def test_soak_two_call_pattern_vs_oracle(N, A, L, B, T, mode, vary, rc):
+    soak(N, A, L, B, T, mode, vary, rc, rich=True)
+
+
 if __name__ == "__main__":
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     for (N, A, L, B, T, mode, vary, rc) in SCHEDULES:
         soak(N, A, L, B, T * k, mode, vary, rc, every=250 * k)
+    for (N, A, L, B, T, mode, vary, rc) in RICH_SCHEDULES:
+        soak(N, A, L, B, T * k, mode, vary, rc, every=250 * k, rich=True)
