@@ -216,31 +216,114 @@ __global__ void sps_window_kernel(size_t total, int A, const T* chobs, const int
   win[e] = sps_rssi_from_chobs((double)chobs[e], (int)(e - i * A) == actions[i]);
 }
 
-constexpr int kSpsFusedMaxA = 64;
+// ---- wave-cooperative SPS step (A <= 256) ------------------------------------------------
+// Re-selection is rare (counter expiry x 20 % = 1.7 % of the agents per slot), but with one
+// thread per agent almost every wave holds one such lane and then runs at the speed of that
+// lane's serial window scan.  Here the 64 lanes of the wave serve each of their re-selecting
+// agents together: lane s holds subframe s (+64c) of that agent's window - one coalesced row
+// read, one log10 per lane - the threshold loop is a ballot + popcount, and the stable-sort
+// position of every candidate is counted against the candidates' values read lane by lane.
+constexpr int kSpsWaveMaxA = 256;
 
-// The two steps above in one launch: the window is only built (in private memory) by the few agents
-// that re-select this slot - no [agents][A] float64 array, no log10 for everybody.
-template <typename T>
-__global__ void sps_step_chobs_kernel(int agents, int A, const T* chobs, const int32_t* actions_in,
-                                      int32_t* prev_action, int32_t* counter, double threshold, double inc_db,
-                                      double keep_prob, const int32_t* draw_counter, const double* draw_keep,
-                                      const int32_t* draw_choice, uint64_t seed, int32_t* actions_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= agents) return;
-  int action = prev_action[i];
-  int cnt = counter[i];
-  if (sps_advance(i, cnt, keep_prob, draw_counter, draw_keep, seed)) {
-    double wl[kSpsFusedMaxA];
-    const T* row = chobs + (size_t)i * A;
-    const int own = actions_in[i];
-    for (int s = 0; s < A; ++s) wl[s] = sps_rssi_from_chobs((double)row[s], s == own);
-    const unsigned int r = draw_choice ? (unsigned int)draw_choice[i]
-                                       : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
-    action = sps_choose([&](int s) { return wl[s]; }, A, action, threshold, inc_db, r);
-    prev_action[i] = action;
+__device__ inline double sps_readlane(double v, int j) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+
+// choose_new_resource (algorithms/v2x_sps.py:24-74) for ONE agent by the whole wave; every argument
+// but `w` / `lane` is wave-uniform, and so is the result.
+template <int NC>
+__device__ inline int sps_choose_wave(const double (&w)[NC], int lane, int A, int prev, double threshold, double inc_db,
+                                      unsigned int r) {
+  const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
+  double thr_next = threshold, thr = threshold;
+  unsigned long long el[NC];                                       // sA: candidates of chunk c
+  int n_sa = 0;
+  for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
+    thr = thr_next;
+    n_sa = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int s = lane + 64 * c;
+      el[c] = __ballot(s < A && s != prev && w[c] < thr);
+      n_sa += __popcll(el[c]);
+    }
+    thr_next = thr + inc_db;                                       // tmp_threshold += self.inc_dB
+    if (!((double)n_sa < min_sA)) break;
   }
-  counter[i] = cnt;
-  actions_out[i] = action;
+  const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
+  int need = (int)min_len;
+  if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
+  if (need < 1) need = 1;
+  const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
+  // position of every candidate in sorted(sA.items(), key=value): a stable sort, i.e. ordered by
+  // (value, subframe)
+  int rank[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) rank[c] = 0;
+#pragma unroll
+  for (int cj = 0; cj < NC; ++cj) {
+    unsigned long long m = el[cj];
+    while (m) {
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      const double wj = sps_readlane(w[cj], j);
+      const int sj = j + 64 * cj;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) rank[c] += (wj < w[c] || (wj == w[c] && sj < lane + 64 * c)) ? 1 : 0;
+    }
+  }
+  int chosen = prev;                                               // (only if sA stayed empty: cannot happen)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const unsigned long long hit = __ballot(((el[c] >> lane) & 1ull) && rank[c] == pick);
+    if (hit) chosen = __builtin_ctzll(hit) + 64 * c;
+  }
+  return chosen;
+}
+
+// SemiPersistentScheduling.step for 64 agents per wave.  CHOBS: `src` is the env's channel observation
+// [agents][A] (T) and the window is built on the fly; otherwise `src` is the window itself (double).
+template <int NC, typename T, bool CHOBS>
+__global__ void sps_step_wave_kernel(int agents, int A, const T* src, const int32_t* actions_in, int32_t* prev_action,
+                                     int32_t* counter, double threshold, double inc_db, double keep_prob,
+                                     const int32_t* draw_counter, const double* draw_keep, const int32_t* draw_choice,
+                                     uint64_t seed, int32_t* actions_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = i < agents;
+  int action = live ? prev_action[i] : 0;
+  int cnt = live ? counter[i] : 1;
+  const bool resel = live && sps_advance(i, cnt, keep_prob, draw_counter, draw_keep, seed);
+  unsigned int r = 0;
+  int own = -1;
+  if (resel) {
+    r = draw_choice ? (unsigned int)draw_choice[i] : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
+    if constexpr (CHOBS) own = actions_in[i];
+  }
+  unsigned long long todo = __ballot(resel);
+  const int i0 = i - lane;
+  while (todo) {
+    const int j = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const T* row = src + (size_t)(i0 + j) * A;
+    const int prev_j = __builtin_amdgcn_readlane(action, j);
+    const int own_j = __builtin_amdgcn_readlane(own, j);
+    const unsigned int r_j = (unsigned int)__builtin_amdgcn_readlane((int)r, j);
+    double w[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int s = lane + 64 * c;
+      w[c] = 0.0;
+      if (s < A) w[c] = CHOBS ? sps_rssi_from_chobs((double)row[s], s == own_j) : (double)row[s];
+    }
+    const int ch = sps_choose_wave<NC>(w, lane, A, prev_j, threshold, inc_db, r_j);
+    if (lane == j) action = ch;
+  }
+  if (resel) prev_action[i] = action;                                 // v2x_sps.py:98
+  if (live) {
+    counter[i] = cnt;
+    actions_out[i] = action;
+  }
 }
 
 // np.sum over one row in NumPy's order (numpy/_core/src/umath/loops_utils.h pairwise_sum): fewer

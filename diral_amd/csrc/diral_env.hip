@@ -615,9 +615,20 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
                    int32_t* actions_out, void* stream) {
   if (agents < 1 || num_channels < 1 || !selection_window || !prev_action || !counter || !actions_out)
     return DIRAL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(sps_step_kernel, dim3(blocks((size_t)agents, 128)), dim3(128), 0, (hipStream_t)stream, agents,
-                     num_channels, selection_window, prev_action, counter, rssi_threshold, inc_db, keep_prob,
-                     draw_counter, draw_keep, draw_choice, seed, actions_out);
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(blocks((size_t)agents, 256)), t(256);
+#define DIRAL_SPS_WAVE(NC)                                                                                           \
+  hipLaunchKernelGGL((sps_step_wave_kernel<NC, double, false>), g, t, 0, st, agents, num_channels, selection_window, \
+                     (const int32_t*)nullptr, prev_action, counter, rssi_threshold, inc_db, keep_prob, draw_counter, \
+                     draw_keep, draw_choice, seed, actions_out)
+  if (num_channels <= 64) DIRAL_SPS_WAVE(1);
+  else if (num_channels <= 128) DIRAL_SPS_WAVE(2);
+  else if (num_channels <= kSpsWaveMaxA) DIRAL_SPS_WAVE(4);
+  else                                                            // one thread per agent
+    hipLaunchKernelGGL(sps_step_kernel, dim3(blocks((size_t)agents, 128)), dim3(128), 0, st, agents, num_channels,
+                       selection_window, prev_action, counter, rssi_threshold, inc_db, keep_prob, draw_counter, draw_keep,
+                       draw_choice, seed, actions_out);
+#undef DIRAL_SPS_WAVE
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 
@@ -667,16 +678,23 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
   if (agents < 1 || num_channels < 1 || !chobs || !actions || !prev_action || !counter || !actions_out)
     return DIRAL_ERR_BAD_ARG;
   if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
-  if (num_channels > kSpsFusedMaxA) return DIRAL_ERR_UNSUPPORTED;   // use window_from_chobs + sps_step
-  const dim3 g(blocks((size_t)agents, 128)), t(128);
-  if (chobs_dtype == DIRAL_F64)
-    hipLaunchKernelGGL(sps_step_chobs_kernel<double>, g, t, 0, (hipStream_t)stream, agents, num_channels,
-                       static_cast<const double*>(chobs), actions, prev_action, counter, rssi_threshold, inc_db,
-                       keep_prob, draw_counter, draw_keep, draw_choice, seed, actions_out);
-  else
-    hipLaunchKernelGGL(sps_step_chobs_kernel<float>, g, t, 0, (hipStream_t)stream, agents, num_channels,
-                       static_cast<const float*>(chobs), actions, prev_action, counter, rssi_threshold, inc_db,
-                       keep_prob, draw_counter, draw_keep, draw_choice, seed, actions_out);
+  if (num_channels > kSpsWaveMaxA) return DIRAL_ERR_UNSUPPORTED;   // use window_from_chobs + sps_step
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(blocks((size_t)agents, 256)), t(256);
+#define DIRAL_SPS_WAVE(NC, T)                                                                                          \
+  hipLaunchKernelGGL((sps_step_wave_kernel<NC, T, true>), g, t, 0, st, agents, num_channels, static_cast<const T*>(chobs), \
+                     actions, prev_action, counter, rssi_threshold, inc_db, keep_prob, draw_counter, draw_keep,        \
+                     draw_choice, seed, actions_out)
+#define DIRAL_SPS_WAVE_T(T)                          \
+  do {                                               \
+    if (num_channels <= 64) DIRAL_SPS_WAVE(1, T);    \
+    else if (num_channels <= 128) DIRAL_SPS_WAVE(2, T); \
+    else DIRAL_SPS_WAVE(4, T);                       \
+  } while (0)
+  if (chobs_dtype == DIRAL_F64) DIRAL_SPS_WAVE_T(double);
+  else DIRAL_SPS_WAVE_T(float);
+#undef DIRAL_SPS_WAVE_T
+#undef DIRAL_SPS_WAVE
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 

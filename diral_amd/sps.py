@@ -92,7 +92,7 @@ class SpsPolicy:
                         draw_choice=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One SPS step straight from the env's channel observation [B, N, A] (float32 / float64) and
         the actions of the slot that produced it: `window_from_chobs` + `step` in ONE launch, with the
-        window built only by the agents that re-select (`diral_sps_step_chobs`).  A <= 64."""
+        window built only for the agents that re-select (`diral_sps_step_chobs`).  A <= 256."""
         if chobs.dtype not in (torch.float32, torch.float64) or tuple(chobs.shape) != (self.B, self.N, self.A):
             raise ValueError("chobs must be float32/float64 [B, N, A]")
         c = chobs.contiguous()

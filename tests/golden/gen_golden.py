@@ -452,7 +452,7 @@ def main_driver():
                     ia_penalty_enable=True, ia_penalty_threshold=2)
 
 
-def run_sps_case(name, n_agents, A, T, threshold, seed, level_lo, level_hi, tie_step):
+def run_sps_case(name, n_agents, A, T, threshold, seed, level_lo, level_hi, tie_step, keep_lo=0.0):
     """The reference's SPS agent (algorithms/v2x_sps.py) itself, one object per agent, fed
     recorded selection windows; its three global-RNG calls are mocked with recorded draws:
       random.randint(a, b)  -> the recorded counter / initial values
@@ -489,7 +489,7 @@ def run_sps_case(name, n_agents, A, T, threshold, seed, level_lo, level_hi, tie_
 
     codes = np.zeros((T, n_agents, A), np.int16)
     d_counter = rng.integers(5, 17, size=(T, n_agents)).astype(np.int32)
-    d_keep = rng.random((T, n_agents))
+    d_keep = keep_lo + (1.0 - keep_lo) * rng.random((T, n_agents))   # keep_lo > 0: more re-selections per recorded step
     d_choice = rng.integers(0, 1 << 20, size=(T, n_agents)).astype(np.int32)
     actions = np.zeros((T, n_agents), np.int32)
     counters = np.zeros((T, n_agents), np.int32)
@@ -534,6 +534,16 @@ def main_sps():
     # sA stays empty while len(sA) < 0.2 ... the reference loops forever there, so A >= 2)
     run_sps_case("s3_sps_small_window", n_agents=24, A=3, T=200, threshold=-110.0, seed=83,
                  level_lo=-120, level_hi=-100, tie_step=0.5)
+    # wide windows: exactly one wavefront of subframes, then 2 and 4 subframes per lane of the
+    # wave-cooperative kernel (csrc/aux_kernels.hpp), then beyond it (one thread per agent)
+    run_sps_case("s4_sps_window64", n_agents=70, A=64, T=40, threshold=-110.0, seed=84,
+                 level_lo=-125, level_hi=-95, tie_step=1.0, keep_lo=0.7)
+    run_sps_case("s5_sps_window100", n_agents=30, A=100, T=60, threshold=-110.3, seed=85,
+                 level_lo=-460, level_hi=-400, tie_step=0.25, keep_lo=0.7)
+    run_sps_case("s6_sps_window200", n_agents=20, A=200, T=60, threshold=-110.0, seed=86,
+                 level_lo=-118, level_hi=-102, tie_step=1.0, keep_lo=0.7)
+    run_sps_case("s7_sps_window300", n_agents=12, A=300, T=70, threshold=-110.0, seed=87,
+                 level_lo=-240, level_hi=-200, tie_step=0.5, keep_lo=0.7)
 
 
 if __name__ == "__main__":

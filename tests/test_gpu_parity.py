@@ -518,20 +518,22 @@ def test_secondary_observation_modes_vs_oracle(N, A, full, ptype):
     random_rollout(cfg, B=5, T=26, seed=500 + N + ptype)
 
 
-@pytest.mark.parametrize("name", ["s1_sps_int_threshold", "s2_sps_frac_threshold", "s3_sps_small_window"])
+@pytest.mark.parametrize("name", ["s1_sps_int_threshold", "s2_sps_frac_threshold", "s3_sps_small_window", "s4_sps_window64",
+                                  "s5_sps_window100", "s6_sps_window200", "s7_sps_window300"])
 def test_sps_policy_matches_the_reference_fixtures(name):
     """the SPS baseline on the device against fixtures recorded from the
     reference's own algorithms/v2x_sps.py (tests/golden/gen_golden.py `sps`: one
     SemiPersistentScheduling object per agent, its random.randint / random.random /
     random.choice calls mocked with the recorded draws): action, reselection counter and
     prev_action after every step, incl. stable-sort ties, repeated 3 dB threshold raises
-    and a non-integer threshold."""
+    and a non-integer threshold; s4-s7: windows of 64 / 100 / 200 subframes (1, 2, 4 per lane of the
+    wave-cooperative kernel) and 300 (one thread per agent)."""
     import os
     from diral_amd.sps import SpsPolicy
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     A = int(g["A"])
     T, n = g["actions"].shape
-    assert T * n >= 200 and int(g["reselections"]) >= 50
+    assert T * n >= 200 and int(g["reselections"]) >= 40
     pol = SpsPolicy(1, n, A, rssi_threshold=float(g["threshold"]), seed=5)
     pol.prev_action.copy_(torch.as_tensor(g["init_prev"]).view(1, n))
     pol.counter.copy_(torch.as_tensor(g["init_counter"]).view(1, n))
@@ -570,14 +572,15 @@ def test_sps_device_draws_follow_the_reference_distributions():
     assert abs(resel / expired - 0.2) < 0.03, resel / expired
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_sps_from_channel_obs_fused_equals_two_step_path(dtype):
+@pytest.mark.parametrize("dtype,N,A", [(torch.float32, 64, 32), (torch.float64, 64, 32), (torch.float32, 24, 100),
+                                       (torch.float64, 20, 160)])
+def test_sps_from_channel_obs_fused_equals_two_step_path(dtype, N, A):
     """`diral_sps_step_chobs` (window + decision in one launch, window built only by re-selecting
     agents) == `diral_sps_window_from_chobs` + `diral_sps_step` with the same draws, decision for
     decision; and the device window is the documented formula (rssi_from_channel_obs in torch)."""
     from diral_amd.sps import SpsPolicy, rssi_from_channel_obs
-    cfg = bench_config(64, 32, 2000.0)
-    B, N, A = 16, 64, 32
+    cfg = bench_config(N, A, 2000.0)
+    B = 16
     env = make_env(cfg, B, dtype=dtype)
     env.reset_topology(seed=12)
     fused, two = SpsPolicy(B, N, A, seed=4), SpsPolicy(B, N, A, seed=4)
@@ -600,7 +603,7 @@ def test_sps_from_channel_obs_fused_equals_two_step_path(dtype):
         assert torch.equal(fused.counter, two.counter) and torch.equal(fused.prev_action, two.prev_action), t
         nres += int((a1 != acts).sum())
         acts = a1
-    assert nres > 200                                    # re-selections really happened
+    assert nres > 3 * N                                  # re-selections really happened
     env.check()
 
 
