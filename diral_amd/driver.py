@@ -84,6 +84,9 @@ class DriverLoop:
         # The torch statement below stays: it is what runs on the CPU (oracle-backed tests) and what the
         # kernel is tested against.
         self.device_shaping = (hasattr(env, "lib") and hasattr(env, "_stream")) if device_shaping is None else device_shaping
+        # the env rotates >= 2 output-buffer sets (VecV2VEnv(io_ring=2)): what a slot returns stays intact
+        # during the next slot, no defensive copies
+        self._own_outputs = getattr(env, "io_ring", 1) < 2
         self.episode = 0
         self.N = env.get_total_users()
         self.A = env.get_action_space()
@@ -130,8 +133,10 @@ class DriverLoop:
         else:
             obs, reward = env.my_step(action, time_step)                     # :146
         reward_ret = reward                      # as returned: what main_test.py:164 hands to obtain_state
-        reward = self._t(reward).clone()
-        raw = reward.clone()
+        reward = self._t(reward)
+        if self._own_outputs:
+            reward = reward.clone()
+        raw = reward.clone() if self._own_outputs else reward    # (nothing below writes `reward` in place)
         out: Dict[str, Any] = {}
         need_ia = self.ia_averaging if want_ia is None else want_ia
         ia_penalty = None
@@ -147,11 +152,13 @@ class DriverLoop:
                 self._sum_ia_prev = ia_sum
                 out["ia_penalty"] = ia_penalty
         if fused_state is not None:
-            next_state = fused_state.clone()
+            next_state = fused_state.clone() if self._own_outputs else fused_state
         else:
             # (the returned tensors, unmodified: VecV2VEnv then serves the state its fused launch
             # already built instead of a second launch)
-            next_state = self._t(env.obtain_state(obs, action, reward_ret, self.episode, self.eps)).clone()   # :164
+            next_state = self._t(env.obtain_state(obs, action, reward_ret, self.episode, self.eps))   # :164
+            if self._own_outputs:
+                next_state = next_state.clone()
         a = self._actions(action).to(reward.device)
         if self.device_shaping:
             shaped, sum_r, collision, pen, ia_sum = self._shape_on_device(reward, a, out.get("ia"))

@@ -64,12 +64,18 @@ class VecV2VEnv:
         returns it when it is called with exactly what ``my_step*`` returned and
         nothing changed the env in between (otherwise it launches
         ``diral_env_observe`` as before).
+    io_ring : int
+        number of output-buffer sets (state, reward, done, channel observation) the step
+        calls rotate through.  1 (default): the returned tensors are overwritten by the next
+        step.  K > 1: they stay intact for K - 1 further steps - a slot loop that needs
+        ``state`` and ``next_state`` side by side (main_test.py:207-214, memory.add) takes
+        ``io_ring=2`` instead of cloning 13 KB per env and slot.
     """
 
     def __init__(self, cfg: Union[EnvConfig, Mapping[str, Any]], batch: int = 1,
                  device: Union[str, int, torch.device] = "cuda:0",
                  out_dtype: torch.dtype = torch.float32, step_mode: Union[str, int] = "my_step",
-                 env_offset: int = 0, speculate_state: bool = True):
+                 env_offset: int = 0, speculate_state: bool = True, io_ring: int = 1):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_dict(cfg)
         cfg.validate()
@@ -104,11 +110,17 @@ class VecV2VEnv:
             raise DiralError(st, "diral_env_create")
         assert self.lib.diral_env_state_space(ctypes.byref(self._ccfg)) == self.S
         # I/O tensors are allocated once; step() never allocates
+        if int(io_ring) < 1:
+            raise ValueError("io_ring must be >= 1")
+        self.io_ring = int(io_ring)
         with torch.cuda.device(self.device):
-            self._obs = torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device)
-            self._rew = torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device)
-            self._done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
-            self._chobs: Optional[torch.Tensor] = None
+            self._ring = [dict(obs=torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device),
+                               rew=torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device),
+                               done=torch.zeros((self.B,), dtype=torch.uint8, device=self.device), chobs=None)
+                          for _ in range(self.io_ring)]
+        self._ri = 0
+        self._obs, self._rew, self._done = self._ring[0]["obs"], self._ring[0]["rew"], self._ring[0]["done"]
+        self._chobs: Optional[torch.Tensor] = None
         self.t = 0
         self.env_offset = 0
         if env_offset:
@@ -234,8 +246,12 @@ class VecV2VEnv:
 
     def _step(self, mode: int, actions: torch.Tensor, t: int, episode: float = 0.0, eps: float = 1.0,
               want_chobs: bool = False, want_obs: bool = True):
-        if want_chobs and self._chobs is None:
-            self._chobs = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+        if self.io_ring > 1:
+            self._ri = (self._ri + 1) % self.io_ring
+        slot = self._ring[self._ri]
+        if want_chobs and slot["chobs"] is None:
+            slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+        self._obs, self._rew, self._done, self._chobs = slot["obs"], slot["rew"], slot["done"], slot["chobs"]
         self._spec = None
         st = self.lib.diral_env_step(self._h, mode, _ptr(actions), int(t),
                                      _ptr(self._obs) if (want_obs and self.S > 0) else None,

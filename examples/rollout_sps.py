@@ -34,7 +34,8 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cfg = c2_config()
-    env, start = make_sharded_env(cfg, args.envs, out_dtype=torch.float32)
+    # io_ring=2: state and next_state of consecutive slots live in two alternating output sets (no copies)
+    env, start = make_sharded_env(cfg, args.envs, out_dtype=torch.float32, io_ring=2)
     env.reset_topology(seed=1234)                     # one global seed: the shard offset selects the envs
     loop = DriverLoop(env, global_reward_avg=True, episode_interval=cfg.episode_interval,
                       fused=args.fused and args.policy == "random")

@@ -134,3 +134,37 @@ def test_device_reward_shaping_equals_the_torch_statement(N, dtype):
                 lp.end_episode(np.full((B, N), 3, np.uint8))
     assert torch.equal(loops[0]._pen_counter.long(), loops[1]._pen_counter.long())
     assert int(loops[0]._pen_counter.max()) > 2          # the threshold penalty really fired
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_io_ring_keeps_the_previous_slot_intact_without_copies(fused):
+    """VecV2VEnv(io_ring=2): the step calls alternate between two output-buffer sets, DriverLoop
+    makes no defensive copies, and (state, next_state) of consecutive slots (what memory.add takes,
+    main_test.py:207-214) are still two intact tensors; same values as the copying loop."""
+    from diral_amd.config import c2_config
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = c2_config()
+    B, N, A = 12, 64, 32
+    e1, e2 = VecV2VEnv(cfg, batch=B), VecV2VEnv(cfg, batch=B, io_ring=2)
+    l1, l2 = (DriverLoop(e, global_reward_avg=True, fused=fused) for e in (e1, e2))
+    assert l1._own_outputs and not l2._own_outputs
+    for e in (e1, e2):
+        e.reset_topology(seed=77)
+    rng = np.random.default_rng(3)
+    a0 = torch.as_tensor(rng.integers(0, A, size=(B, N)).astype(np.int32), device="cuda:0")
+    s1, s2 = l1.bootstrap(a0), l2.bootstrap(a0)
+    prev = None
+    for t in range(30):
+        a = torch.as_tensor(rng.integers(0, A, size=(B, N)).astype(np.int32), device="cuda:0")
+        o1, o2 = l1.slot(a, t), l2.slot(a, t)
+        for k in ("next_state", "reward", "raw_reward", "sum_r", "collision"):
+            assert torch.equal(o1[k], o2[k]), (k, t)
+        if prev is not None:
+            # the previous slot of the ring env: still what the copying loop holds
+            assert o2["next_state"].data_ptr() != prev[1]["next_state"].data_ptr()
+            assert torch.equal(prev[0]["next_state"], prev[1]["next_state"]), t
+            assert torch.equal(prev[0]["raw_reward"], prev[1]["raw_reward"]), t
+        prev = (o1, o2)
+    with pytest.raises(ValueError):
+        VecV2VEnv(cfg, batch=1, io_ring=0)
