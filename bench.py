@@ -273,6 +273,40 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
     return env, res
 
 
+def rollout_sps(device, envs=4096, slots=400, warm=80):
+    """SURVEY 8f rows 1 + 3 together, end to end: the driver's slot loop (env step with channel
+    observation and state -> reward shaping -> SPS policy picking the next actions), everything
+    on the device, three launches per slot.  Not the metric - a reported side measurement."""
+    from diral_amd import c2_config
+    from diral_amd.driver import DriverLoop
+    from diral_amd.sps import SpsPolicy
+    cfg = c2_config()
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
+    env.reset_topology(seed=GLOBAL_SEED)
+    loop = DriverLoop(env, global_reward_avg=True, episode_interval=cfg.episode_interval)
+    pol = SpsPolicy(env.B, env.N, env.A, device=device, seed=0)
+    loop.bootstrap(pol.prev_action)
+    actions = pol.prev_action.clone()
+    t0 = None
+    for t in range(warm + slots):
+        if t == warm:
+            torch.cuda.synchronize(device)
+            env.metrics(clear=True)
+            t0 = time.perf_counter()
+        out = loop.slot(actions, t)
+        actions = pol.step_from_chobs(env._chobs, actions)
+        if out["episode_end"]:
+            loop.end_episode()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    m = env.metrics().sum(0)
+    return {"what": "examples/rollout_sps.py in short: c2 env (my_step + obtain_state, one launch) + driver reward "
+                    "shaping + SPS policy (algorithms/v2x_sps.py) from the channel observation, %d envs, %d slots" % (envs, slots),
+            "agent_steps_per_s": envs * env.N * slots / dt, "ms_per_slot": dt / slots * 1e3,
+            "collision_fraction": float(m[3] / (m[2] + m[3]))}
+
+
 def short(res):
     """The keys of a secondary measurement that go into the JSON line."""
     return {"workload": "%s: %d-UE/%d-res, batch=%d" % (res["workload"], res["N"], res["A"], res["B"]),
@@ -399,6 +433,17 @@ def main() -> int:
                     also[key]["emit_chobs"] = kw["emit_chobs"]
                 except Exception as exc:                      # a secondary measurement never fails the line
                     also[key] = {"error": repr(exc)[:200]}
+            if args.workload == "c2" and not args.batch:
+                try:
+                    # SURVEY 8d's "converged" action distribution: each agent keeps its resource with p = 0.9
+                    e2, r2 = run_workload("c2", device, 0, 1, 300, 10, 0, args.out_dtype, args.step_mode, emit, 0.9, False)
+                    del e2
+                    also["c2_sticky_0.9"] = short(r2)
+                    also["c2_sticky_0.9"]["emit_chobs"] = emit
+                    also["rollout_sps"] = rollout_sps(device)
+                    torch.cuda.empty_cache()
+                except Exception as exc:
+                    also["rollout_sps"] = {"error": repr(exc)[:200]}
             line["also_measured"] = also
             line["cpu_baseline"] = cpu_baseline(cfg)
             line["prr_parity"] = prr_parity(cfg, device)
