@@ -43,6 +43,18 @@ struct WideLds {
 #endif
 // waves per workgroup: 8 x 16 columns (N <= 128), 8 x 32 columns (N <= 256)
 __host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DIRAL_WIDE_WAVES4; }
+#ifndef DIRAL_WIDE_PC2
+#define DIRAL_WIDE_PC2 8                 // subject columns per merge pass, N <= 128
+#endif
+#ifndef DIRAL_WIDE_PC4
+#define DIRAL_WIDE_PC4 4                 // subject columns per merge pass, N <= 256
+#endif
+// merge scratch per wave: a pass's rank words (one byte per column and viewer), then the
+// rank -> xpos table (256 doubles)
+__host__ __device__ constexpr uint32_t wide_scratch(int vpl) {
+  const uint32_t words = 64u * vpl * (vpl == 2 ? DIRAL_WIDE_PC2 : DIRAL_WIDE_PC4);
+  return words > 2048u ? words : 2048u;
+}
 // histogram row stride in 32-bit words: two 16-bit bins per word (counts <= 255), odd stride
 __host__ __device__ constexpr int wide_hist_stride(int K) { return ((K + 1) / 2) | 1; }
 // row stride of the gather-source table in elements (u32 of 4 source bytes at N <= 256, u16 of
@@ -58,7 +70,7 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   // address 2048 W, which the merge loop (one copy per wave index) folds into the immediate
   // offset of its gathers instead of adding a base register to every gather address.
   l.scratch = 0;
-  uint32_t o = 2048u * wide_waves(vpl);        // 2 KB per wave: merge words, then the rank -> xpos table
+  uint32_t o = wide_scratch(vpl) * wide_waves(vpl);        // 2 KB per wave (4 KB at 16 columns per pass)
   l.px = o;    o += 8u * npad;
   l.npx = o;   o += 8u * npad;
   l.rv = o;    o += 8u * A;
@@ -108,7 +120,13 @@ __device__ inline void max_u8x32(unsigned int (&a)[8], const unsigned int (&b)[8
 template <int NK>
 __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&b)[NK]) {
   if constexpr (NK == 4) max_u8x16(a, b);
-  else max_u8x32(a, b);
+  else if constexpr (NK == 8) max_u8x32(a, b);
+  else {
+    static_assert(NK % 8 == 0, "4, 8 or a multiple of 8 words");
+#pragma unroll
+    for (int q = 0; q < NK; q += 8)
+      max_u8x32(*reinterpret_cast<unsigned int (*)[8]>(&a[q]), *reinterpret_cast<const unsigned int (*)[8]>(&b[q]));
+  }
 }
 
 #ifndef DIRAL_WIDE_WAVECONST
@@ -268,12 +286,6 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #ifndef DIRAL_WIDE_ADDTID
 #define DIRAL_WIDE_ADDTID 1              // lane-linear write-back of the merge words with ds_write_addtid_b32 (no address VGPR: half the LDS store cycles)
 #endif
-#ifndef DIRAL_WIDE_PC2
-#define DIRAL_WIDE_PC2 8                 // subject columns per merge pass, N <= 128
-#endif
-#ifndef DIRAL_WIDE_PC4
-#define DIRAL_WIDE_PC4 4                 // subject columns per merge pass, N <= 256
-#endif
 #ifndef DIRAL_WIDE_RELOAD2
 #define DIRAL_WIDE_RELOAD2 0             // N <= 128: see DIRAL_WIDE_RELOAD4
 #endif
@@ -303,7 +315,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // NW-word vector per viewer gathered with ONE 8/16-byte read
   constexpr bool VEC = (NK != 4) || (VPL == 2 ? (DIRAL_WIDE_VEC2 != 0) : false);
   constexpr bool RELOAD = VPL == 2 ? (DIRAL_WIDE_RELOAD2 != 0) : (DIRAL_WIDE_RELOAD4 != 0);
-  static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= 2048, "a pass's rank words fill at most the wave's 2 KB of scratch");
+  static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= wide_scratch(VPL), "a pass's rank words fill at most the wave's scratch");
+  constexpr uint32_t SCR = wide_scratch(VPL);
+  static_assert(WAVES >= VPL && WAVES <= 8, "P2 runs on the first VPL waves; the merge loop has 8 per-wave copies");
   constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
   constexpr int MT = wide_mtab_stride(VPL);    // gather-source table row stride (elements)
   // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
@@ -327,10 +341,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // values live in the merge scratch of wave u / 64, which is idle until that wave - the
   // one that reads them in P2 - starts its own P3
   auto rtx_of = [&](int u) -> double* {
-    return reinterpret_cast<double*>(smem + lay.scratch + 2048u * (u >> 6)) + (u & 63);
+    return reinterpret_cast<double*>(smem + lay.scratch + SCR * (u >> 6)) + (u & 63);
   };
   auto inr_of = [&](int u) -> int* {
-    return reinterpret_cast<int*>(smem + lay.scratch + 2048u * (u >> 6) + 512u) + (u & 63);
+    return reinterpret_cast<int*>(smem + lay.scratch + SCR * (u >> 6) + 512u) + (u & 63);
   };
 
   const int b = blockIdx.x;
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   }
 
   // ---- P3: stamp + gossip merge + xpos + histogram over this wave's 16 columns ---
-  unsigned int* const sw = reinterpret_cast<unsigned int*>(smem + lay.scratch + 2048u * wave);   // merge words
+  unsigned int* const sw = reinterpret_cast<unsigned int*>(smem + lay.scratch + SCR * wave);   // merge words
   double* const xt = reinterpret_cast<double*>(sw);                                             // rank -> xpos
   const unsigned int sw_lds = __builtin_amdgcn_readfirstlane(lds_addr(sw));
   // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             for (int j = 0; j < VPL; ++j) {
 #pragma unroll
               for (int w = 0; w < NW; ++w)
-                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(2048u * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
+                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(SCR * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
                                       : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
             }
             // a transmitter's words are not written during its own resource, so all
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
-              const uvec g = W >= 0 ? *lds_at<uvec>(2048u * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
+              const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
 #pragma unroll
               for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
             }
