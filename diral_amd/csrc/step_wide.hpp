@@ -129,6 +129,22 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
   }
 }
 
+// Thermometer codes (DIRAL_WIDE_THERMO).  In steady state the lag of an entry behind its subject's
+// own sequence number is tiny (C3: <= 4, C2: <= 5, C5: <= 7 for 98 % of the entries -
+// profiles/lag_distribution.py), so a pass first tries the 8-level code c(lag) = (0xff << lag) & 0xff
+// (0: never heard): the codes form a chain under bit inclusion, the code of the smaller lag is the
+// bitwise OR, and ONE v_or_b32 merges the four columns of a word where the byte ranks take four
+// SDWA maxes.  Exact while every entry of the pass has lag <= 7 or was never heard; otherwise the
+// pass is redone with byte ranks (lag < 255), then with 32-bit keys.
+#ifndef DIRAL_WIDE_THERMO
+#define DIRAL_WIDE_THERMO 1
+#endif
+// lag bytes (0..7 exact, 12 = never heard) -> codes, four at a time: v_perm_b32 selectors 0-7 pick
+// bytes of the table {0xff, 0xfe, 0xfc, 0xf8, 0xf0, 0xe0, 0xc0, 0x80}, selector 12 yields 0x00
+__device__ inline unsigned int thermo_codes(unsigned int lag_bytes) {
+  return __builtin_amdgcn_perm(0x80c0e0f0u, 0xf8fcfeffu, lag_bytes);
+}
+
 #ifndef DIRAL_WIDE_WAVECONST
 #define DIRAL_WIDE_WAVECONST 1           // one copy of the merge loop per wave index: scratch base as an immediate offset
 #endif
@@ -622,6 +638,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
     if (kbase >= p.NR) break;
+    // one packed pass: thermometer codes (lag <= 7) or byte ranks (lag < 255); false = not exact for this pass
+    auto packed_pass = [&](auto thermo_tag) -> bool {
+    constexpr bool THERMO = decltype(thermo_tag)::value;
+    constexpr int FIN_UNROLL_L = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;   // (a pragma argument is not a capture)
     DIRAL_WCLOCK(tc0);
     // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
     //    own fresh sequence number
@@ -671,9 +691,16 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
         const unsigned int lag = t - seq[j];
-        bad = bad || (lag >= 255u && seq[j] != 0u);
-        const unsigned int rank = lag < 255u ? 255u - lag : 0u;
-        kp[(c >> 2) * VPL + j] |= rank << (8 * (c & 3));
+        if constexpr (THERMO) {
+          // lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); anything else: not exact
+          const unsigned int lagc = min(lag, 12u);
+          bad = bad || (lagc >= 8u && (lagc < 12u || seq[j] != 0u));
+          kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
+        } else {
+          bad = bad || (lag >= 255u && seq[j] != 0u);
+          const unsigned int rank = lag < 255u ? 255u - lag : 0u;
+          kp[(c >> 2) * VPL + j] |= rank << (8 * (c & 3));
+        }
         if constexpr (!RELOAD) agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
       }
     }
@@ -681,8 +708,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     }
     const bool packed_ok = (__ballot(bad) == 0ull);
     DIRAL_WCLOCK(tc1);
-
-    if (packed_ok) {
+    if (!packed_ok) return false;
+    if constexpr (THERMO) {
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kp[q] = thermo_codes(kp[q]);
+    }
+    {
       unsigned int kp0[NK];                      // the ranks before the merge
 #pragma unroll
       for (int q = 0; q < NK; ++q) kp0[q] = RELOAD ? 0u : kp[q];
@@ -716,7 +747,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             // a transmitter's words are not written during its own resource, so all
             // gathers of a step may precede all its writes
             wave_lds_order();
-            max_u8_words<NK>(kp, v);
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
 #if DIRAL_WIDE_ADDTID
             lds_store4_lane_linear(sw_lds, kp);     // sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
 #else
@@ -764,7 +800,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
               for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
             }
             wave_lds_order();
-            max_u8_words<NK>(kp, v);
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
             put();
             wave_lds_order();
           }
@@ -784,7 +825,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
 #pragma unroll
       for (int w = 0; w < NW; ++w)
-#pragma unroll FIN_UNROLL
+#pragma unroll FIN_UNROLL_L
       for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * w + cc;
         const int k = kbase + c;
@@ -825,7 +866,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
               age0[j] = own ? 0u : age0[j];
             }
             const unsigned int lag = tk_own - sq;
-            rank0[j] = lag < 255u ? 255u - lag : 0u;
+            if constexpr (THERMO) rank0[j] = lag <= 7u ? ((0xffu << lag) & 0xffu) : 0u;
+            else rank0[j] = lag < 255u ? 255u - lag : 0u;
           }
         }
 #pragma unroll
@@ -842,13 +884,20 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           const double xr = xt[rf];
           const bool upd = rf != rank0[j];
           const double xg = upd ? xr : x_cur[j];
-          const unsigned int seqf = rf ? tk_own - 255u + rf : 0u;
+          // sequence number back from the rank / from the code (lag = 8 - popcount)
+          const unsigned int seqf = rf ? (THERMO ? tk_own - 8u + (unsigned int)__popc(rf) : tk_own - 255u + rf) : 0u;
           const unsigned int wn = (seqf << 8) | (upd ? 0u : (RELOAD ? age0[j] : pick(agew, j, w, cc)));
           emit(k, kvalid, j, upd, wn, xg, tkrow, txrow);
         }
         wave_lds_order();
       }
-    } else {
+    }
+    return true;
+    };
+    bool pass_done = false;
+    if constexpr (DIRAL_WIDE_THERMO != 0) pass_done = packed_pass(std::true_type{});
+    if (!pass_done) pass_done = packed_pass(std::false_type{});
+    if (!pass_done) {
       // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
       //    very stale tables: an entry with lag >= 255 and seq != 0)
       DIRAL_WCLOCK(tc2);
