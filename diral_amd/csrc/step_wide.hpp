@@ -139,6 +139,12 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
 #ifndef DIRAL_WIDE_THERMO
 #define DIRAL_WIDE_THERMO 1
 #endif
+#ifndef DIRAL_WIDE_PIN2
+#define DIRAL_WIDE_PIN2 1               // N <= 128: pin the packed words in front of the pass's exit test (C5 -3.6 %)
+#endif
+#ifndef DIRAL_WIDE_PIN4
+#define DIRAL_WIDE_PIN4 0               // N <= 256: +0.8 % with the pin
+#endif
 // lag bytes (0..7 exact, 12 = never heard) -> codes, four at a time: v_perm_b32 selectors 0-7 pick
 // bytes of the table {0xff, 0xfe, 0xfc, 0xf8, 0xf0, 0xe0, 0xc0, 0x80}, selector 12 yields 0x00
 __device__ inline unsigned int thermo_codes(unsigned int lag_bytes) {
@@ -705,6 +711,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    }
+    // (pinned packed words: left alone, the compiler sinks the packing below the exit test and keeps all
+    // PC x VPL lags alive across it)
+    if constexpr (VPL == 2 ? (DIRAL_WIDE_PIN2 != 0) : (DIRAL_WIDE_PIN4 != 0)) {
+#pragma unroll
+      for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
     }
     const bool packed_ok = (__ballot(bad) == 0ull);
     DIRAL_WCLOCK(tc1);

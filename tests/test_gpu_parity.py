@@ -865,18 +865,27 @@ def test_wide_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
         e.check()
 
 
-@pytest.mark.parametrize("N,stale_frac", [(256, 0.0), (256, 0.01), (128, 0.3), (150, 0.05)])
-def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac):
-    """step_wide merges 8-bit ranks when every entry of a pass is younger than 255
-    slots (or never heard) and takes the 32-bit (seq, source) path otherwise; imported
-    tables with arbitrarily stale sequence numbers exercise both against the oracle."""
+@pytest.mark.parametrize("N,stale_frac,lag_hi", [(256, 0.0, 40), (256, 0.01, 40), (128, 0.3, 40), (150, 0.05, 40),
+                                                 (256, 0.0, 8), (128, 0.0, 8), (150, 0.0, 5), (256, 0.0, -1), (128, 0.0, -1),
+                                                 (200, 0.002, -1), (256, 0.0, 9)])
+def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac, lag_hi):
+    """step_wide merges a pass of subject columns as 8-level thermometer codes when every entry
+    of the pass is at most 7 slots behind (or never heard), as 8-bit ranks when younger than 255
+    slots, and takes the 32-bit (seq, source) path otherwise; imported tables with chosen lags
+    exercise all three against the oracle (lag_hi -1: subjects alternate between lags < 8 and
+    < 40, so consecutive passes of one launch take different paths; 9: a single lag-8 entry
+    here and there is enough to leave the thermometer path)."""
     from oracle.oracle import Oracle, SQ_IEEE
     A, T0, B = 64, 5000, 4
     cfg = bench_config(N, A, 15.0 * N + 100)
-    rng = np.random.default_rng(int(stale_frac * 1000) + N)
+    rng = np.random.default_rng(int(stale_frac * 1000) + N + 7 * lag_hi)
     x0 = rng.integers(0, int(cfg.highway_length), size=(B, N)).astype(np.float64)
     v0 = rng.uniform(1.1, 2.7, size=(B, N))
-    seq = T0 - rng.integers(0, 40, size=(B, N, N))
+    if lag_hi > 0:
+        hi = np.full((B, N, 1), lag_hi)
+    else:
+        hi = np.where((np.arange(N) // 4) % 3 == 0, 40, 8)[None, :, None] * np.ones((B, 1, 1), dtype=np.int64)
+    seq = T0 - rng.integers(0, hi, size=(B, N, N))             # [env][subject][viewer]
     stale = rng.random((B, N, N)) < stale_frac
     seq = np.where(stale, rng.integers(0, T0 - 255, size=(B, N, N)), seq)   # lag >= 255, some seq == 0
     seq = np.where(rng.random((B, N, N)) < 0.05, 0, seq)                    # never-heard entries
