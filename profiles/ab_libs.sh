@@ -1,5 +1,5 @@
 #!/bin/bash
-# ab.sh <workload> <emit> <rounds> libs... : interleaved rounds, 400 timed steps each; prints every kernel time and the minimum per lib
+# profiles/ab_libs.sh <workload> <emit> <rounds> libs... : interleaved rounds, 400 timed steps each; prints every kernel time and the minimum per lib
 W=$1; E=$2; R=$3; shift 3
 for r in $(seq $R); do
 for l in "$@"; do
