@@ -1,16 +1,16 @@
 #!/bin/bash
-# Copy the summaries of a gpurun profiling session (profiles/run_profile.sh tags c2_chobs1, c2_chobs0,
-# c3_chobs0, c5_chobs0, c4shard; traffic_only.sh c3_chobs1 / c5_chobs1; bench lines) from gpurun_out/
-# into profiles/r02/ and rebuild profiles/pmc_traffic.json.  Run in the build container.
+# Copy the summaries of a gpurun profiling session (profiles/session_r02.sh: run_profile.sh tags c2_chobs1,
+# c2_chobs0, c3_chobs1, c3_chobs0, c5_chobs1, c5_chobs0, c4shard; bench lines; the rollout example) from
+# gpurun_out/ into profiles/r02/ and rebuild profiles/pmc_traffic.json.  Run in the build container.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p profiles/r02
-for t in c2_chobs1 c2_chobs0 c3_chobs0 c5_chobs0 c4shard; do
+rm -f profiles/r02/c3_chobs1_traffic.txt profiles/r02/c5_chobs1_traffic.txt
+for t in c2_chobs1 c2_chobs0 c3_chobs1 c3_chobs0 c5_chobs1 c5_chobs0 c4shard; do
   cp gpurun_out/prof_$t/summary.txt profiles/r02/${t}_summary.txt
   find gpurun_out/prof_$t/trace -name "*kernel_stats.csv" -exec cp {} profiles/r02/${t}_kernel_stats.csv \;
 done
-cp gpurun_out/traffic_c3_chobs1.txt profiles/r02/c3_chobs1_traffic.txt
-cp gpurun_out/traffic_c5_chobs1.txt profiles/r02/c5_chobs1_traffic.txt
+cp gpurun_out/rollout_r02.txt profiles/r02/rollout_example.txt
 for f in full driverlike c3 c3_nochobs c5 c5_nochobs; do cp gpurun_out/bench_r02_$f.json profiles/r02/bench_$f.json; done
 bash profiles/resource_usage.sh profiles/r02/resource_usage.txt
 python3 - <<'PY'
@@ -23,22 +23,18 @@ def add(key, summary):
     f = float(re.search(r"FETCH_SIZE\s+mean=([0-9.e+]+)", txt).group(1)); w = float(re.search(r"WRITE_SIZE\s+mean=([0-9.e+]+)", txt).group(1))
     out[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024.0, "rule": rule,
                 "source": summary + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, mean over the last 40 launches after "
-                          "bench.py's pre-roll; kernels of the commit after " + head + ")"}
+                          "bench.py's pre-roll; kernels of commit " + head + ")"}
 add("c2", "profiles/r02/c2_chobs1_summary.txt"); add("c2_nochobs", "profiles/r02/c2_chobs0_summary.txt")
 add("c3_nochobs", "profiles/r02/c3_chobs0_summary.txt"); add("c5_nochobs", "profiles/r02/c5_chobs0_summary.txt")
+add("c3", "profiles/r02/c3_chobs1_summary.txt"); add("c5", "profiles/r02/c5_chobs1_summary.txt")
 add("c4shard", "profiles/r02/c4shard_summary.txt")
-for key, f in (("c3", "profiles/r02/c3_chobs1_traffic.txt"), ("c5", "profiles/r02/c5_chobs1_traffic.txt")):
-    txt = open(f).read()
-    fe = float(re.search(r"FETCH_SIZE .* mean=([0-9.e+]+) KB", txt).group(1)); wr = float(re.search(r"WRITE_SIZE .* mean=([0-9.e+]+) KB", txt).group(1))
-    out[key] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024.0, "rule": rule,
-                "source": f + " (profiles/traffic_only.sh; kernels of the commit after " + head + ")"}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 for k, v in out.items():
     print(k, "%.4g GB" % (v["hbm_bytes_per_launch"] / 1e9))
 PY
 python3 - <<'PY'
 import re
-for t, in (("c2_chobs1",), ("c2_chobs0",), ("c3_chobs0",), ("c5_chobs0",), ("c4shard",)):
+for t, in (("c2_chobs1",), ("c2_chobs0",), ("c3_chobs1",), ("c3_chobs0",), ("c5_chobs1",), ("c5_chobs0",), ("c4shard",)):
     txt = open("profiles/r02/%s_summary.txt" % t).read()
     ns = float(re.search(r"steady state:.*avg_ns=([0-9.]+) ", txt).group(1))
     g = lambda k: float(re.search(k + r"\s+mean=([0-9.e+]+)", txt).group(1))
