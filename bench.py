@@ -408,8 +408,10 @@ def main() -> int:
                 "layout_bytes_per_launch": res["layout_bytes_per_launch"],
                 "layout_rate_GBps": res["layout_rate_GBps"],
                 "layout_frac_of_peak": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
-                "limiter": "VALU issue (~87 % busy) with the HBM at ~0.85 of copy-kernel speed - two pipes near their "
-                           "practical limits at once, see profiles/README.md",
+                "limiter": ("VALU issue (~87 % busy) with the HBM at ~0.85 of copy-kernel speed - two pipes near their "
+                            "practical limits at once, see profiles/README.md") if N <= 64 else
+                           ("three pipes at once: LDS array ~0.7 busy (gossip merge), VALU ~0.7, HBM at ~0.85 of "
+                            "copy-kernel speed, see profiles/README.md"),
             },
             "episode_metrics": totals,
         }
