@@ -644,17 +644,22 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
     if (kbase >= p.NR) break;
-    // one packed pass: thermometer codes (lag <= 7) or byte ranks (lag < 255); false = not exact for this pass
-    auto packed_pass = [&](auto thermo_tag) -> bool {
-    constexpr bool THERMO = decltype(thermo_tag)::value;
-    constexpr int FIN_UNROLL_L = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;   // (a pragma argument is not a capture)
+    // One packed pass, ONE body for both packed representations (two copies of it cost 12 more spilled
+    // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
+    // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are
+    // simply repeated with the other pair of constants.  Only the merge loop exists per representation.
+    bool thermo = (DIRAL_WIDE_THERMO != 0);
+    bool packed_ok;
+    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 lag bytes (then codes / ranks) each; ages, same packing
+    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
+    for (;;) {
+    const unsigned int lag_clamp = thermo ? 12u : 255u, lag_limit = thermo ? 8u : 255u;
     DIRAL_WCLOCK(tc0);
-    // -- load + Vehicle.periodic_update (vehicle.py:56-70), ranks against the subject's
+    // -- load + Vehicle.periodic_update (vehicle.py:56-70), lags behind the subject's
     //    own fresh sequence number
-    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 ranks each; ages, same packing
 #pragma unroll
     for (int q = 0; q < NK; ++q) { kp[q] = 0u; agew[q] = 0u; }
-    unsigned int tkov = 0u;                      // lane c: column c's fresh sequence number of its subject
+    tkov = 0u;
     bool bad = false;
     // (16 table words in flight at a time: LC columns x VPL slots)
     constexpr int LC = 16 / VPL;
@@ -696,17 +701,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       tkov = (lane == c) ? t : tkov;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
-        const unsigned int lag = t - seq[j];
-        if constexpr (THERMO) {
-          // lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); anything else: not exact
-          const unsigned int lagc = min(lag, 12u);
-          bad = bad || (lagc >= 8u && (lagc < 12u || seq[j] != 0u));
-          kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
-        } else {
-          bad = bad || (lag >= 255u && seq[j] != 0u);
-          const unsigned int rank = lag < 255u ? 255u - lag : 0u;
-          kp[(c >> 2) * VPL + j] |= rank << (8 * (c & 3));
-        }
+        // codes: lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); ranks: 0..254, or 255 =
+        // never heard; anything else is not exact in that representation
+        const unsigned int lagc = min(t - seq[j], lag_clamp);
+        bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
+        kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
         if constexpr (!RELOAD) agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
       }
     }
@@ -718,14 +717,16 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
       for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
     }
-    const bool packed_ok = (__ballot(bad) == 0ull);
+    packed_ok = (__ballot(bad) == 0ull);
     DIRAL_WCLOCK(tc1);
-    if (!packed_ok) return false;
-    if constexpr (THERMO) {
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp[q] = thermo_codes(kp[q]);
+    if (packed_ok || !thermo) break;
+    thermo = false;
     }
-    {
+    if (packed_ok) {
+      // lag bytes -> thermometer codes, or byte ranks 255 - lag (the complement; 255 -> 0: never heard)
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kp[q] = thermo ? thermo_codes(kp[q]) : ~kp[q];
+      const unsigned int seq_base = thermo ? 8u : 255u;
       unsigned int kp0[NK];                      // the ranks before the merge
 #pragma unroll
       for (int q = 0; q < NK; ++q) kp0[q] = RELOAD ? 0u : kp[q];
@@ -738,8 +739,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
           for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
         wave_lds_order();
-        auto merge_loop = [&](auto wtag) {
+        auto merge_loop = [&](auto wtag, auto ttag) {
           constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
+          constexpr bool THERMO = decltype(ttag)::value;
           const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
           unsigned long long rem = actw;
           unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
@@ -776,7 +778,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             wave_lds_order();
           }
         };
-        DIRAL_WIDE_DISPATCH_WAVE(merge_loop);
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
+        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
       } else {
         // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
         // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
@@ -794,8 +799,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         };
         put();
         wave_lds_order();
-        auto merge_loop = [&](auto wtag) {
+        auto merge_loop = [&](auto wtag, auto ttag) {
           constexpr int W = decltype(wtag)::value;
+          constexpr bool THERMO = decltype(ttag)::value;
           const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
           unsigned long long rem = actw;
           unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
@@ -822,7 +828,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             wave_lds_order();
           }
         };
-        DIRAL_WIDE_DISPATCH_WAVE(merge_loop);
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
+        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
       }
       DIRAL_WCLOCK(tc2);
 
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
 #pragma unroll
       for (int w = 0; w < NW; ++w)
-#pragma unroll FIN_UNROLL_L
+#pragma unroll FIN_UNROLL
       for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * w + cc;
         const int k = kbase + c;
@@ -878,8 +887,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
               age0[j] = own ? 0u : age0[j];
             }
             const unsigned int lag = tk_own - sq;
-            if constexpr (THERMO) rank0[j] = lag <= 7u ? ((0xffu << lag) & 0xffu) : 0u;
-            else rank0[j] = lag < 255u ? 255u - lag : 0u;
+            rank0[j] = thermo ? (lag <= 7u ? ((0xffu << lag) & 0xffu) : 0u) : (lag < 255u ? 255u - lag : 0u);
           }
         }
 #pragma unroll
@@ -897,19 +905,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           const bool upd = rf != rank0[j];
           const double xg = upd ? xr : x_cur[j];
           // sequence number back from the rank / from the code (lag = 8 - popcount)
-          const unsigned int seqf = rf ? (THERMO ? tk_own - 8u + (unsigned int)__popc(rf) : tk_own - 255u + rf) : 0u;
+          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
           const unsigned int wn = (seqf << 8) | (upd ? 0u : (RELOAD ? age0[j] : pick(agew, j, w, cc)));
           emit(k, kvalid, j, upd, wn, xg, tkrow, txrow);
         }
         wave_lds_order();
       }
-    }
-    return true;
-    };
-    bool pass_done = false;
-    if constexpr (DIRAL_WIDE_THERMO != 0) pass_done = packed_pass(std::true_type{});
-    if (!pass_done) pass_done = packed_pass(std::false_type{});
-    if (!pass_done) {
+    } else {
       // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
       //    very stale tables: an entry with lag >= 255 and seq != 0)
       DIRAL_WCLOCK(tc2);
