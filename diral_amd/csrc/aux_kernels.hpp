@@ -79,6 +79,33 @@ __global__ void export_tables_kernel(int B, int N, int NV, int NR, const uint32_
   if (y) y[i] = (w >> 8) ? pos_y[(size_t)b * N + k] : 0.0;
 }
 
+// The xpos ring of the N <= 64 kernel (step_fast64.hpp, DIRAL_FAST_RING): ring[env][subject][seq & 7]
+// is the subject's stamp at sequence number `seq`, for its 8 most recent numbers.  An entry that
+// lags its subject by at most 7 finds its xpos there; only older entries need the per-entry plane.
+// rebuild: plane -> ring (after an import or a step of another kernel family); materialise: ring ->
+// plane (before anything else reads the plane).  Entries of one subject with equal sequence numbers
+// hold equal xpos in every reachable state, so concurrent writers of a slot agree.
+__global__ void ring_rebuild_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* tx, double* ring) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * N * N) return;
+  const int u = (int)(i % N);
+  const int k = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t row = (size_t)b * NR + k;
+  const uint32_t seq = tkey[row * NV + u] >> 8, tk = tkey[row * NV + k] >> 8;
+  if (tk - seq <= 7u) ring[row * 8 + (seq & 7u)] = tx[row * NV + u];
+}
+__global__ void ring_materialize_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* ring, double* tx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * N * N) return;
+  const int u = (int)(i % N);
+  const int k = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t row = (size_t)b * NR + k;
+  const uint32_t seq = tkey[row * NV + u] >> 8, tk = tkey[row * NV + k] >> 8;
+  if (tk - seq <= 7u) tx[row * NV + u] = ring[row * 8 + (seq & 7u)];
+}
+
 __global__ void import_tables_kernel(int B, int N, int NV, int NR, const int32_t* seq, const int32_t* age,
                                      const double* x, uint32_t* tkey, double* tx) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

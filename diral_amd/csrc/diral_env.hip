@@ -35,6 +35,10 @@ struct DiralEnv {
   double* vel = nullptr;
   uint32_t* tkey = nullptr;
   double* tx = nullptr;
+  // the xpos ring of the N <= 64 kernel (aux_kernels.hpp): while it is in use the per-entry plane `tx` is only
+  // kept for entries older than the ring reaches; `plane_valid` / `ring_valid` say which of the two is complete
+  double* ring = nullptr;
+  bool plane_valid = true, ring_valid = false;
   int32_t* la = nullptr;
   int32_t* pf = nullptr;
   double* metrics = nullptr;
@@ -144,6 +148,26 @@ bool is_plain_cfg(const StepParams& p) {
          p.state_out != nullptr && p.chobs_out == nullptr;
 }
 
+int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
+
+// every consumer of the per-entry xpos plane other than step_fast64 goes through here first
+hipError_t ensure_plane(DiralEnv* e, hipStream_t s) {
+  if (e->plane_valid || !e->ring) { e->plane_valid = true; return hipSuccess; }
+  const size_t total = (size_t)e->B * e->N * e->N;
+  hipLaunchKernelGGL(ring_materialize_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
+                     e->ring, e->tx);
+  e->plane_valid = true;
+  return hipGetLastError();
+}
+hipError_t ensure_ring(DiralEnv* e, hipStream_t s) {
+  if (e->ring_valid) return hipSuccess;
+  const size_t total = (size_t)e->B * e->N * e->N;
+  hipLaunchKernelGGL(ring_rebuild_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
+                     e->tx, e->ring);
+  e->ring_valid = true;
+  return hipGetLastError();
+}
+
 hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const int vpl = e->vpl;
   const bool flat_y = e->flat_y;
@@ -154,6 +178,16 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const bool wide_rich_ok = plain || !(p.flags & DIRAL_F_ADD_REWARD) || p.state_out == nullptr || p.rew_out != nullptr;
   const bool use_fast64 = spec && vpl == 1 && p.A <= kFastMaxA && p.NV == 64;
   const bool use_wide = spec && vpl > 1 && p.A <= kWideMaxA && flat_y && wide_rich_ok;
+  // xpos ring (step_fast64.hpp): the N <= 64 kernel keeps the plane only for entries older than the ring reaches
+  const bool use_ring = use_fast64 && e->ring != nullptr;
+  if (use_ring) {
+    const hipError_t st = ensure_ring(e, s);
+    if (st != hipSuccess) return st;
+  } else {
+    const hipError_t st = ensure_plane(e, s);
+    if (st != hipSuccess) return st;
+    if (p.mode != kModeObserve) e->ring_valid = false;         // this step moves the tables without the ring
+  }
   if (use_fast64 || use_wide) {
     FastParams f;
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
@@ -164,6 +198,8 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges; f.inv_tab = e->inv_tab;
+    f.ring = use_ring ? e->ring : nullptr;
+    if (use_ring) e->plane_valid = false;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
     f.trace = p.trace; f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
@@ -191,13 +227,15 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   return launch_general(vpl, fast, p, e->lds_bytes, s);
 }
 
-int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
-
 // Secondary observation modes (a15/a16) run as their own launch after the step.
 hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const bool full = (p.flags & DIRAL_F_ADD_POSDIST) != 0;
   const bool type1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1;
   if (!p.state_out || !(full || type1)) return hipSuccess;
+  {
+    const hipError_t st = ensure_plane(e, s);
+    if (st != hipSuccess) return st;
+  }
   PosdistParams q;
   q.N = p.N; q.A = p.A; q.K = p.K; q.S = p.S; q.NV = p.NV; q.NR = p.NR; q.flags = p.flags;
   q.posdist_type = p.posdist_type; q.age_limit = p.age_limit; q.out_f64 = p.out_f64;
@@ -327,6 +365,13 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   // end of a row without clamping (the values are masked, never stored)
   CREATE_TRY(alloc((void**)&e->tkey, (tab + 256) * 4));
   CREATE_TRY(alloc((void**)&e->tx, (tab + 256) * 8));
+#if DIRAL_FAST_RING
+  if (e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) {
+    CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
+    CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
+    e->ring_valid = true;                                       // all tables zero: seq 0 -> slot 0 -> xpos 0
+  }
+#endif
   CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(alloc((void**)&e->err, 4));
   CREATE_TRY(alloc((void**)&e->yflag, 4));
@@ -401,7 +446,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
@@ -439,6 +484,8 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   const size_t tab = (size_t)e->B * e->NR * e->NV;
   HIP_TRY(e, hipMemsetAsync(e->tkey, 0, tab * 4, s));
   HIP_TRY(e, hipMemsetAsync(e->tx, 0, tab * 8, s));
+  if (e->ring) HIP_TRY(e, hipMemsetAsync(e->ring, 0, (size_t)e->B * e->NR * 8 * 8, s));
+  e->plane_valid = true; e->ring_valid = e->ring != nullptr;
   HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
   if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));
   if (e->pf) HIP_TRY(e, hipMemsetAsync(e->pf, 0, bn * 4, s));
@@ -530,6 +577,7 @@ int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* ve
   if (vel) HIP_TRY(e, hipMemcpyAsync(vel, e->vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x || tab_y) {
     const size_t total = bn * e->N;
+    if (tab_x) HIP_TRY(e, ensure_plane(e, s));
     hipLaunchKernelGGL(export_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                        e->tx, e->pos_y, tab_seq, tab_age, tab_x, tab_y);
     HIP_TRY(e, hipGetLastError());
@@ -556,6 +604,8 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
   if (vel) HIP_TRY(e, hipMemcpyAsync(e->vel, vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x) {
     const size_t total = bn * e->N;
+    HIP_TRY(e, ensure_plane(e, s));                             // (a partial import keeps the other planes)
+    e->ring_valid = false;
     hipLaunchKernelGGL(import_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, tab_seq,
                        tab_age, tab_x, e->tkey, e->tx);
     HIP_TRY(e, hipGetLastError());

@@ -39,6 +39,18 @@ namespace diral {
 #define DIRAL_PACKED_MERGE 1           // 16-bit packed gossip merge (exact; falls back per wave)
 #endif
 
+#ifndef DIRAL_FAST_RING
+#define DIRAL_FAST_RING 1              // xpos ring + thermometer-coded merge, see P3 of step_fast64_kernel
+#endif
+// Thermometer codes of table lags: c(lag) = (0xff << lag) & 0xff for lag 0..7, 0 = never heard.
+// The codes form a chain under bit inclusion, so the code of the smaller lag (the fresher entry)
+// is the bitwise OR, and the lag comes back as 8 - popcount.  Four lag bytes (0..7 exact, 12 =
+// never heard) -> four codes with one v_perm_b32: selectors 0-7 pick bytes of the table
+// {0xff, 0xfe, 0xfc, 0xf8, 0xf0, 0xe0, 0xc0, 0x80}, selector 12 yields 0x00.
+__device__ inline unsigned int thermo_codes(unsigned int lag_bytes) {
+  return __builtin_amdgcn_perm(0x80c0e0f0u, 0xf8fcfeffu, lag_bytes);
+}
+
 constexpr int kFastMaxA = 64;           // LDS is sized by the actual A (rounded up to 32): A <= 32 keeps 8 workgroups per CU
 
 struct FastParams {
@@ -59,6 +71,7 @@ struct FastParams {
   const double* vel;
   uint32_t* tkey;
   double* tx;
+  double* ring;                  // [B][NR][8] xpos ring (DIRAL_FAST_RING) or null: every xpos from the plane `tx`
   int32_t* la;                   // last_arrival_time[tx][rx] (network.py:39-42) or null: not tracked
   const double* trace;           // replayed x positions (network.py:171-178, 194-199) or null
   int trace_len, trace_per_env;
@@ -524,6 +537,221 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // word seen reaches the limit exactly when some own stamp does
     if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
   }
+#if DIRAL_FAST_RING
+  // Vehicle.received_update for every (resource, rx), resources ascending: per column the entry of
+  // viewer u becomes the fresher of its own and that of its gather source m_i(u).
+  //
+  // RING path.  In steady state an entry lags its subject's own sequence number by a handful of
+  // slots (C2: <= 5, profiles/lag_distribution.py).  (a) The 16 columns then travel as 8-level
+  // thermometer codes, four per register: ONE ds_bpermute + ONE v_or per four columns and resource,
+  // no gather source to track.  (b) An entry's xpos is a function of (subject, sequence number), and
+  // the xpos ring keeps every subject's 8 latest stamps: the xpos of EVERY entry that lags at most 7
+  // is one lookup in the subject's ring row (two ds_bpermute from the lanes that hold it) - the
+  // per-entry xpos plane, two thirds of the table bytes, is neither read nor written.  Only an entry
+  // that reaches lag 7 saves its xpos to the plane, where it lives from lag 8 on.  Exact iff every
+  // entry of the wave lags at most 7 or was never heard (seq 0, at least 12 slots behind); otherwise
+  // the wave takes the KEYED path below, which reads the xpos of young entries from the ring, of old
+  // ones from the plane, and leaves the plane complete for its columns.
+  //
+  // KEYED path: two columns share one register as 16-bit keys (rank << 6) | source, rank = 1023 - lag,
+  // merged with v_pk_max_u16 - exact iff no entry of the wave has lag >= 1023 with seq != 0 (never-heard
+  // entries, seq == 0, all share rank 0) - or, for imported / very stale tables, 32-bit keys.
+  // resources with at least one transmitter, as a wave-uniform bit word: the merge visits only those
+  const unsigned long long actw = __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
+  // the xpos rings of this wave's 16 subjects: lane l holds slot l & 7 of subject l >> 3 (ringv0) / 8 + (l >> 3)
+  // (ringv1); loaded here, first needed after the codes are built
+  const LateFastArgs lpr = (LateFastArgs)late_kernarg_base();
+  double* const ring = lpr->ring;
+  const bool use_ring = ring != nullptr;       // uniform
+  double* const ringp = ring + ((size_t)b * p.NR + (has_cols ? wave * 16 : 0)) * 8;
+  double ringv0 = 0.0, ringv1 = 0.0;
+  if (use_ring) { ringv0 = ringp[lane]; ringv1 = ringp[64 + lane]; }
+  bool thermo_ok = false;
+  // codes after / before the merge and ages, column c in byte c & 3 of word c >> 2; lane c of `tkov`: the
+  // fresh sequence number of column c's subject
+  unsigned int cw[4], cold[4], agw[4] = {0u, 0u, 0u, 0u}, tkov = 0u;
+  if (use_ring) {
+    unsigned int lw[4] = {0u, 0u, 0u, 0u};
+    bool bad8 = false;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const unsigned int seq = w1[c] >> 8;
+      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)seq, (wave * 16 + c) & 63);
+      tkov = (lane == c) ? tk_own : tkov;
+      // lag byte 0..7, or 12 = never heard; anything else: not exact in this representation
+      const unsigned int lagc = min(tk_own - seq, 12u);
+      bad8 = bad8 || (lagc >= 8u && (lagc < 12u || seq != 0u));
+      lw[c >> 2] |= lagc << (8 * (c & 3));
+      agw[c >> 2] |= (w1[c] & 255u) << (8 * (c & 3));
+    }
+    thermo_ok = (__ballot(bad8) == 0ull);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cw[q] = cold[q] = thermo_codes(lw[q]);
+    // this slot's stamps (vehicle.py:61-63: the subject's pre-move position under its fresh sequence
+    // number) into the ring rows, in registers and in memory
+    const int cl = lane >> 3;
+    const unsigned int tk0 = (unsigned int)__builtin_amdgcn_ds_bpermute(cl << 2, (int)tkov);
+    const unsigned int tk1 = (unsigned int)__builtin_amdgcn_ds_bpermute((cl + 8) << 2, (int)tkov);
+    const int a0 = ((wave * 16 + cl) & 63) << 2, a1 = ((wave * 16 + cl + 8) & 63) << 2;
+    const double px0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(a0, __double2hiint(mypx)),
+                                        __builtin_amdgcn_ds_bpermute(a0, __double2loint(mypx)));
+    const double px1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(a1, __double2hiint(mypx)),
+                                        __builtin_amdgcn_ds_bpermute(a1, __double2loint(mypx)));
+    const bool h0 = (unsigned int)(lane & 7) == (tk0 & 7u), h1 = (unsigned int)(lane & 7) == (tk1 & 7u);
+    ringv0 = h0 ? px0 : ringv0;
+    ringv1 = h1 ? px1 : ringv1;
+    if (has_cols) {
+      if (h0) ringp[lane] = px0;
+      if (h1) ringp[64 + lane] = px1;
+    }
+  }
+  if (thermo_ok) {
+    unsigned long long rem = actw;
+    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
+#pragma unroll 1
+    while (rem) {
+      rem &= rem - 1;
+      const int m4 = m_next;
+      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cw[q] |= (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)cw[q]);
+    }
+  }
+  DIRAL_FSTAMP(4);
+
+  // ---- P3b: the entry's xpos, the table word, the histogram ------------------------
+  unsigned int mycnt = 0u;
+  const double inv_w = p.inv_w;
+  unsigned int* const hrow = s_hist + lane * KP;
+  const int ncol = has_cols ? 16 : 0;
+  // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) of one entry:
+  // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
+  auto tally = [&](int k, unsigned int wn, double xg) {
+    double d, v;
+    if constexpr (FLAT) {
+      // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v|
+      v = xg - mynpx;
+      const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+      d = __hiloint2double((int)vh, __double2loint(v));
+      if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
+        d = dist_general(mynpx - xg, 0.0);
+        v = (xg - mynpx > 0.0) ? d : -d;
+      }
+    } else {
+      const double pyk = readlane_f64(mypy, k);
+      d = fast_dist<false>(xg, (wn >> 8) ? pyk : 0.0, mynpx, mypy);
+      v = (xg - mynpx > 0.0) ? d : -d;
+    }
+    const bool ok = live && (k < N) && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    if (ok) {
+      // |v| < Rb, so the estimate is in [0, K] and the edge correction needs no bounds
+      // tests: edges[0] = -Rb <= v and v < Rb = edges[K] hold by construction
+      int est = (int)((v + p.Rb) * inv_w);
+      est = est > K - 1 ? K - 1 : est;
+      const double e0 = s_edges[est], e1 = s_edges[est + 1];
+      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      atomicAdd(&hrow[bin], 1u);
+      mycnt += 1u;
+    }
+  };
+  // xpos of (column c, sequence number seq) from the ring rows
+  auto ring_x = [&](double rv, int c, unsigned int seq) -> double {
+    const int src = (int)((((unsigned int)c & 7u) << 3) | (seq & 7u)) << 2;
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(rv)),
+                            __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
+  };
+  if (thermo_ok) {
+    // (the packed words move down one register every four columns: a dynamically indexed array would
+    // live in scratch memory)
+    unsigned int cn0 = cw[0], cn1 = cw[1], cn2 = cw[2], cn3 = cw[3], co0 = cold[0], co1 = cold[1], co2 = cold[2], co3 = cold[3];
+    unsigned int ag0 = agw[0], ag1 = agw[1], ag2 = agw[2], ag3 = agw[3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double rv = h ? ringv1 : ringv0;
+#pragma unroll 1
+      for (int cc = 0; cc < (ncol >> 1); ++cc) {
+        const int c = 8 * h + cc;
+        const int k = wave * 16 + c;
+        const int off = c * NV + lane;
+        const unsigned int sh = 8u * (unsigned int)(c & 3);
+        const unsigned int rf = (cn0 >> sh) & 255u, r0 = (co0 >> sh) & 255u, age = (ag0 >> sh) & 255u;
+        if ((c & 3) == 3) { cn0 = cn1; cn1 = cn2; cn2 = cn3; co0 = co1; co1 = co2; co2 = co3; ag0 = ag1; ag1 = ag2; ag2 = ag3; }
+        const bool upd = rf != r0;
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        // sequence number back from the code: lag = 8 - popcount (code 0: never heard, seq 0)
+        const unsigned int seqn = tk_own - 8u + (unsigned int)__popc(rf);
+        double xg = ring_x(rv, c, seqn);
+        if (rf == 0u) xg = txp[off];                                // never heard: the ghost xpos lives in the plane
+        const unsigned int wn = (rf ? (seqn << 8) : 0u) | (upd ? 0u : age);   // a fresh copy has age 0
+        tk[off] = wn;
+        if (rf == 0x80u) txp[off] = xg;                            // lag 7: next slot it may be beyond the ring
+        tally(k, wn, xg);
+      }
+    }
+  } else {
+    // 32-bit keys (seq << 8) | source lane, one ds_bpermute + max per column and resource (the 16-bit packed
+    // keys of the build without the ring are not worth their registers on a path this rare)
+    unsigned int key[16];
+    {
+      const int own_c = live ? lane - wave * 16 : -1;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const unsigned int w = tk_ld[c * NV + lane];             // (re-read: keeping w1[] alive for this path would spill it in front of the other)
+        key[c] = (((w >> 8) + (own_c == c ? 1u : 0u)) << 8) | (unsigned int)lane;
+      }
+    }
+    {
+      unsigned long long rem = actw;
+      int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
+#pragma unroll 1
+      while (rem) {
+        rem &= rem - 1;
+        const int m4 = m_next;
+        if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
+          key[c] = max(key[c], v);
+        }
+      }
+    }
+    // (a rolled loop with uniform register indexing of key[]; the table word is re-read - it is what
+    // w1[c] held before the stamp - rather than indexed: a second dynamically indexed array would put
+    // both in scratch memory.  The next column's xpos and word are loaded one iteration ahead.)
+    const int own_c = live ? lane - wave * 16 : -1;
+    double x_next = has_cols ? txp[lane] : 0.0;
+    unsigned int w_next = has_cols ? tk[lane] : 0u;
+#pragma unroll 1
+    for (int c = 0; c < ncol; ++c) {
+      const int k = wave * 16 + c;
+      const int off = c * NV + lane;
+      const unsigned int kf = key[c];
+      const unsigned int wr = w_next;
+      double x_cur = x_next;
+      if (c + 1 < ncol) { x_next = txp[off + NV]; w_next = tk[off + NV]; }
+      // Vehicle.periodic_update again (vehicle.py:56-70)
+      const bool own = (own_c == c);
+      const unsigned int a0 = wr & 255u;
+      const unsigned int w = (((wr >> 8) + (own ? 1u : 0u)) << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
+      const bool upd = ((kf ^ w) >> 8) != 0u;
+      if (use_ring) {
+        // a young entry's xpos is in the ring, not (necessarily) in the plane
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        const double xr = ring_x(c < 8 ? ringv0 : ringv1, c, w >> 8);
+        x_cur = (tk_own - (w >> 8) <= 7u) ? xr : x_cur;
+      }
+      const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
+      const int src4 = (int)(kf & 255u) << 2;
+      const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
+      const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
+      const double xg = upd ? __hiloint2double(hi, lo) : xs;
+      const unsigned int wn = upd ? (kf & ~255u) : w;
+      tk[off] = wn;
+      if (use_ring || upd || lane == k) txp[off] = xg;            // with the ring: the plane complete for these columns
+      tally(k, wn, xg);
+    }
+  }
+#else
   // Vehicle.received_update for every (resource, rx), resources ascending:
   // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
   //
@@ -661,6 +889,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       mycnt += 1u;
     }
   }
+#endif
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
   DIRAL_FSTAMP(5);
   __syncthreads();

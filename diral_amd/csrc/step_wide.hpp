@@ -145,11 +145,7 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
 #ifndef DIRAL_WIDE_PIN4
 #define DIRAL_WIDE_PIN4 0               // N <= 256: +0.8 % with the pin
 #endif
-// lag bytes (0..7 exact, 12 = never heard) -> codes, four at a time: v_perm_b32 selectors 0-7 pick
-// bytes of the table {0xff, 0xfe, 0xfc, 0xf8, 0xf0, 0xe0, 0xc0, 0x80}, selector 12 yields 0x00
-__device__ inline unsigned int thermo_codes(unsigned int lag_bytes) {
-  return __builtin_amdgcn_perm(0x80c0e0f0u, 0xf8fcfeffu, lag_bytes);
-}
+// (thermo_codes(): step_fast64.hpp)
 
 #ifndef DIRAL_WIDE_WAVECONST
 #define DIRAL_WIDE_WAVECONST 1           // one copy of the merge loop per wave index: scratch base as an immediate offset

@@ -54,15 +54,24 @@ def test_histogram_bin_edges_sweep_on_the_hip_path(K, rb, N, path):
     pos_x = np.full((B, N), L - v)
     pos_y = np.full((B, N), ylane)
     vel = np.full((B, N), v)
-    cand = edge_candidates(K, rb, rng, B * N * N).reshape(B, N, N)
-    for b in range(B):                                  # shuffle so every kernel column sees edge cases
-        cand[b] = rng.permutation(cand[b].ravel()).reshape(N, N)
-    seq = np.ones((B, N, N), np.int32)
+    # A table entry is its subject's stamp at that sequence number: entries about one subject with equal
+    # sequence numbers carry equal xpos in every reachable state (what import_state asks for, and what the
+    # xpos ring of the N <= 64 kernel and the rank -> xpos table of the N > 64 kernel build on).  So the
+    # candidates come as six values per subject, for lags 1..6 behind the subject's own number, and viewer u
+    # holds the one of lag 1 + (u + k) % 6 about subject k.
+    T0, NL = 50, 6
+    pool = edge_candidates(K, rb, rng, B * N * NL)
+    pool = np.stack([rng.permutation(pool[b * N * NL:(b + 1) * N * NL]).reshape(N, NL) for b in range(B)])   # [B][subject][lag]
+    uu, kk = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")   # [viewer][subject]
+    lag = (uu + kk) % NL
+    cand = np.stack([pool[b][kk, lag] for b in range(B)])            # [B][viewer][subject]
+    seq = np.broadcast_to((T0 - 1 - lag).astype(np.int32), (B, N, N)).copy()
     age = rng.integers(0, 20, size=(B, N, N)).astype(np.int32)      # 19 -> 20 after the stamp: invalid
     x = cand.copy()
     for u in range(N):                                  # own entries: what a run would hold
         x[:, u, u] = L - v
         age[:, u, u] = 0
+        seq[:, u, u] = T0
     envs = {dt: make_env(cfg, B, dtype=dt) for dt in (torch.float64, torch.float32)}
     orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=4)
     orc.reset(pos_x, pos_y, vel)
