@@ -53,6 +53,7 @@ KERNEL_WIDE = 2
 KERNEL_RICH = 16
 KERNEL_EXTRA = 32
 KERNEL_CH = 64
+KERNEL_RING = 128
 
 MAX_USERS = 256
 MAX_CHANNELS = 256

@@ -214,7 +214,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
-                     (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0);
+                     (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
     return launch_fast64(f, r, k, p.B, s);
   }

@@ -661,21 +661,19 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
                             __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
   };
   if (thermo_ok) {
-    // (the packed words move down one register every four columns: a dynamically indexed array would
-    // live in scratch memory)
-    unsigned int cn0 = cw[0], cn1 = cw[1], cn2 = cw[2], cn3 = cw[3], co0 = cold[0], co1 = cold[1], co2 = cold[2], co3 = cold[3];
-    unsigned int ag0 = agw[0], ag1 = agw[1], ag2 = agw[2], ag3 = agw[3];
+    // (four rolled loops of four columns, one per packed word: a dynamically indexed word array would live
+    // in scratch memory, a register rotation costs a dozen moves per column)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double rv = h ? ringv1 : ringv0;
+    for (int q = 0; q < 4; ++q) {
+      const double rv = q >= 2 ? ringv1 : ringv0;
+      const unsigned int cnq = cw[q], coq = cold[q], agq = agw[q];
 #pragma unroll 1
-      for (int cc = 0; cc < (ncol >> 1); ++cc) {
-        const int c = 8 * h + cc;
+      for (int cc = 0; cc < (ncol >> 2); ++cc) {
+        const int c = 4 * q + cc;
         const int k = wave * 16 + c;
         const int off = c * NV + lane;
-        const unsigned int sh = 8u * (unsigned int)(c & 3);
-        const unsigned int rf = (cn0 >> sh) & 255u, r0 = (co0 >> sh) & 255u, age = (ag0 >> sh) & 255u;
-        if ((c & 3) == 3) { cn0 = cn1; cn1 = cn2; cn2 = cn3; co0 = co1; co1 = co2; co2 = co3; ag0 = ag1; ag1 = ag2; ag2 = ag3; }
+        const unsigned int sh = 8u * (unsigned int)cc;
+        const unsigned int rf = (cnq >> sh) & 255u, r0 = (coq >> sh) & 255u, age = (agq >> sh) & 255u;
         const bool upd = rf != r0;
         const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
         // sequence number back from the code: lag = 8 - popcount (code 0: never heard, seq 0)

@@ -11,11 +11,13 @@ outputs:
 C2 (N=64, A=32, S=52): 155136 B/env-slot = 2424 B/agent-step.  This is the figure
 `roofline.achieved` is built from (the task's definition).
 
-The packed layout of this build moves 12 B per entry (u32 key + f64 x), so the
-bytes that really cross the HBM interface are fewer: `layout_bytes_per_env_slot`
-(matches the rocprofv3 FETCH_SIZE / WRITE_SIZE counters within a few percent,
-profiles/README.md).  bench.py reports both; the kernels are VALU-bound, and the
-layout figure over the kernel time is their real HBM rate.
+The packed layout of this build moves fewer bytes: N > 64 12 B per entry (u32 key +
+f64 x), N <= 64 the 4-byte key only - the xpos of an entry that lags its subject by at
+most 7 stamps comes from an 8-deep per-subject ring (csrc/step_fast64.hpp), and in steady
+state that is every entry.  `layout_bytes_per_env_slot` is that figure (matches the
+rocprofv3 FETCH_SIZE / WRITE_SIZE counters within a few percent plus spill scratch,
+profiles/README.md).  bench.py reports both; the layout figure over the kernel time is the
+real HBM rate.
 """
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 
@@ -25,7 +27,9 @@ def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
 
 
 def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4) -> int:
-    """What csrc/step_fast64.hpp / step_wide.hpp move per env-slot: every table word read and
-    written once at 12 B per entry, the per-vehicle arrays, reward and state, and the channel
-    observation only when it is requested."""
-    return 2 * 12 * n * n + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)
+    """What csrc/step_fast64.hpp / step_wide.hpp move per env-slot in steady state: every table word read
+    and written once (N <= 64: the 4-byte key plus the subjects' ring rows read, one stamp each written;
+    N > 64: 12 B per entry), the per-vehicle arrays, reward and state, and the channel observation only
+    when it is requested."""
+    table = 2 * 4 * n * n + 64 * n + 8 * n if n <= 64 else 2 * 12 * n * n
+    return table + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)

@@ -179,7 +179,8 @@ enum {
   DIRAL_KERNEL_WIDE    = 2,   /* csrc/step_wide.hpp,  64 < N <= 256  */
   DIRAL_KERNEL_RICH    = 16,  /* channel-obs output / cheap State flags (csrc/rich_out.hpp) */
   DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
-  DIRAL_KERNEL_CH      = 64   /* my_step_ch */
+  DIRAL_KERNEL_CH      = 64,  /* my_step_ch */
+  DIRAL_KERNEL_RING    = 128  /* step_fast64 with the xpos ring (the per-entry xpos plane only for old entries) */
 };
 int diral_env_last_kernel(const DiralEnv* env);
 
@@ -249,7 +250,14 @@ int diral_env_set_trace(DiralEnv* env, const double* x_positions, int T, int per
  * skipped.  pos_x,pos_y,vel [B][N] f64; tab_seq, tab_age [B][N][N] int32 and
  * tab_x, tab_y [B][N][N] f64 indexed [env][viewer][subject]
  * (Vehicle.pos_of_neighbors, vehicle.py:20-33; age saturates at 255);
- * last_arrival [B][N][N] int32 indexed [env][tx][rx] (network.py:39-42). */
+ * last_arrival [B][N][N] int32 indexed [env][tx][rx] (network.py:39-42).
+ * Imported tables must be states the reference can reach in this one respect:
+ * entries about one subject that carry equal sequence numbers carry equal xpos
+ * (an entry IS the subject's stamp at that number, vehicle.py:56-63; every
+ * exported state qualifies).  The kernels build on it: N <= 64 keeps the xpos of
+ * entries at most 7 stamps old in a per-subject ring instead of the per-entry
+ * plane, N > 64 routes xpos through a rank-indexed table; export / observe /
+ * other consumers see the plane completed first (no caller-visible difference). */
 int diral_env_export_state(DiralEnv* env, double* pos_x, double* pos_y,
                            double* vel, int32_t* tab_seq, int32_t* tab_age,
                            double* tab_x, double* tab_y, int32_t* last_arrival,

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_WIDE, STEP_MY_STEP, bench_config
+from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RING, KERNEL_WIDE, STEP_MY_STEP, bench_config
 from tests.test_gpu_parity import make_env
 
 pytestmark = pytest.mark.gpu
@@ -86,7 +86,7 @@ def test_histogram_bin_edges_sweep_on_the_hip_path(K, rb, N, path):
         env.force_general_kernel(path == "general")
         obs, rew, _ = env.step(acts, 0)
         torch.cuda.synchronize()
-        assert env.last_kernel() == want_kernel
+        assert (env.last_kernel() & ~KERNEL_RING) == want_kernel and bool(env.last_kernel() & KERNEL_RING) == path.startswith("fast64")
         assert np.array_equal(env.export_state()["pos_x"].cpu().numpy(), np.zeros((B, N)))   # post-move x == 0
         got = obs.cpu().numpy()
         assert np.array_equal(got, o_state if dt == torch.float64 else o_state.astype(np.float32)), (K, rb, N, path)
@@ -203,7 +203,7 @@ def test_c4_shard_sized_run_properties_and_sampled_oracle():
         if t % 7 == 0 or t == T - 1:
             assert np.array_equal(obs[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_state.astype(np.float32)), t
             assert np.array_equal(rew[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_rew.astype(np.float32)), t
-    assert env.last_kernel() == KERNEL_FAST64
+    assert env.last_kernel() == KERNEL_FAST64 | KERNEL_RING
     # properties on all 32768 envs of the last slot
     onehot = obs[:, :, :A]
     assert torch.equal(onehot.argmax(-1).to(torch.int32), a) and torch.all(onehot.sum(-1) == 1)

@@ -1151,7 +1151,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     * the reference's own call pattern `obs, rews = env.my_step*(a, t)` (channel observation
       requested) and every cheap State flag on a RICH instantiation,
     and the obtain_state that follows my_step* must not launch anything."""
-    from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RICH, KERNEL_WIDE)
+    from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RICH, KERNEL_RING, KERNEL_WIDE)
     fam = KERNEL_FAST64 if N <= 64 else KERNEL_WIDE
     L = 2000.0 if N <= 64 else 4000.0
     B = 16
@@ -1160,16 +1160,17 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     env.reset_topology(seed=3)
     a = env.sample(seed=1)
     env.step(a, 0)
-    assert env.last_kernel() == fam                                     # plain
+    ring = KERNEL_RING if N <= 64 else 0                                # the xpos ring rides on every step_fast64 launch
+    assert env.last_kernel() == fam | ring                              # plain
     chobs, rew = env.my_step(a, 1)
-    assert env.last_kernel() == fam | KERNEL_RICH
+    assert env.last_kernel() == fam | KERNEL_RICH | ring
     k = env.last_kernel()
     st = env.obtain_state(chobs, a, rew)                                  # served by the fused launch
     assert env.last_kernel() == k and st is env._obs
     env.my_step_ch(a, 2)
-    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_CH
+    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_CH | ring
     env.my_step_design(a, 0)
-    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_EXTRA
+    assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_EXTRA | ring
     env.force_general_kernel(True)
     env.step(a, 3)
     assert env.last_kernel() == KERNEL_GENERAL
@@ -1185,7 +1186,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         e2 = make_env(c2, B, dtype=torch.float64)
         e2.reset_topology(seed=4)
         e2.step(e2.sample(seed=2), 0)
-        assert e2.last_kernel() == want, (state, extra, e2.last_kernel())
+        assert (e2.last_kernel() & ~KERNEL_RING) == want, (state, extra, e2.last_kernel())
         e2.check()
     # what stays on the general kernel
     for state, extra in ((dict(add_positional_dist=True), {}), (dict(add_positional_dist_type=1), {}),
@@ -1230,3 +1231,53 @@ def test_specialised_kernels_are_faster_than_the_general_kernel(N, A, B):
     fast2, general2 = min(run(False, True), run(False, True)), min(run(True, True), run(True, True))
     assert general2 > 1.4 * fast2, (fast2, general2)
     assert fast2 < 1.35 * fast, (fast, fast2)       # the channel-observation output costs little
+
+
+@pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 9, 1500.0), (64, 16, 9000.0)])
+def test_xpos_ring_agrees_with_the_plane_through_every_consumer(N, A, L, monkeypatch):
+    """The N <= 64 kernel keeps the xpos of young entries in a per-subject ring and the per-entry plane only
+    for older ones (csrc/step_fast64.hpp).  Everything else that reads the plane - export_state, a stand-alone
+    obtain_state with foreign arguments (diral_env_observe), a step of the general kernel, import_state - must
+    see it completed first, and the ring must be rebuilt when another kernel moved the tables.  A ring env and
+    a DIRAL_NO_RING env (plane only, the round-2 kernel) take the same rollout with those calls mixed in; the
+    third topology is sparse enough for lags beyond the ring (keyed fallback, plane hand-over at lag 7)."""
+    from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RING
+    cfg = bench_config(N, A, L, mobility_vary=True, communication_range=250.0 if L < 5000 else 140.0)
+    B = 6
+    ring = make_env(cfg, B, dtype=torch.float64)
+    monkeypatch.setenv("DIRAL_NO_RING", "1")
+    plane = make_env(cfg, B, dtype=torch.float64)
+    monkeypatch.delenv("DIRAL_NO_RING")
+    for e in (ring, plane):
+        e.reset_topology(seed=41)
+    rng = np.random.default_rng(N + A)
+
+    def same_tables(t):
+        a, b = ring.export_state(), plane.export_state()
+        for k in ("seq", "age", "x", "pos_x", "vel"):
+            assert torch.equal(a[k], b[k]), (k, t)
+
+    for t in range(90):
+        acts = torch.as_tensor(rng.integers(0, A, size=(B, N)).astype(np.int32), device="cuda:0")
+        general = t in (17, 18, 40) or 60 <= t < 64                  # the general kernel takes over for some slots
+        for e in (ring, plane):
+            e.force_general_kernel(general)
+        (o1, r1, _), (o2, r2, _) = ring.step(acts, t), plane.step(acts, t)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2), t
+        assert ring.last_kernel() == (KERNEL_GENERAL if general else KERNEL_FAST64 | KERNEL_RING)
+        assert plane.last_kernel() == (KERNEL_GENERAL if general else KERNEL_FAST64)
+        if t % 7 == 3:
+            same_tables(t)                                           # export: the plane completed from the ring
+        if t % 11 == 5:                                              # foreign arguments: a diral_env_observe launch
+            fake = torch.full((B, N), 0.25, dtype=torch.float64, device="cuda:0")
+            s1 = ring.obtain_state(None, acts, fake).clone()
+            s2 = plane.obtain_state(None, acts, fake).clone()
+            assert torch.equal(s1, s2), t
+        if t == 30 or t == 71:                                       # checkpoint round trip through import_state
+            st = ring.export_state()
+            ring.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"], x=st["x"])
+        if t % 25 == 24:
+            for e in (ring, plane):
+                e.update_velocity(seed=t)
+    same_tables(90)
+    ring.check(); plane.check()
