@@ -179,7 +179,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const bool use_fast64 = spec && vpl == 1 && p.A <= kFastMaxA && p.NV == 64;
   const bool use_wide = spec && vpl > 1 && p.A <= kWideMaxA && flat_y && wide_rich_ok;
   // xpos ring (step_fast64.hpp): the N <= 64 kernel keeps the plane only for entries older than the ring reaches
-  const bool use_ring = use_fast64 && e->ring != nullptr;
+  const bool use_ring = (use_fast64 || use_wide) && e->ring != nullptr;
   if (use_ring) {
     const hipError_t st = ensure_ring(e, s);
     if (st != hipSuccess) return st;
@@ -365,8 +365,10 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   // end of a row without clamping (the values are masked, never stored)
   CREATE_TRY(alloc((void**)&e->tkey, (tab + 256) * 4));
   CREATE_TRY(alloc((void**)&e->tx, (tab + 256) * 8));
-#if DIRAL_FAST_RING
-  if (e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) {
+#if DIRAL_FAST_RING || DIRAL_WIDE_RING
+  // (DIRAL_NO_RING: test hook, N <= 64 only - the N > 64 kernels are built for the ring or without it)
+  if ((DIRAL_FAST_RING && e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) ||
+      (DIRAL_WIDE_RING && e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
     e->ring_valid = true;                                       // all tables zero: seq 0 -> slot 0 -> xpos 0

@@ -147,6 +147,16 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
 #endif
 // (thermo_codes(): step_fast64.hpp)
 
+// xpos ring (DIRAL_WIDE_RING, see step_fast64.hpp / aux_kernels.hpp): an entry's xpos is a function of
+// (subject, sequence number), the ring keeps every subject's 8 latest stamps, so the finalize phase fills
+// the rank -> xpos table of a column from the subject's ring row (8 lanes) instead of having all viewers
+// scatter their old xpos into it, and EVERY entry that lags at most 7 reads its xpos there.  The per-entry
+// xpos plane - two thirds of the table bytes - is only read for older entries and only written when an
+// entry reaches lag 7 (or copies an older one).
+#ifndef DIRAL_WIDE_RING
+#define DIRAL_WIDE_RING 1
+#endif
+
 #ifndef DIRAL_WIDE_WAVECONST
 #define DIRAL_WIDE_WAVECONST 1           // one copy of the merge loop per wave index: scratch base as an immediate offset
 #endif
@@ -571,6 +581,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
   const bool lds_base_is_zero = __builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u;
   const double inv_w = p.inv_w;
+#if DIRAL_WIDE_RING
+  const global_ptr<double> ringp = uniform_ptr(((LateFastArgs)late_kernarg_base())->ring, 0);
+#endif
 
   // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
   unsigned long long actw;
@@ -591,14 +604,17 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   unsigned int mycnt[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
+  // xmode 0: xpos is stored for the whole 64-viewer slot as soon as one of its entries changed
+  // (unchanged lanes rewrite their value): a lane-masked store leaves partially written
+  // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic.
+  // xmode 1 (xpos ring): only the lanes with `upd` set store (an entry at lag 7 or a copy of an older one: rare);
+  // xmode 2: every lane stores.
   auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, global_ptr<unsigned int> tkrow,
-                  global_ptr<double> txrow) {
+                  global_ptr<double> txrow, auto xmode_tag) {
+    constexpr int XMODE = decltype(xmode_tag)::value;
     const int u = lane + 64 * j;
     const bool lv = FULL || ((u < N) && kvalid);
-    // xpos is stored for the whole 64-viewer slot as soon as one of its entries changed
-    // (unchanged lanes rewrite their value): a lane-masked store leaves partially written
-    // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic
-    const bool slot_upd = __ballot(upd || u == k) != 0ull;
+    const bool slot_upd = XMODE == 0 ? (__ballot(upd || u == k) != 0ull) : (XMODE == 2 || upd);
     if (lv) {
       tkrow[(unsigned int)u] = wn;
       if (slot_upd) txrow[(unsigned int)u] = xg;
@@ -831,6 +847,61 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
       DIRAL_WCLOCK(tc2);
 
+#if DIRAL_WIDE_RING
+      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
+      //    extraction).  The rank -> xpos table of the column: the subject's 8 latest stamps from its ring row
+      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass), the few older entries
+      //    scatter their xpos from the plane; then EVERY entry reads its xpos by its final rank.
+      double rg = 0.0;
+      {
+        const unsigned int rc = ul >> 3, rl = ul & 7u;
+        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
+        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
+      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll FIN_UNROLL
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * w + cc;
+        const int k = kbase + c;
+        const bool kvalid = FULL || k < N;
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        const double pxk = s_px[kvalid ? k : 0];
+        if ((ul >> 3) == (unsigned int)c) {
+          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
+          const unsigned int l = ul & 7u;
+          xt[thermo ? ((0xffu << l) & 0xffu) : 255u - l] = (l == 0u) ? pxk : rg;
+          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
+        }
+        unsigned int rank0[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          rank0[j] = pick(kp0, j, w, cc);
+          // older than the ring reaches (codes: only the never-heard entries): the plane holds its xpos
+          const bool old = thermo ? rank0[j] == 0u : rank0[j] <= 247u;
+          if (old && (FULL || (u < N && kvalid))) xt[rank0[j]] = txrow[ul + 64u * j];
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int rf = pick(kp, j, w, cc);
+          const double xg = xt[rf];
+          const bool upd = rf != rank0[j];
+          // sequence number back from the rank / from the code (lag = 8 - popcount)
+          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
+          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, w, cc));
+          // the plane must hold the xpos of every entry the ring may not reach next slot: an entry that is now 7
+          // behind, or a fresh copy of an older one
+          const bool at7 = thermo ? rf == 0x80u : rf == 248u;
+          const bool far = thermo ? rf == 0x80u : (rf != 0u && rf <= 248u);
+          emit(k, kvalid, j, far && (upd || at7), wn, xg, tkrow, txrow, std::integral_constant<int, 1>{});
+        }
+        wave_lds_order();
+      }
+#else
       // -- xpos follows the winning sequence number; histogram.  One column at a time
       //    (rolled: uniform byte extraction): old xpos -> xt[old rank]; updated entries
       //    read xt[new rank].  The next column's xpos is loaded one iteration ahead.
@@ -903,10 +974,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           // sequence number back from the rank / from the code (lag = 8 - popcount)
           const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
           const unsigned int wn = (seqf << 8) | (upd ? 0u : (RELOAD ? age0[j] : pick(agew, j, w, cc)));
-          emit(k, kvalid, j, upd, wn, xg, tkrow, txrow);
+          emit(k, kvalid, j, upd, wn, xg, tkrow, txrow, std::integral_constant<int, 0>{});
         }
         wave_lds_order();
       }
+#endif
     } else {
       // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
       //    very stale tables: an entry with lag >= 255 and seq != 0)
@@ -948,12 +1020,27 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
         const double pxk = s_px[kvalid ? k : 0];
         double xo[VPL];
+#if DIRAL_WIDE_RING
+        unsigned int tk_own = 0u;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(ws[j] >> 8), k & 63);
+          tk_own = ((k >> 6) == j) ? cand : tk_own;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
           xo[j] = txrow[u < N ? u : 0];
+#if DIRAL_WIDE_RING
+          // a young entry's xpos is in the subject's ring row, not (necessarily) in the plane
+          if (tk_own - (ws[j] >> 8) <= 7u) xo[j] = ringp[(size_t)(bR + (kvalid ? k : 0)) * 8 + ((ws[j] >> 8) & 7u)];
+#endif
           xo[j] = (u == k) ? pxk : xo[j];
         }
+#if DIRAL_WIDE_RING
+        if (lane == 0 && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;   // this slot's stamp (after the row was read)
+#endif
         wave_lds_order();
 #pragma unroll
         for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
@@ -965,7 +1052,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
-          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow);
+          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow,
+               std::integral_constant<int, DIRAL_WIDE_RING ? 2 : 0>{});   // with the ring: the plane complete for this column
         }
         wave_lds_order();
       }

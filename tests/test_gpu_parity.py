@@ -1160,7 +1160,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     env.reset_topology(seed=3)
     a = env.sample(seed=1)
     env.step(a, 0)
-    ring = KERNEL_RING if N <= 64 else 0                                # the xpos ring rides on every step_fast64 launch
+    ring = KERNEL_RING                                                  # the xpos ring rides on every specialised launch
     assert env.last_kernel() == fam | ring                              # plain
     chobs, rew = env.my_step(a, 1)
     assert env.last_kernel() == fam | KERNEL_RICH | ring
