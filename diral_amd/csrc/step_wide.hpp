@@ -47,7 +47,7 @@ __host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DI
 #define DIRAL_WIDE_PC2 8                 // subject columns per merge pass, N <= 128
 #endif
 #ifndef DIRAL_WIDE_PC4
-#define DIRAL_WIDE_PC4 4                 // subject columns per merge pass, N <= 256
+#define DIRAL_WIDE_PC4 8                 // subject columns per merge pass, N <= 256 (4 until the xpos ring freed the registers: C3 -3.5 %)
 #endif
 // merge scratch per wave: a pass's rank words (one byte per column and viewer), then the
 // rank -> xpos table (256 doubles)
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= wide_scratch(VPL), "a pass's rank words fill at most the wave's scratch");
   constexpr uint32_t SCR = wide_scratch(VPL);
   static_assert(WAVES >= VPL && WAVES <= 8, "P2 runs on the first VPL waves; the merge loop has 8 per-wave copies");
+  static_assert(!DIRAL_WIDE_RING || 8 * PC <= 64, "xpos ring: one lane per (column, lag) of a pass");
   constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
   constexpr int MT = wide_mtab_stride(VPL);    // gather-source table row stride (elements)
   // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
