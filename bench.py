@@ -403,17 +403,15 @@ def main() -> int:
                 "kernel": res["kernel"],
                 "kernel_ms": res["kernel_ms"],
                 "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
-                # what this build's packed layout moves at least (N <= 64: 4-byte keys + the subjects' xpos rings,
-                # N > 64: 12 B per table entry, instead of the canonical 16 B of SURVEY 8d): its real HBM rate.
+                # what this build's packed layout moves at least (4-byte keys + the subjects' xpos rings instead of the
+                # canonical 16 B per entry of SURVEY 8d): its real HBM rate up to spill scratch.
                 # `frac` prices the CANONICAL bytes, so a layout that moves fewer can approach or pass 1.0 without
                 # the HBM being saturated - read it together with layout_frac_of_peak and the limiter
                 "layout_bytes_per_launch": res["layout_bytes_per_launch"],
                 "layout_rate_GBps": res["layout_rate_GBps"],
                 "layout_frac_of_peak": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
-                "limiter": ("VALU issue (~92 % busy); the xpos ring took the per-entry xpos plane - two thirds of the table "
-                            "bytes - off the HBM (real rate ~3.7 TB/s), see profiles/README.md") if N <= 64 else
-                           ("three pipes at once: LDS array ~0.7 busy (gossip merge), VALU ~0.7, HBM at ~0.85 of "
-                            "copy-kernel speed, see profiles/README.md"),
+                "limiter": "VALU issue (~0.9 busy); the xpos ring took the per-entry xpos plane - two thirds of the table bytes - "
+                           "off the HBM (real rate ~4 TB/s), see profiles/README.md",
             },
             "episode_metrics": totals,
         }

@@ -11,13 +11,13 @@ outputs:
 C2 (N=64, A=32, S=52): 155136 B/env-slot = 2424 B/agent-step.  This is the figure
 `roofline.achieved` is built from (the task's definition).
 
-The packed layout of this build moves fewer bytes: N > 64 12 B per entry (u32 key +
-f64 x), N <= 64 the 4-byte key only - the xpos of an entry that lags its subject by at
-most 7 stamps comes from an 8-deep per-subject ring (csrc/step_fast64.hpp), and in steady
-state that is every entry.  `layout_bytes_per_env_slot` is that figure (matches the
-rocprofv3 FETCH_SIZE / WRITE_SIZE counters within a few percent plus spill scratch,
-profiles/README.md).  bench.py reports both; the layout figure over the kernel time is the
-real HBM rate.
+The packed layout of this build moves fewer bytes: per table entry only the 4-byte key
+(sequence number, age) - the xpos of an entry that lags its subject by at most 7 stamps comes
+from an 8-deep per-subject ring (csrc/step_fast64.hpp, step_wide.hpp), and in
+steady state that is every entry; the per-entry xpos plane is touched only for older entries.
+`layout_bytes_per_env_slot` is that figure (the rocprofv3 FETCH_SIZE / WRITE_SIZE counters show
+it plus the register-spill scratch of the kernel, profiles/README.md).  bench.py reports both;
+the layout figure over the kernel time is the real HBM rate.
 """
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 
@@ -27,9 +27,8 @@ def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
 
 
 def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4) -> int:
-    """What csrc/step_fast64.hpp / step_wide.hpp move per env-slot in steady state: every table word read
-    and written once (N <= 64: the 4-byte key plus the subjects' ring rows read, one stamp each written;
-    N > 64: 12 B per entry), the per-vehicle arrays, reward and state, and the channel observation only
-    when it is requested."""
-    table = 2 * 4 * n * n + 64 * n + 8 * n if n <= 64 else 2 * 12 * n * n
+    """What csrc/step_fast64.hpp / step_wide.hpp move per env-slot in steady state: every table key read
+    and written once, the subjects' ring rows read and one stamp each written, the per-vehicle arrays, reward
+    and state, and the channel observation only when it is requested."""
+    table = 2 * 4 * n * n + 64 * n + 8 * n
     return table + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)
