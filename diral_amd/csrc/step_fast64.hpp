@@ -566,13 +566,19 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   double* const ringp = ring + ((size_t)b * p.NR + (has_cols ? wave * 16 : 0)) * 8;
   double ringv0 = 0.0, ringv1 = 0.0;
   if (use_ring) { ringv0 = ringp[lane]; ringv1 = ringp[64 + lane]; }
+  // thermo_ok: the coded merge serves the wave's columns - all sixteen, or (qkey >= 0) all but the four of code
+  // word qkey, which hold an entry older than the codes reach and are merged as 32-bit keys in a loop of their
+  // own in P3b (a straggler is usually ONE subject, sticky policies produce them: profiles/lag_distribution*.py).
+  // Two stale words or more: the whole wave takes 32-bit keys.  (Serving every stale word with such a loop was
+  // measured: 20 % slower on waves without any.)
   bool thermo_ok = false;
+  int qkey = -1;
   // codes after / before the merge and ages, column c in byte c & 3 of word c >> 2; lane c of `tkov`: the
   // fresh sequence number of column c's subject
   unsigned int cw[4], cold[4], agw[4] = {0u, 0u, 0u, 0u}, tkov = 0u;
   if (use_ring) {
     unsigned int lw[4] = {0u, 0u, 0u, 0u};
-    bool bad8 = false;
+    bool bad8[4] = {false, false, false, false};
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const unsigned int seq = w1[c] >> 8;
@@ -580,11 +586,17 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       tkov = (lane == c) ? tk_own : tkov;
       // lag byte 0..7, or 12 = never heard; anything else: not exact in this representation
       const unsigned int lagc = min(tk_own - seq, 12u);
-      bad8 = bad8 || (lagc >= 8u && (lagc < 12u || seq != 0u));
+      bad8[c >> 2] = bad8[c >> 2] || (lagc >= 8u && (lagc < 12u || seq != 0u));
       lw[c >> 2] |= lagc << (8 * (c & 3));
       agw[c >> 2] |= (w1[c] & 255u) << (8 * (c & 3));
     }
-    thermo_ok = (__ballot(bad8) == 0ull);
+    int nstale = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (__ballot(bad8[q]) != 0ull) { ++nstale; qkey = q; }
+    }
+    thermo_ok = nstale <= 1;
+    if (nstale != 1) qkey = -1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) cw[q] = cold[q] = thermo_codes(lw[q]);
     // this slot's stamps (vehicle.py:61-63: the subject's pre-move position under its fresh sequence
@@ -606,6 +618,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
   }
   if (thermo_ok) {
+    // (qkey >= 0: the codes of that word are merged along - meaningless, never read)
     unsigned long long rem = actw;
     int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
 #pragma unroll 1
@@ -660,11 +673,67 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(rv)),
                             __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
   };
+  // one column with a 32-bit key kf = (final seq << 8) | source lane: wr its table word as loaded, x_pl its xpos in the plane
+  const int own_col = live ? lane - wave * 16 : -1;
+  auto keyed_column = [&](int c, unsigned int kf, unsigned int wr, double x_pl) {
+    const int k = wave * 16 + c;
+    const int off = c * NV + lane;
+    // Vehicle.periodic_update again (vehicle.py:56-70)
+    const bool own = (own_col == c);
+    const unsigned int a0 = wr & 255u;
+    const unsigned int w = (((wr >> 8) + (own ? 1u : 0u)) << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
+    const bool upd = ((kf ^ w) >> 8) != 0u;
+    double x_cur = x_pl;
+    if (use_ring) {
+      // a young entry's xpos is in the ring, not (necessarily) in the plane
+      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+      const double xr = ring_x(c < 8 ? ringv0 : ringv1, c, w >> 8);
+      x_cur = (tk_own - (w >> 8) <= 7u) ? xr : x_cur;
+    }
+    const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
+    const int src4 = (int)(kf & 255u) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
+    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
+    const double xg = upd ? __hiloint2double(hi, lo) : xs;
+    const unsigned int wn = upd ? (kf & ~255u) : w;
+    tk[off] = wn;
+    if (use_ring || upd || lane == k) txp[off] = xg;            // with the ring: the plane complete for these columns
+    tally(k, wn, xg);
+  };
   if (thermo_ok) {
+    if (qkey >= 0 && has_cols) {
+      // the stale word's four columns: 32-bit keys (seq << 8) | source lane from the table words as loaded,
+      // a merge loop of their own, then column by column (the keys rotate through kq[0])
+      unsigned int kq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * qkey + i;
+        const unsigned int w = tk[c * NV + lane];
+        kq[i] = (((w >> 8) + (own_col == c ? 1u : 0u)) << 8) | (unsigned int)lane;
+      }
+      unsigned long long rem = actw;
+      int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
+#pragma unroll 1
+      while (rem) {
+        rem &= rem - 1;
+        const int m4 = m_next;
+        if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
+      }
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * qkey + i;
+        const unsigned int kf = kq[0];
+        kq[0] = kq[1]; kq[1] = kq[2]; kq[2] = kq[3];
+        keyed_column(c, kf, tk[c * NV + lane], txp[c * NV + lane]);
+      }
+    }
     // (four rolled loops of four columns, one per packed word: a dynamically indexed word array would live
     // in scratch memory, a register rotation costs a dozen moves per column)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (q == qkey) continue;
       const double rv = q >= 2 ? ringv1 : ringv0;
       const unsigned int cnq = cw[q], coq = cold[q], agq = agw[q];
 #pragma unroll 1
@@ -716,37 +785,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // (a rolled loop with uniform register indexing of key[]; the table word is re-read - it is what
     // w1[c] held before the stamp - rather than indexed: a second dynamically indexed array would put
     // both in scratch memory.  The next column's xpos and word are loaded one iteration ahead.)
-    const int own_c = live ? lane - wave * 16 : -1;
     double x_next = has_cols ? txp[lane] : 0.0;
     unsigned int w_next = has_cols ? tk[lane] : 0u;
 #pragma unroll 1
     for (int c = 0; c < ncol; ++c) {
-      const int k = wave * 16 + c;
-      const int off = c * NV + lane;
-      const unsigned int kf = key[c];
       const unsigned int wr = w_next;
-      double x_cur = x_next;
-      if (c + 1 < ncol) { x_next = txp[off + NV]; w_next = tk[off + NV]; }
-      // Vehicle.periodic_update again (vehicle.py:56-70)
-      const bool own = (own_c == c);
-      const unsigned int a0 = wr & 255u;
-      const unsigned int w = (((wr >> 8) + (own ? 1u : 0u)) << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
-      const bool upd = ((kf ^ w) >> 8) != 0u;
-      if (use_ring) {
-        // a young entry's xpos is in the ring, not (necessarily) in the plane
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        const double xr = ring_x(c < 8 ? ringv0 : ringv1, c, w >> 8);
-        x_cur = (tk_own - (w >> 8) <= 7u) ? xr : x_cur;
-      }
-      const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
-      const int src4 = (int)(kf & 255u) << 2;
-      const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
-      const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
-      const double xg = upd ? __hiloint2double(hi, lo) : xs;
-      const unsigned int wn = upd ? (kf & ~255u) : w;
-      tk[off] = wn;
-      if (use_ring || upd || lane == k) txp[off] = xg;            // with the ring: the plane complete for these columns
-      tally(k, wn, xg);
+      const double x_pl = x_next;
+      if (c + 1 < ncol) { x_next = txp[(c + 1) * NV + lane]; w_next = tk[(c + 1) * NV + lane]; }
+      keyed_column(c, key[c], wr, x_pl);
     }
   }
 #else

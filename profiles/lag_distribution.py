@@ -1,4 +1,4 @@
-import sys, torch, numpy as np
+import os, sys, torch, numpy as np
 sys.path.insert(0, ".")
 from diral_amd.config import bench_config
 from diral_amd.vec_env import VecV2VEnv
@@ -6,8 +6,16 @@ for name,(N,A,L,vary) in {"c3":(256,64,4000.0,False),"c5":(128,64,4000.0,True),"
     cfg = bench_config(N, A, L, mobility_vary=vary)
     env = VecV2VEnv(cfg, batch=16)
     env.reset_topology(seed=1234)
-    for t in range(120):
-        env.step(env.sample(seed=1000+t), t)
+    sticky = float(os.environ.get("STICKY", "0"))                # probability an agent keeps its resource (converged policy)
+    acts = env.sample(seed=999)
+    for t in range(160):
+        new = env.sample(seed=1000+t)
+        if sticky > 0:
+            keep = torch.rand((16, N), device=acts.device) < sticky
+            acts = torch.where(keep, acts, new)
+        else:
+            acts = new
+        env.step(acts, t)
         if t % 25 == 24: env.update_velocity(seed=t)
     st = env.export_state()
     seq = st["seq"].cpu().numpy().astype(np.int64)   # [B][N(subject k)][N(viewer u)]?

@@ -24,9 +24,14 @@ NW = {"c2": 4, "c3": 8 if not os.environ.get("DIRAL_NO_WIDE") else 16, "c5": 8}[
 GENERAL = WL != "c2"
 env = VecV2VEnv(cfg, batch=B, out_dtype=torch.float32)
 env.reset_topology(seed=1)
-acts = [env.sample(seed=i) for i in range(8)]
-for t in range(60):
-    env.step(acts[t % 8], t)
+STICKY = float(os.environ.get("STICKY", "0"))            # probability an agent keeps its resource (converged policy)
+acts = [env.sample(seed=i) for i in range(64)]
+if STICKY > 0:
+    for i in range(1, 64):
+        keep = torch.rand(acts[i].shape, device=acts[i].device) < STICKY
+        acts[i] = torch.where(keep, acts[i - 1], acts[i])
+for t in range(64):
+    env.step(acts[t], t)
 torch.cuda.synchronize()
 fn = env.lib.diral_env_debug_timing
 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
