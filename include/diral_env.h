@@ -147,7 +147,10 @@ int diral_env_abi_version(void);
 
 /* Replaces TestEnv.__init__ -> Network.__init__ (test_env.py:7-107,
  * network.py:15-67) for B independent envs on HIP device `device`.
- * Allocates all persistent state in HBM; tables zeroed (vehicle.py:24-33). */
+ * Allocates all persistent state in HBM; tables zeroed (vehicle.py:24-33).
+ * Test hooks, read from the process environment ONCE here: DIRAL_NO_FAST64 /
+ * DIRAL_NO_WIDE (the general kernel also for N <= 64 / N > 64), DIRAL_NO_RING
+ * (N <= 64: no xpos ring, every xpos in the per-entry plane). */
 int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out);
 int diral_env_destroy(DiralEnv* env);
 
