@@ -704,12 +704,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (qkey >= 0 && has_cols) {
       // the stale word's four columns: 32-bit keys (seq << 8) | source lane from the table words as loaded,
       // a merge loop of their own, then column by column (the keys rotate through kq[0])
-      unsigned int kq[4];
+      unsigned int kq[4], wr4[4];
+      double xp4[4];                              // (all eight loads in flight together: one round trip, not four)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = 4 * qkey + i;
-        const unsigned int w = tk[c * NV + lane];
-        kq[i] = (((w >> 8) + (own_col == c ? 1u : 0u)) << 8) | (unsigned int)lane;
+        wr4[i] = tk[c * NV + lane];
+        xp4[i] = txp[c * NV + lane];
+        kq[i] = (((wr4[i] >> 8) + (own_col == c ? 1u : 0u)) << 8) | (unsigned int)lane;
       }
       unsigned long long rem = actw;
       int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
@@ -721,13 +723,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #pragma unroll
         for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
       }
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int c = 4 * qkey + i;
-        const unsigned int kf = kq[0];
-        kq[0] = kq[1]; kq[1] = kq[2]; kq[2] = kq[3];
-        keyed_column(c, kf, tk[c * NV + lane], txp[c * NV + lane]);
-      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) keyed_column(4 * qkey + i, kq[i], wr4[i], xp4[i]);
     }
     // (four rolled loops of four columns, one per packed word: a dynamically indexed word array would live
     // in scratch memory, a register rotation costs a dozen moves per column)
