@@ -611,6 +611,9 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
     hipLaunchKernelGGL(import_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, tab_seq,
                        tab_age, tab_x, e->tkey, e->tx);
     HIP_TRY(e, hipGetLastError());
+    // the ring again, right away (not at the next step: a step sequence captured into a hipGraph must not
+    // contain a rebuild from a plane that later replays find stale)
+    if (e->ring) HIP_TRY(e, ensure_ring(e, s));
   }
   if (last_arrival) {
     if (!e->la) return DIRAL_ERR_BAD_CONFIG;

@@ -260,7 +260,10 @@ int diral_env_set_trace(DiralEnv* env, const double* x_positions, int T, int per
  * exported state qualifies).  The kernels build on it: N <= 64 keeps the xpos of
  * entries at most 7 stamps old in a per-subject ring instead of the per-entry
  * plane, N > 64 routes xpos through a rank-indexed table; export / observe /
- * other consumers see the plane completed first (no caller-visible difference). */
+ * other consumers see the plane completed first (no caller-visible difference;
+ * inside ONE captured hipGraph do not switch DIRAL_OPT_KERNEL_PATH between steps:
+ * the ring is rebuilt lazily after a step of the general kernel, and a captured
+ * rebuild would replay against a plane that is no longer complete). */
 int diral_env_export_state(DiralEnv* env, double* pos_x, double* pos_y,
                            double* vel, int32_t* tab_seq, int32_t* tab_age,
                            double* tab_x, double* tab_y, int32_t* last_arrival,
