@@ -1124,15 +1124,30 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       out_t* const co = static_cast<out_t*>(rr.chobs_out) + bN * A;
       if ((A % CV) == 0) {
         const int qpr = A / CV, total = N * qpr;
+        // (row, piece) advance incrementally: one integer division per thread, not one per store; the
+        // transmitter bits of the piece's resources and the byte lane of the viewer's gather sources are
+        // taken once per piece
+        const int du = THREADS / qpr, dq = THREADS - du * qpr;
+        int u = tid / qpr, qr = tid - u * qpr;
         for (int q = tid; q < total; q += THREADS) {
-          const int u = q / qpr, i0 = (q - u * qpr) * CV;
+          const int i0 = qr * CV;
           const int a = s_act[u];
           const double xu = s_px[u];
-          if constexpr (OUT64)
-            stream_store2(co + 2 * q, make_double2(chv_row(u, a, xu, i0), chv_row(u, a, xu, i0 + 1)));
-          else
-            stream_store4(co + 4 * q, make_float4((float)chv_row(u, a, xu, i0), (float)chv_row(u, a, xu, i0 + 1),
-                                                  (float)chv_row(u, a, xu, i0 + 2), (float)chv_row(u, a, xu, i0 + 3)));
+          const unsigned int tx_bits = (unsigned int)(actw >> i0);
+          const unsigned int sh = 8u * (unsigned int)(u >> 6);
+          const mword_t* const mrow = s_mtab + (u & 63);
+          auto piece = [&](int d) -> double {
+            const int i = i0 + d;
+            if (a == i || ((tx_bits >> d) & 1u) == 0u) return 0.0;
+            if (!dist_obs) return 1.0;
+            const int src = (int)(((unsigned int)mrow[i * MT] >> sh) & 255u);
+            if (src == u) return 100000.0;                                    // network.py:385
+            return fast_dist<true>(s_px[src], 0.0, xu, 0.0);
+          };
+          if constexpr (OUT64) stream_store2(co + 2 * q, make_double2(piece(0), piece(1)));
+          else stream_store4(co + 4 * q, make_float4((float)piece(0), (float)piece(1), (float)piece(2), (float)piece(3)));
+          u += du; qr += dq;
+          if (qr >= qpr) { qr -= qpr; u += 1; }
         }
       } else {
         for (int e = tid; e < N * A; e += THREADS) {
