@@ -291,7 +291,9 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #define DIRAL_WCLOCK(v) do {} while (0)
 #endif
 #ifndef DIRAL_WIDE_MINWAVES2
-#define DIRAL_WIDE_MINWAVES2 6           // N <= 128: 84 VGPRs, three 512-thread workgroups per CU (1.61 / 1.68 / 1.76 ms for 6 / 7 / 8)
+#define DIRAL_WIDE_MINWAVES2 8           // N <= 128: 64 VGPRs, four 512-thread workgroups per CU (35 KB of LDS each).  Before the xpos ring
+                                         // freed the xpos prefetch registers: 1.61 / 1.68 / 1.76 ms for 6 / 7 / 8; with it 1.375 / 1.386 / 1.349 ms
+                                         // (with the channel observation 1.46 / 1.47 / 1.33)
 #endif
 #ifndef DIRAL_WIDE_MINWAVES4
 #define DIRAL_WIDE_MINWAVES4 6           // N <= 256: 84 VGPRs, three 512-thread workgroups per CU
