@@ -33,7 +33,8 @@
 namespace diral {
 
 #ifndef DIRAL_FAST_MINWAVES
-#define DIRAL_FAST_MINWAVES 8           // <= 64 VGPRs: 8 waves/SIMD (the phases are latency-bound; occupancy pays)
+#define DIRAL_FAST_MINWAVES 7           // <= 72 VGPRs, 7 waves/SIMD.  8 (64 VGPRs) was the optimum while the phases were latency-bound;
+                                        // with the xpos ring (VALU-bound, 15 spilled registers at 64) 7 is 3 % faster, 6 no better
 #endif
 #ifndef DIRAL_PACKED_MERGE
 #define DIRAL_PACKED_MERGE 1           // 16-bit packed gossip merge (exact; falls back per wave)
