@@ -397,6 +397,9 @@ def main() -> int:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": res["frac"],
+                "frac_note": "achieved = SURVEY 8d's ALGORITHMIC bytes (canonical 16-byte table entry, read + written) / kernel time; "
+                             "this build moves a 4-byte key per entry plus per-subject xpos rings (DESIGN.md 2), so frac can "
+                             "approach or pass 1.0 with the HBM far from saturated: see layout_frac_of_peak and limiter",
                 "traffic": traffic,
                 "traffic_source": ("committed PMC passes of this command, not measured in this run: %s" % tr.get("source")) if tr else None,
                 "traffic_rate_GBps": (traffic / (res["kernel_ms"] * 1e-3) / 1e9) if traffic else None,
