@@ -139,6 +139,9 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
 #ifndef DIRAL_WIDE_THERMO
 #define DIRAL_WIDE_THERMO 1
 #endif
+#ifndef DIRAL_WIDE_BITTEST4
+#define DIRAL_WIDE_BITTEST4 0           // N <= 256: the lag encoder's range test in its straight-line form (see the encoder)
+#endif
 #ifndef DIRAL_WIDE_PIN2
 #define DIRAL_WIDE_PIN2 1               // N <= 128: pin the packed words in front of the pass's exit test (C5 -3.6 %)
 #endif
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         // ('||' / '&&' compile to exec-mask control flow per entry, the bitwise form to straight-line code: the
         // latter is 8 % faster on the plain N <= 128 kernel, 4 % slower on its RICH instantiation and 25 % SLOWER at
         // N <= 256 - register allocation - so each gets the form that measured best)
-        if constexpr (VPL == 2 && !RICH) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
+        if constexpr ((VPL == 2 && !RICH) || (VPL == 4 && DIRAL_WIDE_BITTEST4 != 0)) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
         else bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
         kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
         if constexpr (!RELOAD) agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
