@@ -139,6 +139,9 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
 #ifndef DIRAL_WIDE_THERMO
 #define DIRAL_WIDE_THERMO 1
 #endif
+#ifndef DIRAL_WIDE_INFLIGHT
+#define DIRAL_WIDE_INFLIGHT 16          // table words a lane has in flight while a pass loads its columns
+#endif
 #ifndef DIRAL_WIDE_BITTEST4
 #define DIRAL_WIDE_BITTEST4 0           // N <= 256: the lag encoder's range test in its straight-line form (see the encoder)
 #endif
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     tkov = 0u;
     bool bad = false;
     // (16 table words in flight at a time: LC columns x VPL slots)
-    constexpr int LC = 16 / VPL;
+    constexpr int LC = DIRAL_WIDE_INFLIGHT / VPL;
 #pragma unroll
     for (int c0 = 0; c0 < PC; c0 += LC) {
     unsigned int wraw[LC * VPL];
