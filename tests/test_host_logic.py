@@ -187,3 +187,14 @@ def test_metric_allreduce_over_gloo_world2():
         assert summ["envs"] == 10 and summ["env_slots"] == 250
         assert abs(summ["prr"] - (40 + e).sum() / 640.0) < 1e-12
         assert abs(summ["collision_fraction"] - (54 - e).sum() / 640.0) < 1e-12
+
+
+def test_byte_models_of_the_roofline_bookkeeping():
+    """SURVEY 8d's algorithmic bytes per env-slot (what `roofline.achieved` is built from) at the three bench
+    configurations, and this build's layout bytes (4-byte keys + the subjects' xpos rings)."""
+    from diral_amd.roofline import algorithmic_bytes_per_env_slot as alg, layout_bytes_per_env_slot as lay
+    assert alg(64, 32, 52) == 155136 and alg(256, 64, 84) == 2258944 and alg(128, 64, 84) == 605184
+    # keys read + written, ring rows read + one stamp written, per-vehicle arrays, reward, state (+ channel observation)
+    assert lay(64, 32, 52, False) == 2 * 4 * 64 * 64 + 72 * 64 + 36 * 64 + 4 * 64 + 4 * 64 * 52
+    assert lay(64, 32, 52, True) - lay(64, 32, 52, False) == 4 * 64 * 32
+    assert lay(256, 64, 84, False) < alg(256, 64, 84) // 4
