@@ -197,4 +197,4 @@ def test_byte_models_of_the_roofline_bookkeeping():
     # keys read + written, ring rows read + one stamp written, per-vehicle arrays, reward, state (+ channel observation)
     assert lay(64, 32, 52, False) == 2 * 4 * 64 * 64 + 72 * 64 + 36 * 64 + 4 * 64 + 4 * 64 * 52
     assert lay(64, 32, 52, True) - lay(64, 32, 52, False) == 4 * 64 * 32
-    assert lay(256, 64, 84, False) < alg(256, 64, 84) // 4
+    assert lay(256, 64, 84, False) == 638976 and 3 * lay(256, 64, 84, False) < alg(256, 64, 84)
