@@ -186,7 +186,9 @@ __device__ inline double fast_dist(double x1, double y1, double x2, double y2) {
   const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
   // (one-sided: beyond 2^500 the square overflows to inf in the reference while |dx| stays finite, but every
   // use of the result compares it with a finite range first - `d < Rc`, `d < Rb`, `d > Rc` - and agrees)
-  const bool in_range = hi >= 0x20b00000u;
+  // ... or dx == 0 exactly, where sqrt(0) == |dx| == 0 as well: the search of P1 measures every transmitter against
+  // ITSELF too, so without this case each of its iterations pays the out-of-line call for that one lane
+  const bool in_range = hi >= 0x20b00000u || (hi | (unsigned int)__double2loint(dx)) == 0u;
   if (FLAT) {
     if (in_range) return __hiloint2double((int)hi, __double2loint(dx));
     return dist_general(dx, 0.0);
