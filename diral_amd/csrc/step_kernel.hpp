@@ -71,7 +71,8 @@ __device__ __attribute__((noinline)) double dist_general(double dx, double dy) {
 __device__ inline double dist2d(double x1, double y1, double x2, double y2) {
   const double dx = x2 - x1, dy = y2 - y1;
   const double ax = __builtin_fabs(dx);
-  if (dy == 0.0 && ax >= 0x1p-500 && ax <= 0x1p500) return ax;
+  // (dx == 0 as well: sqrt(0) == 0 - a vehicle measured against itself, as the transmitter search does)
+  if (dy == 0.0 && (ax == 0.0 || (ax >= 0x1p-500 && ax <= 0x1p500))) return ax;
   return dist_general(dx, dy);
 }
 
