@@ -23,6 +23,7 @@ SYMBOLS = [
     "diral_env_metrics", "diral_env_check", "diral_env_last_hip_error", "diral_sps_step", "diral_sps_init",
     "diral_env_set_trace", "diral_env_set_option", "diral_env_last_kernel",
     "diral_sps_window_from_chobs", "diral_sps_step_chobs", "diral_driver_shape",
+    "diral_env_export_entries", "diral_env_import_entries",
 ]
 
 _lib = None
@@ -68,6 +69,8 @@ def load() -> ctypes.CDLL:
         "diral_env_info_age": (I, [P, I64, P, P]),
         "diral_env_export_state": (I, [P] + [P] * 8 + [P]),
         "diral_env_import_state": (I, [P] + [P] * 7 + [P]),
+        "diral_env_export_entries": (I, [P, P, P]),
+        "diral_env_import_entries": (I, [P, P, P]),
         "diral_env_metrics": (I, [P, P, I, P]),
         "diral_env_check": (I, [P, P]),
         "diral_env_last_hip_error": (ctypes.c_char_p, [P]),

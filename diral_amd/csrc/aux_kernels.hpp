@@ -126,6 +126,39 @@ __global__ void import_tables_kernel(int B, int N, int NV, int NR, const int32_t
   if (x) tx[dst] = x[i];
 }
 
+// The tables as RealNeS MA_NeighborTableEntry records (diral_env.h: DiralNeighborEntry), one 16-byte
+// record per thread: a coalesced dwordx4 on the record side, a stride-NV gather on the plane side.
+__global__ void export_entries_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* tx,
+                                      const double* pos_y, DiralNeighborEntry* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * N * N) return;
+  const int k = (int)(i % N);
+  const int u = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t src = ((size_t)b * NR + k) * NV + u;
+  const uint32_t w = tkey[src];
+  DiralNeighborEntry r;
+  r.pos_x = (float)tx[src];
+  r.pos_y = (w >> 8) ? (float)pos_y[(size_t)b * N + k] : 0.0f;
+  r.seq_num = (int32_t)(w >> 8);
+  r.last_update = (int32_t)(w & 255u);
+  out[i] = r;
+}
+
+__global__ void import_entries_kernel(int B, int N, int NV, int NR, const DiralNeighborEntry* in, uint32_t* tkey,
+                                      double* tx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * N * N) return;
+  const int k = (int)(i % N);
+  const int u = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t dst = ((size_t)b * NR + k) * NV + u;
+  const DiralNeighborEntry r = in[i];
+  const int a = r.last_update > 255 ? 255 : (r.last_update < 0 ? 0 : r.last_update);
+  tkey[dst] = ((uint32_t)r.seq_num << 8) | (uint32_t)a;
+  tx[dst] = (double)r.pos_x;
+}
+
 // Network.get_information_age (network.py:560-574); one workgroup per env.
 // Python's negative list indexing (ia in [-100,-1]) is reproduced.
 __global__ void info_age_kernel(int N, long long t, const int32_t* la, int32_t* out) {

@@ -622,6 +622,32 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
   return DIRAL_OK;
 }
 
+int diral_env_export_entries(DiralEnv* e, DiralNeighborEntry* entries, void* stream) {
+  if (!e || !entries) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)e->B * e->N * e->N;
+  HIP_TRY(e, ensure_plane(e, s));
+  hipLaunchKernelGGL(export_entries_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
+                     e->tx, e->pos_y, entries);
+  HIP_TRY(e, hipGetLastError());
+  return DIRAL_OK;
+}
+
+int diral_env_import_entries(DiralEnv* e, const DiralNeighborEntry* entries, void* stream) {
+  if (!e || !entries) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)e->B * e->N * e->N;
+  e->plane_valid = true;                                        // every entry of the plane is rewritten
+  e->ring_valid = false;
+  hipLaunchKernelGGL(import_entries_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, entries,
+                     e->tkey, e->tx);
+  HIP_TRY(e, hipGetLastError());
+  if (e->ring) HIP_TRY(e, ensure_ring(e, s));                    // as in diral_env_import_state
+  return DIRAL_OK;
+}
+
 int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_env, void* stream) {
   if (!e || T < 0) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);

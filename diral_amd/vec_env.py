@@ -14,11 +14,15 @@ from __future__ import annotations
 import ctypes
 from typing import Any, Dict, Mapping, Optional, Tuple, Union
 
+import numpy as np
 import torch
 
 from . import _lib
 from .config import (DT_F32, DT_F64, ERR_HIP, M_COLUMNS, OK, OPT_ENV_OFFSET, OPT_KERNEL_PATH, PATH_AUTO,
                      PATH_GENERAL, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, ConfigError, EnvConfig)
+
+# MA_NeighborTableEntry (envs/ma_messages_pb2.py:195-230) as a host view of DiralNeighborEntry
+ENTRY_DTYPE = np.dtype([("pos_x", "<f4"), ("pos_y", "<f4"), ("seq_num", "<i4"), ("last_update", "<i4")])
 
 _MODES = {"my_step": STEP_MY_STEP, "my_step_ch": STEP_MY_STEP_CH, "my_step_design": STEP_DESIGN,
           STEP_MY_STEP: STEP_MY_STEP, STEP_MY_STEP_CH: STEP_MY_STEP_CH, STEP_DESIGN: STEP_DESIGN}
@@ -424,6 +428,26 @@ class VecV2VEnv:
         self._ok(self.lib.diral_env_import_state(self._h, _ptr(px), _ptr(py), _ptr(v), _ptr(s), _ptr(a), _ptr(xx),
                                                  _ptr(l), self._stream()), "diral_env_import_state")
         torch.cuda.current_stream(self.device).synchronize()   # inputs may be temporaries
+
+    def export_entries(self) -> torch.Tensor:
+        """The neighbour tables as RealNeS `MA_NeighborTableEntry` records (envs/ma_messages_pb2.py:195-230;
+        realness_bridge.py:168-191): [B, N, N, 16] uint8 indexed [env, viewer, subject];
+        `.cpu().numpy().view(ENTRY_DTYPE)[..., 0]` names the fields (pos_x, pos_y f32; seq_num, last_update i32)."""
+        out = torch.empty((self.B, self.N, self.N, 16), dtype=torch.uint8, device=self.device)
+        self._ok(self.lib.diral_env_export_entries(self._h, _ptr(out), self._stream()), "diral_env_export_entries")
+        return out
+
+    def import_entries(self, entries) -> None:
+        """Load tables received in the RealNeS record layout (a [B, N, N] ENTRY_DTYPE array or the uint8
+        tensor `export_entries` returns); pos_y is ignored, pos_x widens exactly to f64."""
+        if isinstance(entries, np.ndarray):
+            entries = torch.from_numpy(np.ascontiguousarray(entries).view(np.uint8).reshape(entries.shape[:3] + (16,)))
+        rec = entries.to(device=self.device, dtype=torch.uint8).contiguous()
+        if tuple(rec.shape) != (self.B, self.N, self.N, 16):
+            raise ValueError("entries must be [B, N, N] records of 16 bytes, got %s" % (tuple(rec.shape),))
+        self._spec = None
+        self._ok(self.lib.diral_env_import_entries(self._h, _ptr(rec), self._stream()), "diral_env_import_entries")
+        torch.cuda.current_stream(self.device).synchronize()   # `rec` may be a temporary
 
     def info_age(self, t: int) -> torch.Tensor:
         """network.py:560-574 (`env.network.get_information_age(t)`), [B, 100] int32."""

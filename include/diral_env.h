@@ -274,6 +274,22 @@ int diral_env_import_state(DiralEnv* env, const double* pos_x,
                            const double* tab_x, const int32_t* last_arrival,
                            void* stream);
 
+/* The same tables as 16-byte records in the field order of the RealNeS bridge's
+ * MA_NeighborTableEntry message (envs/ma_messages_pb2.py:195-230: float pos_x,
+ * float pos_y, int32 seq_num, int32 last_update - what
+ * realness_bridge.py:168-191 unpacks into the pos_of_neighbors dict the
+ * observation code reads).  entries [B][N][N] device records indexed
+ * [env][viewer][subject].  export narrows the f64 positions to f32 (round to
+ * nearest); import widens pos_x exactly, ignores pos_y (an entry's ypos is the
+ * subject's lane) and saturates last_update at 255 like
+ * diral_env_import_state, whose reachability note applies. */
+typedef struct DiralNeighborEntry {
+  float pos_x, pos_y;
+  int32_t seq_num, last_update;
+} DiralNeighborEntry;
+int diral_env_export_entries(DiralEnv* env, DiralNeighborEntry* entries, void* stream);
+int diral_env_import_entries(DiralEnv* env, const DiralNeighborEntry* entries, void* stream);
+
 /* ---- metrics ------------------------------------------------------------------ */
 
 /* out [B][DIRAL_M_COLUMNS] float64 device array; clear != 0 zeroes the

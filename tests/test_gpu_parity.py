@@ -1281,3 +1281,50 @@ def test_xpos_ring_agrees_with_the_plane_through_every_consumer(N, A, L, monkeyp
                 e.update_velocity(seed=t)
     same_tables(90)
     ring.check(); plane.check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 16, 6000.0), (128, 64, 4000.0), (200, 40, 12000.0)])
+def test_realnes_entry_records_round_trip_and_feed_the_step(N, A, L):
+    """diral_env_export_entries / diral_env_import_entries: the tables as the RealNeS bridge's
+    MA_NeighborTableEntry records (envs/ma_messages_pb2.py:195-230, unpacked at realness_bridge.py:168-191).
+    The records must carry exactly export_state's planes (positions narrowed to f32), and an env loaded from
+    records must continue bit-for-bit like one loaded from the same values through import_state, on both
+    kernel families (the xpos ring is rebuilt from what the records hold)."""
+    from diral_amd.vec_env import ENTRY_DTYPE
+    assert ENTRY_DTYPE.itemsize == 16
+    cfg = bench_config(N, A, L, mobility_vary=True, communication_range=250.0 if L < 5000 else 140.0)
+    B = 5
+    src, via_rec, via_planes = (make_env(cfg, B, dtype=torch.float64) for _ in range(3))
+    src.reset_topology(seed=77)
+    rng = np.random.default_rng(N * 3 + A)
+    draw = lambda: torch.as_tensor(rng.integers(0, A, size=(B, N)).astype(np.int32), device="cuda:0")
+    for t in range(45):
+        src.step(draw(), t)
+    st = src.export_state()
+    rec = src.export_entries()
+    host = rec.cpu().numpy().view(ENTRY_DTYPE)[..., 0]
+    assert host.shape == (B, N, N)
+    assert np.array_equal(host["seq_num"], st["seq"].cpu().numpy())
+    assert np.array_equal(host["last_update"], st["age"].cpu().numpy())
+    assert np.array_equal(host["pos_x"], st["x"].cpu().numpy().astype(np.float32))
+    assert np.array_equal(host["pos_y"], st["y"].cpu().numpy().astype(np.float32))
+    assert (host["seq_num"] > 0).any() and (host["seq_num"] == 0).any() == (L > 5000)
+
+    for e in (via_rec, via_planes):
+        e.reset_topology(seed=1)
+    via_rec.import_state(st["pos_x"], st["pos_y"], st["vel"])
+    via_rec.import_entries(host if N != 64 else rec)               # the ndarray and the tensor form
+    via_planes.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"],
+                            x=st["x"].float().double())
+    assert torch.equal(via_rec.export_entries(), rec)              # records survive the round trip
+    for t in range(45, 85):
+        acts = draw()
+        (o1, r1, _), (o2, r2, _) = via_rec.step(acts, t), via_planes.step(acts, t)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2), t
+        assert via_rec.last_kernel() == via_planes.last_kernel()
+    a, b = via_rec.export_state(), via_planes.export_state()
+    for k in ("seq", "age", "x", "pos_x"):
+        assert torch.equal(a[k], b[k]), k
+    with pytest.raises(ValueError):
+        via_rec.import_entries(rec[:, :, :-1])
