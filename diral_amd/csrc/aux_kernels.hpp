@@ -79,7 +79,7 @@ __global__ void export_tables_kernel(int B, int N, int NV, int NR, const uint32_
   if (y) y[i] = (w >> 8) ? pos_y[(size_t)b * N + k] : 0.0;
 }
 
-// The xpos ring of the N <= 64 kernel (step_fast64.hpp, DIRAL_FAST_RING): ring[env][subject][seq & 7]
+// The xpos ring of the N <= 64 kernel (step_fast64.hpp): ring[env][subject][seq & 7]
 // is the subject's stamp at sequence number `seq`, for its 8 most recent numbers.  An entry that
 // lags its subject by at most 7 finds its xpos there; only older entries need the per-entry plane.
 // rebuild: plane -> ring (after an import or a step of another kernel family); materialise: ring ->

@@ -365,15 +365,13 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   // end of a row without clamping (the values are masked, never stored)
   CREATE_TRY(alloc((void**)&e->tkey, (tab + 256) * 4));
   CREATE_TRY(alloc((void**)&e->tx, (tab + 256) * 8));
-#if DIRAL_FAST_RING || DIRAL_WIDE_RING
-  // (DIRAL_NO_RING: test hook, N <= 64 only - the N > 64 kernels are built for the ring or without it)
-  if ((DIRAL_FAST_RING && e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) ||
-      (DIRAL_WIDE_RING && e->vpl > 1 && e->A <= kWideMaxA)) {
+  // the xpos ring of the specialised kernels (DIRAL_NO_RING: test hook, N <= 64 only - that kernel also runs
+  // from the plane alone, the N > 64 kernels are built for the ring)
+  if ((e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) || (e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
     e->ring_valid = true;                                       // all tables zero: seq 0 -> slot 0 -> xpos 0
   }
-#endif
   CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(alloc((void**)&e->err, 4));
   CREATE_TRY(alloc((void**)&e->yflag, 4));

@@ -36,13 +36,7 @@ namespace diral {
 #define DIRAL_FAST_MINWAVES 7           // <= 72 VGPRs, 7 waves/SIMD.  8 (64 VGPRs) was the optimum while the phases were latency-bound;
                                         // with the xpos ring (VALU-bound, 15 spilled registers at 64) 7 is 3 % faster, 6 no better
 #endif
-#ifndef DIRAL_PACKED_MERGE
-#define DIRAL_PACKED_MERGE 1           // 16-bit packed gossip merge (exact; falls back per wave)
-#endif
 
-#ifndef DIRAL_FAST_RING
-#define DIRAL_FAST_RING 1              // xpos ring + thermometer-coded merge, see P3 of step_fast64_kernel
-#endif
 // Thermometer codes of table lags: c(lag) = (0xff << lag) & 0xff for lag 0..7, 0 = never heard.
 // The codes form a chain under bit inclusion, so the code of the smaller lag (the fresher entry)
 // is the bitwise OR, and the lag comes back as 8 - popcount.  Four lag bytes (0..7 exact, 12 =
@@ -72,7 +66,7 @@ struct FastParams {
   const double* vel;
   uint32_t* tkey;
   double* tx;
-  double* ring;                  // [B][NR][8] xpos ring (DIRAL_FAST_RING) or null: every xpos from the plane `tx`
+  double* ring;                  // [B][NR][8] xpos ring, or null: every xpos from the plane `tx`
   int32_t* la;                   // last_arrival_time[tx][rx] (network.py:39-42) or null: not tracked
   const double* trace;           // replayed x positions (network.py:171-178, 194-199) or null
   int trace_len, trace_per_env;
@@ -540,7 +534,6 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // word seen reaches the limit exactly when some own stamp does
     if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
   }
-#if DIRAL_FAST_RING
   // Vehicle.received_update for every (resource, rx), resources ascending: per column the entry of
   // viewer u becomes the fresher of its own and that of its gather source m_i(u).
   //
@@ -795,145 +788,6 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       keyed_column(c, key[c], wr, x_pl);
     }
   }
-#else
-  // Vehicle.received_update for every (resource, rx), resources ascending:
-  // key[u] = max(key[u], key[m_i(u)]) per column, one ds_bpermute + max each.
-  //
-  // PACKED path (DIRAL_PACKED_MERGE): two columns share one register as 16-bit keys
-  // (rank << 6) | source, rank = 1023 - lag, lag = t_k - seq (t_k = the subject's own
-  // fresh sequence number), merged with v_pk_max_u16 - half the LDS and VALU work.
-  // rank is order-preserving and injective for lag < 1023, and an update can only
-  // raise an entry to a rank > 0, so the result is exact iff no entry of the wave
-  // has lag >= 1023 with seq != 0 (never-heard entries, seq == 0, all share rank 0).
-  // Otherwise (imported or very stale tables) the wave takes the 32-bit path.
-  bool packed_ok = false;
-#if DIRAL_PACKED_MERGE
-  unsigned int kp[8];
-  {
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      unsigned int k16[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = 2 * j + h;
-        const unsigned int seq = w1[c] >> 8;
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)seq, (wave * 16 + c) & 63);
-        const unsigned int lag = tk_own - seq;
-        bad = bad || (lag >= 1023u && seq != 0u);
-        const unsigned int rank = lag < 1023u ? 1023u - lag : 0u;
-        k16[h] = (rank << 6) | (unsigned int)lane;
-      }
-      kp[j] = k16[0] | (k16[1] << 16);
-    }
-    packed_ok = (__ballot(bad) == 0ull);
-  }
-  // resources with at least one transmitter, as a wave-uniform bit word: the merge visits only those
-  const unsigned long long actw = __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
-  if (packed_ok) {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    unsigned long long rem = actw;
-    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-    while (rem) {
-      rem &= rem - 1;
-      const int m4 = m_next;
-      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kp[j]);
-        const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, kp[j]), __builtin_bit_cast(u16x2, v));
-        kp[j] = __builtin_bit_cast(unsigned int, r);
-      }
-    }
-    // back to (seq << 8) | source: seq = t_k - (1023 - rank); rank 0 never results
-    // from an update, so such an entry keeps its own word
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const unsigned int k16 = (kp[c >> 1] >> (16 * (c & 1))) & 0xffffu;
-      const unsigned int rank = k16 >> 6, src = k16 & 63u;
-      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)(w1[c] >> 8), (wave * 16 + c) & 63);
-      const unsigned int seqf = tk_own - 1023u + rank;
-      // select without a branch (the compiler turns the plain ternary into exec-mask control flow)
-      const unsigned int m = 0u - (unsigned int)(rank != 0u);
-      key[c] = (((seqf << 8) | src) & m) | (((w1[c] & ~255u) | (unsigned int)lane) & ~m);
-    }
-  }
-#endif
-  if (!packed_ok) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) key[c] = (w1[c] & ~255u) | (unsigned int)lane;
-    unsigned long long rem = actw;
-    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-    while (rem) {
-      rem &= rem - 1;
-      const int m4 = m_next;
-      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
-        key[c] = max(key[c], v);
-      }
-    }
-  }
-  DIRAL_FSTAMP(4);
-
-  // ---- P3b: xpos follows the winning sequence number; histogram ------------------
-  unsigned int mycnt = 0u;
-  const double inv_w = p.inv_w;
-  unsigned int* const hrow = s_hist + lane * KP;
-  // (a rolled loop with uniform register indexing: measured faster than the
-  // unrolled form, which costs 27 VGPRs = 3 waves/SIMD of occupancy; the next
-  // column's xpos load is issued one iteration ahead)
-  const int ncol = has_cols ? 16 : 0;
-  double x_next = has_cols ? txp[lane] : 0.0;
-#pragma unroll 1
-  for (int c = 0; c < ncol; ++c) {
-    const int k = wave * 16 + c;
-    const int off = c * NV + lane;
-    const unsigned int kf = key[c], w = w1[c];
-    const bool upd = ((kf ^ w) >> 8) != 0u;
-    const double x_cur = x_next;
-    if (c + 1 < ncol) x_next = txp[off + NV];
-    const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
-    const int src4 = (int)(kf & 255u) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
-    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
-    const double xg = upd ? __hiloint2double(hi, lo) : xs;
-    const unsigned int wn = upd ? (kf & ~255u) : w;
-    tk[off] = wn;
-    if (upd || lane == k) txp[off] = xg;
-    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513):
-    // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
-    double d, v;
-    if constexpr (FLAT) {
-      // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v|
-      v = xg - mynpx;
-      const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-      d = __hiloint2double((int)vh, __double2loint(v));
-      if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
-        d = dist_general(mynpx - xg, 0.0);
-        v = (xg - mynpx > 0.0) ? d : -d;
-      }
-    } else {
-      const double pyk = readlane_f64(mypy, k);
-      d = fast_dist<false>(xg, (wn >> 8) ? pyk : 0.0, mynpx, mypy);
-      v = (xg - mynpx > 0.0) ? d : -d;
-    }
-    const bool ok = live && (k < N) && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
-    if (ok) {
-      // |v| < Rb, so the estimate is in [0, K] and the edge correction needs no bounds
-      // tests: edges[0] = -Rb <= v and v < Rb = edges[K] hold by construction
-      int est = (int)((v + p.Rb) * inv_w);
-      est = est > K - 1 ? K - 1 : est;
-      const double e0 = s_edges[est], e1 = s_edges[est + 1];
-      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
-      atomicAdd(&hrow[bin], 1u);
-      mycnt += 1u;
-    }
-  }
-#endif
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
   DIRAL_FSTAMP(5);
   __syncthreads();

@@ -129,46 +129,26 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
   }
 }
 
-// Thermometer codes (DIRAL_WIDE_THERMO).  In steady state the lag of an entry behind its subject's
+// Thermometer codes.  In steady state the lag of an entry behind its subject's
 // own sequence number is tiny (C3: <= 4, C2: <= 5, C5: <= 7 for 98 % of the entries -
 // profiles/lag_distribution.py), so a pass first tries the 8-level code c(lag) = (0xff << lag) & 0xff
 // (0: never heard): the codes form a chain under bit inclusion, the code of the smaller lag is the
 // bitwise OR, and ONE v_or_b32 merges the four columns of a word where the byte ranks take four
 // SDWA maxes.  Exact while every entry of the pass has lag <= 7 or was never heard; otherwise the
 // pass is redone with byte ranks (lag < 255), then with 32-bit keys.
-#ifndef DIRAL_WIDE_THERMO
-#define DIRAL_WIDE_THERMO 1
-#endif
 #ifndef DIRAL_WIDE_INFLIGHT
 #define DIRAL_WIDE_INFLIGHT 16          // table words a lane has in flight while a pass loads its columns
 #endif
-#ifndef DIRAL_WIDE_BITTEST4
-#define DIRAL_WIDE_BITTEST4 0           // N <= 256: the lag encoder's range test in its straight-line form (see the encoder)
-#endif
-#ifndef DIRAL_WIDE_PIN2
-#define DIRAL_WIDE_PIN2 1               // N <= 128: pin the packed words in front of the pass's exit test (C5 -3.6 %)
-#endif
-#ifndef DIRAL_WIDE_PIN4
-#define DIRAL_WIDE_PIN4 0               // N <= 256: +0.8 % with the pin
-#endif
 // (thermo_codes(): step_fast64.hpp)
 
-// xpos ring (DIRAL_WIDE_RING, see step_fast64.hpp / aux_kernels.hpp): an entry's xpos is a function of
+// xpos ring (see step_fast64.hpp / aux_kernels.hpp): an entry's xpos is a function of
 // (subject, sequence number), the ring keeps every subject's 8 latest stamps, so the finalize phase fills
 // the rank -> xpos table of a column from the subject's ring row (8 lanes) instead of having all viewers
 // scatter their old xpos into it, and EVERY entry that lags at most 7 reads its xpos there.  The per-entry
 // xpos plane - two thirds of the table bytes - is only read for older entries and only written when an
 // entry reaches lag 7 (or copies an older one).
-#ifndef DIRAL_WIDE_RING
-#define DIRAL_WIDE_RING 1
-#endif
-
-#ifndef DIRAL_WIDE_WAVECONST
-#define DIRAL_WIDE_WAVECONST 1           // one copy of the merge loop per wave index: scratch base as an immediate offset
-#endif
-// run f(std::integral_constant<int, wave>) - a copy of f per wave index (wave-uniform switch) -
-// or f(-1) when the switch is compiled out
-#if DIRAL_WIDE_WAVECONST
+// run f(std::integral_constant<int, wave>) - a copy of f per wave index (wave-uniform switch): the wave's
+// scratch base becomes an immediate offset of the LDS instructions; f(-1): base in a register
 #define DIRAL_WIDE_DISPATCH_WAVE(f)                                      \
   do {                                                                   \
     if (!lds_base_is_zero) { f(std::integral_constant<int, -1>{}); break; } \
@@ -183,9 +163,6 @@ __device__ inline void max_u8_words(unsigned int (&a)[NK], const unsigned int (&
       default: f(std::integral_constant<int, 7>{}); break;               \
     }                                                                    \
   } while (0)
-#else
-#define DIRAL_WIDE_DISPATCH_WAVE(f) f(std::integral_constant<int, -1>{})
-#endif
 
 // An LDS object by its absolute byte address (register + compile-time constant: the constant goes
 // into the DS instruction's immediate offset; going through the `extern __shared__` symbol instead
@@ -304,36 +281,6 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 #ifndef DIRAL_WIDE_MINWAVES4
 #define DIRAL_WIDE_MINWAVES4 6           // N <= 256: 84 VGPRs, three 512-thread workgroups per CU
 #endif
-#ifndef DIRAL_WIDE_REGCNT
-#define DIRAL_WIDE_REGCNT 1
-#endif
-#ifndef DIRAL_WIDE_REGCNT4
-#define DIRAL_WIDE_REGCNT4 0
-#endif
-#ifndef DIRAL_WIDE_XPRE2
-#define DIRAL_WIDE_XPRE2 1
-#endif
-#ifndef DIRAL_WIDE_XPRE4
-#define DIRAL_WIDE_XPRE4 1
-#endif
-#ifndef DIRAL_WIDE_FIN_UNROLL2
-#define DIRAL_WIDE_FIN_UNROLL2 8         // finalize column loop, N <= 128 (8 columns per pass): fully unrolled
-#endif
-#ifndef DIRAL_WIDE_ADDTID
-#define DIRAL_WIDE_ADDTID 1              // lane-linear write-back of the merge words with ds_write_addtid_b32 (no address VGPR: half the LDS store cycles)
-#endif
-#ifndef DIRAL_WIDE_RELOAD2
-#define DIRAL_WIDE_RELOAD2 0             // N <= 128: see DIRAL_WIDE_RELOAD4
-#endif
-#ifndef DIRAL_WIDE_RELOAD4
-#define DIRAL_WIDE_RELOAD4 0             // finalize re-reads the table word (L2 / Infinity Cache) instead of carrying old rank + age through the merge in registers
-#endif
-#ifndef DIRAL_WIDE_VEC2
-#define DIRAL_WIDE_VEC2 1                // N <= 128 at 8 columns per pass: one 8-byte gather per slot instead of two 4-byte ones (C5 -2 %)
-#endif
-#ifndef DIRAL_WIDE_FIN_UNROLL4
-#define DIRAL_WIDE_FIN_UNROLL4 2         // N <= 256 (4 columns per pass): by two (64-VGPR budget; measured 3.42 / 3.60 / 4.00 ms for 2 / 1 / 4)
-#endif
 
 // FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
@@ -349,16 +296,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   constexpr int NK = NW * VPL;                 // ... per lane
   // merge words in LDS: plane layout [word][viewer] with 4-byte gathers (NK == 4 only), or one
   // NW-word vector per viewer gathered with ONE 8/16-byte read
-  constexpr bool VEC = (NK != 4) || (VPL == 2 ? (DIRAL_WIDE_VEC2 != 0) : false);
-  constexpr bool RELOAD = VPL == 2 ? (DIRAL_WIDE_RELOAD2 != 0) : (DIRAL_WIDE_RELOAD4 != 0);
+  constexpr bool VEC = (NK != 4) || VPL == 2;    // (N <= 128, 8 columns per pass: one 8-byte gather instead of two 4-byte ones, C5 -2 %)
   static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= wide_scratch(VPL), "a pass's rank words fill at most the wave's scratch");
   constexpr uint32_t SCR = wide_scratch(VPL);
   static_assert(WAVES >= VPL && WAVES <= 8, "P2 runs on the first VPL waves; the merge loop has 8 per-wave copies");
-  static_assert(!DIRAL_WIDE_RING || 8 * PC <= 64, "xpos ring: one lane per (column, lag) of a pass");
-  constexpr int FIN_UNROLL = VPL == 2 ? DIRAL_WIDE_FIN_UNROLL2 : DIRAL_WIDE_FIN_UNROLL4;
+  static_assert(8 * PC <= 64, "xpos ring: one lane per (column, lag) of a pass");
+  constexpr int FIN_UNROLL = VPL == 2 ? 8 : 2;   // finalize column loop: N <= 128 fully unrolled, N <= 256 by two (VGPR budget)
   constexpr int MT = wide_mtab_stride(VPL);    // gather-source table row stride (elements)
-  // explicit one-column-ahead xpos prefetch (8 VGPRs at VPL = 4, where the 64-VGPR budget has no room)
-  constexpr bool XPRE = VPL == 2 ? (DIRAL_WIDE_XPRE2 != 0) : (DIRAL_WIDE_XPRE4 != 0);
   static_assert(VPL == 2 || VPL == 4, "one lane holds 2 or 4 viewers");
   typedef typename std::conditional<VPL == 4, uint32_t, uint16_t>::type mword_t;
 
@@ -590,9 +534,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
   const bool lds_base_is_zero = __builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u;
   const double inv_w = p.inv_w;
-#if DIRAL_WIDE_RING
   const global_ptr<double> ringp = uniform_ptr(((LateFastArgs)late_kernarg_base())->ring, 0);
-#endif
 
   // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
   unsigned long long actw;
@@ -609,7 +551,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
   // neighbour count per viewer: in registers where the VGPR budget has room (N <= 128: one
   // barrier and one pass over the histogram less), else the row sum of the histogram
-  constexpr bool REGCNT = VPL == 2 ? (DIRAL_WIDE_REGCNT != 0) : (DIRAL_WIDE_REGCNT4 != 0);
+  constexpr bool REGCNT = VPL == 2;
   unsigned int mycnt[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
@@ -669,7 +611,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
     // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are
     // simply repeated with the other pair of constants.  Only the merge loop exists per representation.
-    bool thermo = (DIRAL_WIDE_THERMO != 0);
+    bool thermo = true;
     bool packed_ok;
     unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 lag bytes (then codes / ranks) each; ages, same packing
     unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
@@ -728,17 +670,17 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         // ('||' / '&&' compile to exec-mask control flow per entry, the bitwise form to straight-line code: the
         // latter is 8 % faster on the plain N <= 128 kernel, 4 % slower on its RICH instantiation and 25 % SLOWER at
         // N <= 256 - register allocation - so each gets the form that measured best)
-        if constexpr ((VPL == 2 && !RICH) || (VPL == 4 && DIRAL_WIDE_BITTEST4 != 0)) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
+        if constexpr (VPL == 2 && !RICH) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
         else bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
         kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
-        if constexpr (!RELOAD) agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
+        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     }
     // (pinned packed words: left alone, the compiler sinks the packing below the exit test and keeps all
     // PC x VPL lags alive across it)
-    if constexpr (VPL == 2 ? (DIRAL_WIDE_PIN2 != 0) : (DIRAL_WIDE_PIN4 != 0)) {
+    if constexpr (VPL == 2) {
 #pragma unroll
       for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
     }
@@ -754,7 +696,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       const unsigned int seq_base = thermo ? 8u : 255u;
       unsigned int kp0[NK];                      // the ranks before the merge
 #pragma unroll
-      for (int q = 0; q < NK; ++q) kp0[q] = RELOAD ? 0u : kp[q];
+      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
       // -- Vehicle.received_update for every (resource, rx), resources ascending:
       //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
       if constexpr (!VEC) {
@@ -792,14 +734,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             } else {
               max_u8_words<NK>(kp, v);
             }
-#if DIRAL_WIDE_ADDTID
-            lds_store4_lane_linear(sw_lds, kp);     // sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
-#else
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-              for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
-#endif
+            lds_store4_lane_linear(sw_lds, kp);     // (ds_write_addtid_b32: no address VGPR, half the LDS store cycles) sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
             wave_lds_order();
           }
         };
@@ -860,7 +795,6 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
       DIRAL_WCLOCK(tc2);
 
-#if DIRAL_WIDE_RING
       // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
       //    extraction).  The rank -> xpos table of the column: the subject's 8 latest stamps from its ring row
       //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass), the few older entries
@@ -914,84 +848,6 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
         wave_lds_order();
       }
-#else
-      // -- xpos follows the winning sequence number; histogram.  One column at a time
-      //    (rolled: uniform byte extraction): old xpos -> xt[old rank]; updated entries
-      //    read xt[new rank].  The next column's xpos is loaded one iteration ahead.
-      double x_next[VPL];
-      if constexpr (XPRE) {
-        const global_ptr<const double> txrow0 = uniform_ptr<const double>(p.tx, (bR + kbase) * NV);
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) x_next[j] = txrow0[ul + 64u * j];
-      }
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-#pragma unroll FIN_UNROLL
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * w + cc;
-        const int k = kbase + c;
-        const bool kvalid = FULL || k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        double x_cur[VPL];
-        if constexpr (XPRE) {
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) x_cur[j] = x_next[j];
-          if (w + 1 < NW || cc < 3) {                            // static where the column loop is fully unrolled
-            const global_ptr<const double> txn = uniform_ptr<const double>(p.tx, (bR + k + 1) * NV);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) x_next[j] = txn[ul + 64u * j];
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) x_cur[j] = txrow[ul + 64u * j];
-        }
-        const double pxk = s_px[kvalid ? k : 0];
-        unsigned int rank0[VPL], age0[VPL];
-        if constexpr (RELOAD) {
-          // old rank and age of the entry from the table word itself (re-read: L2 / Infinity Cache)
-          unsigned int wr[VPL];
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) wr[j] = tkrow[ul + 64u * j];
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const int u = lane + 64 * j;
-            const unsigned int wv = (FULL || (kvalid && u < N)) ? wr[j] : 0u;
-            unsigned int sq = wv >> 8;
-            const unsigned int a0 = wv & 255u;
-            age0[j] = a0 + (a0 < 255u ? 1u : 0u);
-            if (j == (k >> 6)) {
-              const bool own = kvalid && (lane == (k & 63));
-              sq += own ? 1u : 0u;
-              age0[j] = own ? 0u : age0[j];
-            }
-            const unsigned int lag = tk_own - sq;
-            rank0[j] = thermo ? (lag <= 7u ? ((0xffu << lag) & 0xffu) : 0u) : (lag < 255u ? 255u - lag : 0u);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          if constexpr (!RELOAD) rank0[j] = pick(kp0, j, w, cc);
-          if (j == (k >> 6)) x_cur[j] = (lane == (k & 63)) ? pxk : x_cur[j];   // own stamp (vehicle.py:63), uniform slot
-          if (FULL || u < N) xt[rank0[j]] = x_cur[j];
-        }
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int rf = pick(kp, j, w, cc);
-          const double xr = xt[rf];
-          const bool upd = rf != rank0[j];
-          const double xg = upd ? xr : x_cur[j];
-          // sequence number back from the rank / from the code (lag = 8 - popcount)
-          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
-          const unsigned int wn = (seqf << 8) | (upd ? 0u : (RELOAD ? age0[j] : pick(agew, j, w, cc)));
-          emit(k, kvalid, j, upd, wn, xg, tkrow, txrow, std::integral_constant<int, 0>{});
-        }
-        wave_lds_order();
-      }
-#endif
     } else {
       // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
       //    very stale tables: an entry with lag >= 255 and seq != 0)
@@ -1033,27 +889,21 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
         const double pxk = s_px[kvalid ? k : 0];
         double xo[VPL];
-#if DIRAL_WIDE_RING
         unsigned int tk_own = 0u;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(ws[j] >> 8), k & 63);
           tk_own = ((k >> 6) == j) ? cand : tk_own;
         }
-#endif
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const int u = lane + 64 * j;
           xo[j] = txrow[u < N ? u : 0];
-#if DIRAL_WIDE_RING
           // a young entry's xpos is in the subject's ring row, not (necessarily) in the plane
           if (tk_own - (ws[j] >> 8) <= 7u) xo[j] = ringp[(size_t)(bR + (kvalid ? k : 0)) * 8 + ((ws[j] >> 8) & 7u)];
-#endif
           xo[j] = (u == k) ? pxk : xo[j];
         }
-#if DIRAL_WIDE_RING
         if (lane == 0 && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;   // this slot's stamp (after the row was read)
-#endif
         wave_lds_order();
 #pragma unroll
         for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
@@ -1066,7 +916,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         for (int j = 0; j < VPL; ++j) {
           const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
           emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow,
-               std::integral_constant<int, DIRAL_WIDE_RING ? 2 : 0>{});   // with the ring: the plane complete for this column
+               std::integral_constant<int, 2>{});   // with the ring: the plane complete for this column
         }
         wave_lds_order();
       }
