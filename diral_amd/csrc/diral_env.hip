@@ -130,22 +130,27 @@ struct DeviceGuard {
 constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | DIRAL_F_ADD_REWARD | DIRAL_F_ADD_INDEX |
                                 DIRAL_F_ADD_VELOCITY | DIRAL_F_ADD_POSITION | DIRAL_F_FINGERPRINT;
 
-// Configurations the specialised kernels (step_fast64 / step_wide) serve: the type-2
-// piggybacked histogram observation with any of the cheap State flags, every step kind, any
-// combination of outputs, proportional fairness.  PRR tracking in my_step, the secondary
-// observation modes (a15/a16) and static topologies stay on the general kernel.
+// Configurations the specialised kernels (step_fast64 / step_wide) serve: every step kind on a mobile
+// topology with piggybacked neighbour tables, any combination of outputs and State flags, proportional
+// fairness.  The type-2 piggybacked histogram is part of the kernels; the secondary observation modes
+// (a15/a16: sorted true distances, type-1 weighted histogram) are columns posdist_kernel fills right
+// after the step, so the step itself runs here all the same (RICH instantiation, histogram columns off
+// unless type 2).  Without State.add_positional_dist_piggy the reference keeps no tables (test_env.py:
+// 138, 231-238): that step, PRR tracking in my_step and static topologies stay on the general kernel.
 bool is_specialised_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
-                          DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | kRichFlags;
-  return (p.flags & ~ignore) == want && p.posdist_type == 2 &&
+                          DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | DIRAL_F_ADD_POSDIST | kRichFlags;
+  return (p.flags & ~ignore) == want &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN);
 }
+// the state vector carries the type-2 piggybacked histogram
+bool has_hist2(const StepParams& p) { return (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 2; }
 // ... of which the PLAIN instantiations serve the toy YAML's State flags with the state vector
 // as the only observation output (the metric's configuration)
 bool is_plain_cfg(const StepParams& p) {
-  return (p.flags & (kRichFlags | DIRAL_F_PROPORTIONAL_FAIR)) == 0 && (p.flags & DIRAL_F_ADD_ACTION) &&
-         p.state_out != nullptr && p.chobs_out == nullptr;
+  return (p.flags & (kRichFlags | DIRAL_F_PROPORTIONAL_FAIR | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) &&
+         (p.flags & DIRAL_F_ADD_ACTION) && p.state_out != nullptr && p.chobs_out == nullptr;
 }
 
 int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
@@ -206,7 +211,8 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.done_out = p.done_out; f.dbg = p.dbg;
     RichParams r = e->rich;
     r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
-    r.plain_state = ((p.flags & kRichFlags) == 0 && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
+    r.plain_state = ((p.flags & (kRichFlags | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
+    if (!has_hist2(p)) r.off_hist = -1;                         // (type 1: posdist_kernel writes those columns)
     r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
@@ -232,7 +238,7 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   const bool full = (p.flags & DIRAL_F_ADD_POSDIST) != 0;
   const bool type1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1;
   if (!p.state_out || !(full || type1)) return hipSuccess;
-  {
+  if (type1) {                                                  // (the sorted true distances read no table)
     const hipError_t st = ensure_plane(e, s);
     if (st != hipSuccess) return st;
   }

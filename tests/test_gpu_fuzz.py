@@ -53,11 +53,10 @@ def test_random_configuration_vs_oracle(i):
     # the general kernel (PRR tracking in my_step, a build extension, keeps the run there) ...
     random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
                    expect_kernel=KERNEL_GENERAL)
-    # ... and whatever the dispatch picks without it: the RICH instantiations of step_fast64 /
-    # step_wide for the type-2 histogram observation with any cheap State flag and A <= 64
-    st = cfg.State
-    special = (st.add_positional_dist_piggy and st.add_positional_dist_type == 2 and not st.add_positional_dist
-               and cfg.num_channels <= 64)
+    # ... and whatever the dispatch picks without it: step_fast64 / step_wide for every State block with
+    # piggybacked tables and A <= 64 (the secondary observation modes get their columns from posdist_kernel
+    # afterwards)
+    special = cfg.State.add_positional_dist_piggy and cfg.num_channels <= 64
     want = (KERNEL_FAST64 if cfg.num_users <= 64 else KERNEL_WIDE) if special else KERNEL_GENERAL
     random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
                    track_prr=False, expect_kernel=want)

@@ -1181,7 +1181,11 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
                                ({}, dict(proportional_fair=True), fam | KERNEL_RICH),
                                (dict(action_index="real", add_channel_obs=True), {}, fam | KERNEL_RICH),
                                (dict(add_action=False), {}, fam | KERNEL_RICH),
-                               (flags, dict(track_arrival=True), fam | KERNEL_RICH | KERNEL_EXTRA)):
+                               (flags, dict(track_arrival=True), fam | KERNEL_RICH | KERNEL_EXTRA),
+                               # the secondary observation modes: the step on a RICH instantiation, their
+                               # columns from posdist_kernel right after it
+                               (dict(add_positional_dist=True), {}, fam | KERNEL_RICH),
+                               (dict(add_positional_dist_type=1), {}, fam | KERNEL_RICH)):
         c2 = bench_config(N, A, L, State=state, **extra)
         e2 = make_env(c2, B, dtype=torch.float64)
         e2.reset_topology(seed=4)
@@ -1189,8 +1193,8 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         assert (e2.last_kernel() & ~KERNEL_RING) == want, (state, extra, e2.last_kernel())
         e2.check()
     # what stays on the general kernel
-    for state, extra in ((dict(add_positional_dist=True), {}), (dict(add_positional_dist_type=1), {}),
-                         ({}, dict(track_prr=True)), (dict(add_positional_dist_piggy=False), {})):
+    for state, extra in (({}, dict(track_prr=True)), (dict(add_positional_dist_piggy=False), {}),
+                         (dict(add_positional_dist=True, add_positional_dist_piggy=False), {})):
         c3 = bench_config(N, A, L, State=state, **extra)
         e3 = make_env(c3, 4, dtype=torch.float64)
         e3.reset_topology(seed=5)
