@@ -233,21 +233,39 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   return launch_general(vpl, fast, p, e->lds_bytes, s);
 }
 
-// Secondary observation modes (a15/a16) run as their own launch after the step.
+// Secondary observation modes (a15/a16) run as their own launch after the step (posdist_kernel.hpp).
 hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const bool full = (p.flags & DIRAL_F_ADD_POSDIST) != 0;
   const bool type1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1;
   if (!p.state_out || !(full || type1)) return hipSuccess;
-  if (type1) {                                                  // (the sorted true distances read no table)
-    const hipError_t st = ensure_plane(e, s);
-    if (st != hipSuccess) return st;
-  }
   PosdistParams q;
   q.N = p.N; q.A = p.A; q.K = p.K; q.S = p.S; q.NV = p.NV; q.NR = p.NR; q.flags = p.flags;
   q.posdist_type = p.posdist_type; q.age_limit = p.age_limit; q.out_f64 = p.out_f64;
   q.off_posdist = p.off_posdist; q.off_hist = p.off_hist;
   q.pos_x = p.pos_x; q.pos_y = p.pos_y; q.tkey = p.tkey; q.tx = p.tx; q.edges1 = e->edges1; q.state_out = p.state_out;
-  hipLaunchKernelGGL(posdist_kernel, dim3(p.B), dim3(64 * kPdWaves), posdist_lds_bytes(p.N, p.K), s, q);
+  q.do_full = 0; q.do_type1 = 0; q.ring = nullptr;
+  const bool full_flat = full && e->flat_y;                     // one ranking of the env's x serves every viewer
+  const bool type1_n64 = type1 && p.NV == 64;                   // lane = viewer, sort in registers
+  if (full_flat) {
+    q.do_full = 1;
+    hipLaunchKernelGGL(posdist_sorted_flat_kernel, dim3(p.B), dim3(256), posdist_flat_lds_bytes(p.N), s, q);
+    q.do_full = 0;
+  }
+  if (type1_n64) {
+    q.do_type1 = 1;
+    q.ring = (e->ring && !e->plane_valid) ? e->ring : nullptr;  // young entries straight from the ring: no materialise pass
+    hipLaunchKernelGGL(posdist_type1_n64_kernel, dim3(p.B), dim3(64), posdist_type1_lds_bytes(p.K), s, q);
+    q.do_type1 = 0; q.ring = nullptr;
+  }
+  q.do_full = (full && !full_flat) ? 1 : 0;
+  q.do_type1 = (type1 && !type1_n64) ? 1 : 0;
+  if (q.do_full || q.do_type1) {
+    if (q.do_type1) {                                           // (the sorted true distances read no table)
+      const hipError_t st = ensure_plane(e, s);
+      if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(posdist_kernel, dim3(p.B), dim3(64 * kPdWaves), posdist_lds_bytes(p.N, p.K), s, q);
+  }
   return hipGetLastError();
 }
 
@@ -369,8 +387,9 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->vel, bn * 8));
   // + 256 elements of slack: step_wide.hpp loads a padded viewer slot (lane + 64 j) past the
   // end of a row without clamping (the values are masked, never stored)
-  CREATE_TRY(alloc((void**)&e->tkey, (tab + 256) * 4));
-  CREATE_TRY(alloc((void**)&e->tx, (tab + 256) * 8));
+  // + 64 rows: posdist_type1_n64_kernel reads rows N .. 63 of its env unmasked as well
+  CREATE_TRY(alloc((void**)&e->tkey, (tab + 256 + 64 * 64) * 4));
+  CREATE_TRY(alloc((void**)&e->tx, (tab + 256 + 64 * 64) * 8));
   // the xpos ring of the specialised kernels (DIRAL_NO_RING: test hook, N <= 64 only - that kernel also runs
   // from the plane alone, the N > 64 kernels are built for the ring)
   if ((e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) || (e->vpl > 1 && e->A <= kWideMaxA)) {
@@ -401,6 +420,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   }
   CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)posdist_lds_bytes(e->N, e->K)));
+  CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_type1_n64_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)posdist_type1_lds_bytes(e->K)));
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
   CREATE_TRY(hipMemset(e->vel, 0, bn * 8));

@@ -10,10 +10,19 @@
 //        cw[idx_{j+1}] - cw[idx_j] with idx = searchsorted(left; last edge right).
 // Both need a per-viewer sort; they run as their own launch right after the fused
 // step (same stream; obtain_state follows the step in the reference too) and write
-// straight into their sections of the state vector.  One workgroup per env, one
-// wave per viewer at a time; the sort is rank-by-counting (ties broken by index,
-// which Python's sort of equal floats cannot distinguish anyway), the prefix sum
-// is one serial lane - exactness first, these are not the headline path.
+// straight into their sections of the state vector.
+//   posdist_kernel               any N, any topology: one workgroup per env, one wave per viewer at a
+//                                time, rank-by-counting sort (ties broken by index, which Python's sort
+//                                of equal floats cannot distinguish anyway), one serial lane for the
+//                                prefix sum - the exact reference statement, slow.
+//   posdist_sorted_flat_kernel   a16 on the one-lane highway (every pos_y equal - the reference draws
+//                                randint(0, 1), network.py:100): the signed distance is a monotone
+//                                function of the other vehicle's x, so ONE ranking of the env's x serves
+//                                all N viewers.
+//   posdist_type1_n64_kernel     a15 for N <= 64: one wave per env, lane = viewer; the viewer's 64
+//                                signed distances live in registers, sorted by a fully unrolled bitonic
+//                                network of v_min_f64 / v_max_f64, the sequential prefix sum and the
+//                                edge walk run in all 64 lanes at once.
 #pragma once
 #include "common.hpp"
 #include "step_kernel.hpp"
@@ -31,6 +40,8 @@ struct PosdistParams {
   const double* tx;
   const double* edges1;     // np.linspace(-1, 1, K+1)
   void* state_out;
+  int do_full, do_type1;    // which of the two modes THIS launch serves
+  const double* ring;       // xpos ring (aux_kernels.hpp) when the plane is incomplete, else null
 };
 
 constexpr int kPdWaves = 4;
@@ -52,8 +63,8 @@ __global__ __launch_bounds__(64 * kPdWaves) void posdist_kernel(const PosdistPar
   for (int j = tid; j <= K; j += blockDim.x) s_e1[j] = p.edges1 ? p.edges1[j] : 0.0;
   __syncthreads();
   const double inf = __builtin_inf();
-  const bool full = (p.flags & DIRAL_F_ADD_POSDIST) != 0;
-  const bool type1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1;
+  const bool full = p.do_full != 0;
+  const bool type1 = p.do_type1 != 0;
 
   for (int t = wave; t < N; t += kPdWaves) {
     const double xt = s_px[t], yt = s_py[t];
@@ -146,6 +157,192 @@ __global__ __launch_bounds__(64 * kPdWaves) void posdist_kernel(const PosdistPar
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+  }
+}
+
+// ---- a16 on a flat highway ------------------------------------------------------------------------
+// v(w) = dist_sign(w, t) (network.py:334-349) is +d for x_w > x_t and -d otherwise, d = dist2d a
+// monotone function of |x_w - x_t| when the y coordinates agree - so v is monotone in x_w, the sorted
+// list of one viewer is the env's x order with the viewer taken out, and the largest distance belongs
+// to one of the two extreme vehicles.  Equal x give equal v: their mutual order cannot show.
+__global__ __launch_bounds__(256) void posdist_sorted_flat_kernel(const PosdistParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = p.N, NP = (N + 63) & ~63;
+  double* s_px = reinterpret_cast<double*>(smem);
+  double* s_py = s_px + NP;
+  double* s_dmax = s_py + NP;
+  int* s_rank = reinterpret_cast<int*>(s_dmax + NP);
+  int* s_ord = s_rank + NP;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const size_t bN = (size_t)b * N;
+  for (int u = tid; u < N; u += 256) { s_px[u] = p.pos_x[bN + u]; s_py[u] = p.pos_y[bN + u]; }
+  __syncthreads();
+  for (int w = tid; w < N; w += 256) {
+    const double x = s_px[w];
+    int r = 0;
+    for (int q = 0; q < N; ++q) { const double o = s_px[q]; r += (o < x || (o == x && q < w)) ? 1 : 0; }
+    s_rank[w] = r; s_ord[r] = w;
+  }
+  __syncthreads();
+  if (N < 2) return;
+  const int lo = s_ord[0], hi = s_ord[N - 1], M = N - 1;
+  for (int t = tid; t < N; t += 256) {                                   // the farthest vehicle is one of the two extremes
+    const double dlo = dist2d(s_px[lo], s_py[lo], s_px[t], s_py[t]), dhi = dist2d(s_px[hi], s_py[hi], s_px[t], s_py[t]);
+    s_dmax[t] = dlo > dhi ? dlo : dhi;
+  }
+  __syncthreads();
+  int t = tid / M, r = tid - t * M;
+  const int dt = 256 / M, dr = 256 - dt * M;
+  for (int e = tid; e < N * M; e += 256) {
+    const double xt = s_px[t], yt = s_py[t], dmax = s_dmax[t];
+    const int w = s_ord[r + (r >= s_rank[t] ? 1 : 0)];                   // the viewer itself is skipped
+    const double d = dist2d(s_px[w], s_py[w], xt, yt);
+    const double v = (s_px[w] - xt > 0.0) ? d : -d;
+    store_out(p.state_out, (bN + t) * (size_t)p.S + p.off_posdist + r, v / dmax, p.out_f64);
+    t += dt; r += dr;
+    if (r >= M) { r -= M; t += 1; }
+  }
+}
+
+__host__ inline uint32_t posdist_flat_lds_bytes(int N) {
+  const int NP = (N + 63) & ~63;
+  return (uint32_t)(NP * (8 + 8 + 8 + 4 + 4));
+}
+
+// ---- a15, N <= 64 -----------------------------------------------------------------------------------
+__device__ inline double pd_readlane_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// dist2d with the general case in line: a call inside the unrolled sweep would force the 128 registers of
+// the value array through the calling convention at every call site
+__device__ inline double pd_dist(double x1, double y1, double x2, double y2) {
+  const double dx = x2 - x1, dy = y2 - y1;
+  // |dx| in [2^-500, 2^501) or dx == 0, and dy == 0: sqrt(dx * dx) == |dx| exactly (the same test on the
+  // high word as step_fast64.hpp's fast_dist)
+  const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
+  const bool plain = (hi - 0x20b00000u <= 0x3e800000u) || (hi | (unsigned int)__double2loint(dx)) == 0u;
+  if (dy == 0.0 && plain) return __hiloint2double((int)hi, __double2loint(dx));
+  return __builtin_sqrt(dx * dx + dy * dy);
+}
+
+constexpr int kPd1Stride = 65;                         // doubles per row of edge sums: lane t at column t, rows 2 banks apart
+
+__host__ __device__ inline uint32_t posdist_type1_lds_bytes(int K) { return (uint32_t)(8 * (66 + (K + 1) * kPd1Stride)); }
+
+__global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* const s_e1 = reinterpret_cast<double*>(smem);                  // [K + 1] edges
+  double* const s_c = s_e1 + 66;                                         // [K + 1][kPd1Stride] edge sums C_j per viewer
+  const int N = p.N, K = p.K, lane = threadIdx.x, b = blockIdx.x;
+  const size_t bN = (size_t)b * N;
+  const bool live = lane < N;
+  const double xt = live ? p.pos_x[bN + lane] : 0.0, yt = live ? p.pos_y[bN + lane] : 0.0;
+  for (int j = lane; j <= K; j += 64) s_e1[j] = p.edges1[j];
+  const double inf = __builtin_inf();
+
+  // the viewer's signed table distances (dist_piggy, network.py:538-558): row k of the subject-major
+  // table holds what every viewer knows about k - one coalesced row read per subject, in batches of
+  // three straight unrolled sweeps (table words, xpos, arithmetic) that keep 16 + 16 loads in flight.
+  // (rows past N - 1 are read all the same - the table allocations carry 64 rows of slack, diral_env_create -
+  // and masked out: every row sits at a compile-time offset from one base pointer)
+  double v[64];
+  double dmax = 0.0;
+  int nvalid = 0;
+  const uint32_t* const trow = p.tkey + (size_t)b * p.NR * 64 + lane;     // NV == 64 for N <= 64
+  const double* const xrow = p.tx + (size_t)b * p.NR * 64 + lane;
+  const double* const rrow = p.ring ? p.ring + (size_t)b * p.NR * 8 : nullptr;
+#pragma unroll
+  for (int k0 = 0; k0 < 64; k0 += 16) {                                    // 16 rows per batch: 48 registers in flight
+    uint32_t tw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tw[c] = trow[(k0 + c) * 64];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = k0 + c;
+      const uint32_t seq = tw[c] >> 8;
+      const double* src = xrow + k * 64;
+      if (rrow && k < N) {                                                 // uniform: the plane holds only entries 7+ stamps old
+        const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tw[c], k) >> 8;   // row k's diagonal
+        if (tk - seq <= 7u) src = rrow + k * 8 + (seq & 7u);
+      }
+      v[k] = *src;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = k0 + c;
+      const uint32_t w = tw[c];
+      const double x1 = v[k];
+      const bool valid = live && k < N && k != lane && (int)(w & 255u) < p.age_limit;
+      const double yk = pd_readlane_f64(yt, k);
+      const double y1 = (w >> 8) ? yk : 0.0;
+      const double d = pd_dist(x1, y1, xt, yt);
+      dmax = (valid && d > dmax) ? d : dmax;
+      v[k] = valid ? ((x1 - xt > 0.0) ? d : -d) : inf;
+      nvalid += valid ? 1 : 0;
+      asm volatile("" : "+v"(v[k]), "+v"(dmax), "+v"(nvalid));            // finish the row here (its table word and xpos die)
+    }
+    // keep the batches apart (registers): no load of the next batch may start above this point
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // dist_sorted / norm before the sort instead of after it: dividing by the positive norm keeps the order
+  // and yields the same 64 quotients (inf stays inf; all-zero distances give the reference's NaN)
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k] = v[k] / dmax;
+  // ascending bitonic network, compile-time indices: everything stays in registers.  Invalid entries are
+  // +inf and end up behind the nvalid real ones; equal values need no tie rule.
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double a = v[i], c = v[l];
+          const double mn = __builtin_fmin(a, c), mx = __builtin_fmax(a, c);
+          const bool asc = (i & k2) == 0;
+          v[i] = asc ? mn : mx;
+          v[l] = asc ? mx : mn;
+        }
+      }
+    }
+  }
+  // dist_sorted / norm, np.histogram(v, linspace(-1, 1, K + 1), weights = v): cw = [0, cumsum(sorted)] - a
+  // sequential sum - and bin j = cw[#(s < e_{j+1})] - cw[#(s < e_j)], the last edge counted with <=.
+  // One walk over the sorted values: every edge the value has reached takes the running sum as it stands.
+  __syncthreads();                                                       // s_e1
+  double acc = 0.0;
+  int jj = 0;
+  double e_cur = s_e1[0], e_next = s_e1[K > 0 ? 1 : 0];                  // (the edge after next is read ahead of its use)
+  double* const col = s_c + lane;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const double s = v[i];
+    const bool real = i < nvalid;                                        // (the +inf fillers behind the real values take no part:
+    for (;;) {                                                           //  the edges they would pass are closed below, all lanes together)
+      // edge jj is passed when the value is not below it (not at or below it, for the last edge)
+      const bool adv = real && jj <= K && (jj == K ? !(s <= e_cur) : !(s < e_cur));
+      if (!__builtin_amdgcn_ballot_w64(adv)) break;
+      if (adv) {
+        col[jj * kPd1Stride] = acc;
+        jj += 1;
+        e_cur = e_next;
+        e_next = s_e1[jj + 1 <= K ? jj + 1 : K];
+      }
+    }
+    acc = real ? acc + s : acc;
+  }
+  for (; jj <= K; ++jj) col[jj * kPd1Stride] = acc;                      // (no vehicle beyond the last edge)
+  __syncthreads();
+  // rows leave coalesced: consecutive lanes on consecutive bins of a viewer
+  for (int e = lane; e < N * K; e += 64) {
+    const int t = e / K, j = e - t * K;
+    const double out = s_c[(j + 1) * kPd1Stride + t] - s_c[j * kPd1Stride + t];
+    store_out(p.state_out, (bN + t) * (size_t)p.S + p.off_hist + j, out, p.out_f64);
   }
 }
 
