@@ -213,6 +213,9 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
     r.plain_state = ((p.flags & (kRichFlags | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
     if (!has_hist2(p)) r.off_hist = -1;                         // (type 1: posdist_kernel writes those columns)
+    // the sorted-distance columns are posdist_kernel's, every one of them: not written here at all
+    const bool skip = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
+    r.off_skip = skip ? p.off_posdist : 0; r.len_skip = skip ? p.N - 1 : 0;
     r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
@@ -461,6 +464,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   std::memset(&r, 0, sizeof(r));
   r.S = e->S; r.state_type = cfg->state_type;
   r.off_act = off.act; r.off_chobs = off.chobs; r.off_hist = off.hist; r.off_rew = off.rew; r.off_idx = off.idx;
+  r.off_skip = 0; r.len_skip = 0;
   r.off_pos = off.pos; r.off_vel = off.vel; r.off_fp = off.fp;
   r.H = cfg->highway_height; r.vel = e->vel; r.pos_y = e->pos_y;
   // test hooks, read ONCE here (never on the step path): force the general kernel

@@ -28,6 +28,7 @@ struct RichParams {
   int state_type;          // State.type: 2 = distance to the closest transmitter, 1 = constant 1
   int plain_state;         // the state vector is the plain [one-hot | histogram]: the vectorised writer serves it
   int off_act, off_chobs, off_hist, off_rew, off_idx, off_pos, off_vel, off_fp;   // -1 = absent
+  int off_skip, len_skip;  // columns [off_skip, off_skip + len_skip) belong to another launch (posdist_kernel): not written
   double H;                // highway_height (network.py:31): pos_y / H
   double episode, eps;     // fingerprint (test_env.py:577-579)
   const double* vel;       // [B][N] (add_velocity reads it in the output phase)
@@ -53,12 +54,15 @@ __device__ inline void rich_write_state(const RichParams& r, uint32_t flags, int
                                         size_t row0, int tid, int nthreads, FAct act, FChv chv, FHist hist, FRew rew,
                                         FNpx npx, FPy py, FVel vel) {
   const int S = r.S;
-  const int total = N * S;
+  const int SW = S - r.len_skip;                 // columns this launch writes per row
+  if (SW <= 0) return;                           // (a state of sorted distances only)
+  const int total = N * SW;
   const int act_w = (flags & DIRAL_F_ACTION_REAL) ? 1 : A;
   int e = tid;
-  int u = e / S, s = e - u * S;
-  const int du = nthreads / S, ds = nthreads - du * S;
+  int u = e / SW, sw = e - u * SW;
+  const int du = nthreads / SW, ds = nthreads - du * SW;
   while (e < total) {
+    const int s = sw < r.off_skip || r.len_skip == 0 ? sw : sw + r.len_skip;
     double val = 0.0;
     if (r.off_act >= 0 && s >= r.off_act && s < r.off_act + act_w) {
       val = (flags & DIRAL_F_ACTION_REAL) ? (double)act(u) : ((act(u) == s - r.off_act) ? 1.0 : 0.0);   // test_env.py:585-595
@@ -81,9 +85,9 @@ __device__ inline void rich_write_state(const RichParams& r, uint32_t flags, int
     } else if (r.off_fp >= 0 && s == r.off_fp + 1) {
       val = r.eps;
     }
-    rich_store<OUT64>(out, row0 * S + e, val);
-    e += nthreads; u += du; s += ds;
-    if (s >= S) { s -= S; u += 1; }
+    rich_store<OUT64>(out, (row0 + u) * S + s, val);
+    e += nthreads; u += du; sw += ds;
+    if (sw >= SW) { sw -= SW; u += 1; }
   }
 }
 

@@ -102,6 +102,7 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
   r.chobs_out = a->chobs_out; r.S = a->S; r.state_type = a->state_type; r.plain_state = a->plain_state;
   r.off_act = a->off_act; r.off_chobs = a->off_chobs; r.off_hist = a->off_hist; r.off_rew = a->off_rew;
   r.off_idx = a->off_idx; r.off_pos = a->off_pos; r.off_vel = a->off_vel; r.off_fp = a->off_fp;
+  r.off_skip = a->off_skip; r.len_skip = a->len_skip;
   r.H = a->H; r.episode = a->episode; r.eps = a->eps; r.vel = a->vel; r.pos_y = a->pos_y;
   r.pf = a->pf; r.pf_threshold = a->pf_threshold; r.pf_penalty = a->pf_penalty;
   return r;
