@@ -1332,3 +1332,28 @@ def test_realnes_entry_records_round_trip_and_feed_the_step(N, A, L):
         assert torch.equal(a[k], b[k]), k
     with pytest.raises(ValueError):
         via_rec.import_entries(rec[:, :, :-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,A,L,K,state,vary", [
+    (64, 32, 2000.0, 20, dict(add_positional_dist_type=1), False),                   # lane-per-viewer register sort, dense
+    (64, 32, 9000.0, 64, dict(add_positional_dist_type=1), True),                    # sparse: few valid entries, stale ones, K = 64,
+                                                                                      # equal positions (one speed: exact ties, d = 0)
+    (40, 16, 1500.0, 7, dict(add_positional_dist_type=1, add_reward=True), True),    # N < 64: masked rows and lanes
+    (2, 2, 100.0, 3, dict(add_positional_dist_type=1, add_positional_dist=True), False),
+    (64, 32, 2000.0, 20, dict(add_positional_dist=True), True),                      # one x ranking per env, ties included
+    (128, 64, 4000.0, 20, dict(add_positional_dist=True, add_index=True), False),
+    (256, 64, 4000.0, 10, dict(add_positional_dist=True, add_action=False, add_positional_dist_piggy=True), False),
+    (90, 8, 3000.0, 12, dict(add_positional_dist_type=1, add_positional_dist=True), False),   # N > 64: the literal type-1 kernel
+])
+def test_secondary_observation_modes_vs_oracle(N, A, L, K, state, vary):
+    """State.add_positional_dist (sorted signed true distances / norm, network.py:409-430) and
+    add_positional_dist_type 1 (weighted np.histogram of the table distances, network.py:432-471) on the
+    kernels built for them (csrc/posdist_kernel.hpp): the step on a specialised RICH instantiation, the
+    columns from posdist_sorted_flat_kernel / posdist_type1_n64_kernel (posdist_kernel at N > 64), bit for
+    bit against the oracle over rollouts with velocity changes; the xpos ring feeds the type-1 kernel."""
+    from diral_amd.config import KERNEL_FAST64, KERNEL_WIDE
+    cfg = bench_config(N, A, L, mobility_vary=vary, communication_range=250.0 if L < 5000 else 160.0,
+                       State=dict(num_bins=K, **state))
+    random_rollout(cfg, B=5 if N <= 128 else 3, T=40, seed=700 + N + K, sticky=0.5, vel_every=9, track_prr=False,
+                   expect_kernel=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE)
