@@ -230,18 +230,25 @@ __device__ inline double pd_dist(double x1, double y1, double x2, double y2) {
 
 constexpr int kPd1Stride = 65;                         // doubles per row of edge sums: lane t at column t, rows 2 banks apart
 
-__host__ __device__ inline uint32_t posdist_type1_lds_bytes(int K) { return (uint32_t)(8 * (66 + (K + 1) * kPd1Stride)); }
+__host__ __device__ inline uint32_t posdist_type1_lds_bytes(int K) { return (uint32_t)(8 * (66 + (K + 2) * kPd1Stride)); }
 
 __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* const s_e1 = reinterpret_cast<double*>(smem);                  // [K + 1] edges
-  double* const s_c = s_e1 + 66;                                         // [K + 1][kPd1Stride] edge sums C_j per viewer
+  double* const s_c = s_e1 + 66;                                         // [K + 2][kPd1Stride] edge sums C_j per viewer (+ a slot for the fillers)
   const int N = p.N, K = p.K, lane = threadIdx.x, b = blockIdx.x;
   const size_t bN = (size_t)b * N;
   const bool live = lane < N;
   const double xt = live ? p.pos_x[bN + lane] : 0.0, yt = live ? p.pos_y[bN + lane] : 0.0;
   for (int j = lane; j <= K; j += 64) s_e1[j] = p.edges1[j];
   const double inf = __builtin_inf();
+#ifdef DIRAL_PD_TIMING
+  unsigned long long pd_t[6];
+#define DIRAL_PD_STAMP(i) pd_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define DIRAL_PD_STAMP(i) do {} while (0)
+#endif
+  DIRAL_PD_STAMP(0);
 
   // the viewer's signed table distances (dist_piggy, network.py:538-558): row k of the subject-major
   // table holds what every viewer knows about k - one coalesced row read per subject, in batches of
@@ -288,10 +295,12 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
+  DIRAL_PD_STAMP(1);
   // dist_sorted / norm before the sort instead of after it: dividing by the positive norm keeps the order
   // and yields the same 64 quotients (inf stays inf; all-zero distances give the reference's NaN)
 #pragma unroll
   for (int k = 0; k < 64; ++k) v[k] = v[k] / dmax;
+  DIRAL_PD_STAMP(2);
   // ascending bitonic network, compile-time indices: everything stays in registers.  Invalid entries are
   // +inf and end up behind the nvalid real ones; equal values need no tie rule.
 #pragma unroll
@@ -311,32 +320,39 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
       }
     }
   }
-  // dist_sorted / norm, np.histogram(v, linspace(-1, 1, K + 1), weights = v): cw = [0, cumsum(sorted)] - a
-  // sequential sum - and bin j = cw[#(s < e_{j+1})] - cw[#(s < e_j)], the last edge counted with <=.
-  // One walk over the sorted values: every edge the value has reached takes the running sum as it stands.
+  // np.histogram(v, linspace(-1, 1, K + 1), weights = v): cw = [0, cumsum(sorted)] - a sequential sum - and
+  // bin j = cw[#(s < e_{j+1})] - cw[#(s < e_j)], the last edge counted with <=.  C_j = cw[#(s < e_j)] is the
+  // running sum through the last value below edge j.  No search and no loop over edges: every value writes the
+  // running sum (itself included) into the slot of the first edge above it - c = #(edges <= s), from the
+  // uniform spacing and two compares against the real edges - later values overwrite earlier ones, and a
+  // forward fill over the K + 1 slots completes the edges no value sits directly below.  (Values never
+  // exceed e_K = 1 = |v| / max |v|, so C_K is the total; slot 0 stays empty: nothing is below -1.)
+  DIRAL_PD_STAMP(3);
   __syncthreads();                                                       // s_e1
-  double acc = 0.0;
-  int jj = 0;
-  double e_cur = s_e1[0], e_next = s_e1[K > 0 ? 1 : 0];                  // (the edge after next is read ahead of its use)
   double* const col = s_c + lane;
+  const int kUnsetHi = 0x7ff8dead;                                       // a NaN no sum can be
+  for (int j = 0; j <= K + 1; ++j) col[j * kPd1Stride] = __hiloint2double(kUnsetHi, 0);   // slots 0..K, + one for the fillers
+  const int nreal = dmax > 0.0 ? nvalid : 0;                             // all distances 0: the reference's NaNs fall into no bin
+  const double half_k = 0.5 * (double)K;
+  double acc = 0.0;
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
-    const double s = v[i];
-    const bool real = i < nvalid;                                        // (the +inf fillers behind the real values take no part:
-    for (;;) {                                                           //  the edges they would pass are closed below, all lanes together)
-      // edge jj is passed when the value is not below it (not at or below it, for the last edge)
-      const bool adv = real && jj <= K && (jj == K ? !(s <= e_cur) : !(s < e_cur));
-      if (!__builtin_amdgcn_ballot_w64(adv)) break;
-      if (adv) {
-        col[jj * kPd1Stride] = acc;
-        jj += 1;
-        e_cur = e_next;
-        e_next = s_e1[jj + 1 <= K ? jj + 1 : K];
-      }
-    }
+    const bool real = i < nreal;                                         // (the +inf fillers behind the real values take no part)
+    const double s = real ? v[i] : 0.0;
+    int est = (int)((s + 1.0) * half_k);
+    est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
+    const double e0 = s_e1[est], e1 = s_e1[est + 1];
+    const int c = est + 1 - (s < e0 ? 1 : 0) + ((est + 1 < K && !(s < e1)) ? 1 : 0);
     acc = real ? acc + s : acc;
+    col[(real ? c : K + 1) * kPd1Stride] = acc;
   }
-  for (; jj <= K; ++jj) col[jj * kPd1Stride] = acc;                      // (no vehicle beyond the last edge)
+  double cur = 0.0;
+  for (int j = 0; j <= K; ++j) {
+    const double t = col[j * kPd1Stride];
+    cur = __double2hiint(t) == kUnsetHi ? cur : t;
+    col[j * kPd1Stride] = cur;
+  }
+  DIRAL_PD_STAMP(4);
   __syncthreads();
   // rows leave coalesced: consecutive lanes on consecutive bins of a viewer
   for (int e = lane; e < N * K; e += 64) {
@@ -344,6 +360,11 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     const double out = s_c[(j + 1) * kPd1Stride + t] - s_c[j * kPd1Stride + t];
     store_out(p.state_out, (bN + t) * (size_t)p.S + p.off_hist + j, out, p.out_f64);
   }
+#ifdef DIRAL_PD_TIMING
+  DIRAL_PD_STAMP(5);
+  if (lane == 0 && (b & 255) == 0)
+    for (int q = 0; q < 5; ++q) store_out(p.state_out, bN * (size_t)p.S + p.off_hist + q, (double)(pd_t[q + 1] - pd_t[q]), p.out_f64);
+#endif
 }
 
 __host__ inline uint32_t posdist_lds_bytes(int N, int K) {

@@ -1346,7 +1346,7 @@ def test_realnes_entry_records_round_trip_and_feed_the_step(N, A, L):
     (256, 64, 4000.0, 10, dict(add_positional_dist=True, add_action=False, add_positional_dist_piggy=True), False),
     (90, 8, 3000.0, 12, dict(add_positional_dist_type=1, add_positional_dist=True), False),   # N > 64: the literal type-1 kernel
 ])
-def test_secondary_observation_modes_vs_oracle(N, A, L, K, state, vary):
+def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
     """State.add_positional_dist (sorted signed true distances / norm, network.py:409-430) and
     add_positional_dist_type 1 (weighted np.histogram of the table distances, network.py:432-471) on the
     kernels built for them (csrc/posdist_kernel.hpp): the step on a specialised RICH instantiation, the
