@@ -21,8 +21,8 @@
 //                                all N viewers.
 //   posdist_type1_n64_kernel     a15 for N <= 64: one wave per env, lane = viewer; the viewer's 64
 //                                signed distances live in registers, sorted by a fully unrolled bitonic
-//                                network of v_min_f64 / v_max_f64, the sequential prefix sum and the
-//                                edge walk run in all 64 lanes at once.
+//                                network of v_min_f64 / v_max_f64; the sequential prefix sum runs in all
+//                                64 lanes at once and drops its running value into per-edge LDS slots.
 #pragma once
 #include "common.hpp"
 #include "step_kernel.hpp"
