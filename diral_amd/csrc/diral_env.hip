@@ -249,6 +249,7 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   q.do_full = 0; q.do_type1 = 0; q.ring = nullptr;
   const bool full_flat = full && e->flat_y;                     // one ranking of the env's x serves every viewer
   const bool type1_n64 = type1 && p.NV == 64;                   // lane = viewer, sort in registers
+  const bool type1_lanes = type1 && !type1_n64;                 // 2 / 4 lanes per viewer (N <= 128 / 256)
   if (full_flat) {
     q.do_full = 1;
     hipLaunchKernelGGL(posdist_sorted_flat_kernel, dim3(p.B), dim3(256), posdist_flat_lds_bytes(p.N), s, q);
@@ -260,8 +261,17 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
     hipLaunchKernelGGL(posdist_type1_n64_kernel, dim3(p.B), dim3(64), posdist_type1_lds_bytes(p.K), s, q);
     q.do_type1 = 0; q.ring = nullptr;
   }
+  if (type1_lanes) {
+    const int lpv = p.N <= 128 ? 2 : 4, vw = 64 / lpv, nvb = (p.N + vw - 1) / vw;
+    q.do_type1 = 1;
+    q.ring = (e->ring && !e->plane_valid) ? e->ring : nullptr;
+    const uint32_t lds = posdist_type1_lanes_lds_bytes(p.K, lpv);
+    if (lpv == 2) hipLaunchKernelGGL(posdist_type1_lanes_kernel<2>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
+    else hipLaunchKernelGGL(posdist_type1_lanes_kernel<4>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
+    q.do_type1 = 0; q.ring = nullptr;
+  }
   q.do_full = (full && !full_flat) ? 1 : 0;
-  q.do_type1 = (type1 && !type1_n64) ? 1 : 0;
+  q.do_type1 = 0;
   if (q.do_full || q.do_type1) {
     if (q.do_type1) {                                           // (the sorted true distances read no table)
       const hipError_t st = ensure_plane(e, s);
@@ -390,9 +400,10 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->vel, bn * 8));
   // + 256 elements of slack: step_wide.hpp loads a padded viewer slot (lane + 64 j) past the
   // end of a row without clamping (the values are masked, never stored)
-  // + 64 rows: posdist_type1_n64_kernel reads rows N .. 63 of its env unmasked as well
-  CREATE_TRY(alloc((void**)&e->tkey, (tab + 256 + 64 * 64) * 4));
-  CREATE_TRY(alloc((void**)&e->tx, (tab + 256 + 64 * 64) * 8));
+  // + 64 rows: the type-1 kernels (posdist_kernel.hpp) read the rows up to the next multiple of 64 of their env
+  // unmasked as well
+  CREATE_TRY(alloc((void**)&e->tkey, (tab + 512 + 64 * 256) * 4));
+  CREATE_TRY(alloc((void**)&e->tx, (tab + 512 + 64 * 256) * 8));
   // the xpos ring of the specialised kernels (DIRAL_NO_RING: test hook, N <= 64 only - that kernel also runs
   // from the plane alone, the N > 64 kernels are built for the ring)
   if ((e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) || (e->vpl > 1 && e->A <= kWideMaxA)) {

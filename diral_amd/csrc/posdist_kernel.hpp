@@ -14,7 +14,8 @@
 //   posdist_kernel               any N, any topology: one workgroup per env, one wave per viewer at a
 //                                time, rank-by-counting sort (ties broken by index, which Python's sort
 //                                of equal floats cannot distinguish anyway), one serial lane for the
-//                                prefix sum - the exact reference statement, slow.
+//                                prefix sum - the literal reference statement, slow; serves a16 with
+//                                vehicles off the common lane only.
 //   posdist_sorted_flat_kernel   a16 on the one-lane highway (every pos_y equal - the reference draws
 //                                randint(0, 1), network.py:100): the signed distance is a monotone
 //                                function of the other vehicle's x, so ONE ranking of the env's x serves
@@ -23,6 +24,7 @@
 //                                signed distances live in registers, sorted by a fully unrolled bitonic
 //                                network of v_min_f64 / v_max_f64; the sequential prefix sum runs in all
 //                                64 lanes at once and drops its running value into per-edge LDS slots.
+//   posdist_type1_lanes_kernel   a15 for 64 < N <= 256: 2 or 4 lanes per viewer, cross-lane bitonic merge.
 #pragma once
 #include "common.hpp"
 #include "step_kernel.hpp"
@@ -365,6 +367,208 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
   if (lane == 0 && (b & 255) == 0)
     for (int q = 0; q < 5; ++q) store_out(p.state_out, bN * (size_t)p.S + p.off_hist + q, (double)(pd_t[q + 1] - pd_t[q]), p.out_f64);
 #endif
+}
+
+// ---- a15, 64 < N <= 256: LPV = 2 or 4 lanes per viewer ----------------------------------------------
+// The same kernel with a viewer's table spread over LPV neighbouring lanes, 64 subjects each (lane l: viewer
+// l / LPV of the wave's 64 / LPV, subjects 64 (l % LPV) ...).  Every lane sorts its 64 values as above; the
+// lanes of a viewer then merge their runs with the cross-lane steps of the same bitonic network - partner
+// values through quad-permute DPP moves, the low lane keeps the minima - after which lane s holds ranks
+// 64 s ... 64 s + 63 of the viewer's sorted list.  The sequential prefix sum passes from lane to lane (LPV
+// passes over the same code, one lane of each viewer active per pass).
+template <int CTRL>
+__device__ inline double pd_quad_perm(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B, kQuadShr1 = 0x90;   // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0] [0,0,1,2]
+
+__device__ inline double pd_pick(bool upper, double a, double b) {        // the partner keeps the other one
+  const double mn = __builtin_fmin(a, b), mx = __builtin_fmax(a, b);
+  return upper ? mx : mn;
+}
+
+template <int LPV>
+__global__ __launch_bounds__(64, 3) void posdist_type1_lanes_kernel(const PosdistParams p) {
+  static_assert(LPV == 2 || LPV == 4, "a viewer's lanes share a quad");
+  constexpr int VW = 64 / LPV;                                           // viewers per wave
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* const s_e1 = reinterpret_cast<double*>(smem);                  // [K + 1] edges
+  double* const s_c = s_e1 + 66;                                         // [K + 2][kPd1Stride] edge sums per viewer (columns 0 .. VW - 1)
+  double* const s_py = s_c + (p.K + 2) * kPd1Stride;                     // [64 LPV] pos_y of the env
+  const int N = p.N, K = p.K, NV = p.NV, lane = threadIdx.x;
+  const int nvb = (N + VW - 1) / VW;                                     // viewer blocks per env
+  const int b = blockIdx.x / nvb, vb = blockIdx.x - b * nvb;
+  const int sub = lane & (LPV - 1), vw = lane / LPV;
+  const int t = vb * VW + vw;
+  const size_t bN = (size_t)b * N;
+  const bool live = t < N;
+  const double xt = live ? p.pos_x[bN + t] : 0.0, yt = live ? p.pos_y[bN + t] : 0.0;
+  for (int j = lane; j <= K; j += 64) s_e1[j] = p.edges1[j];
+  for (int u = lane; u < 64 * LPV; u += 64) s_py[u] = u < N ? p.pos_y[bN + u] : 0.0;
+  __syncthreads();
+  const double inf = __builtin_inf();
+
+  double v[64];
+  double dmax = 0.0;
+  int nvalid = 0;
+  const size_t row0 = (size_t)b * p.NR + sub * 64;                        // the lane's first subject row
+  const uint32_t* const trow = p.tkey + row0 * NV + t;
+  const double* const xrow = p.tx + row0 * NV + t;
+  const uint32_t* const drow = p.tkey + row0 * NV + sub * 64;             // the subjects' own entries (diagonal)
+  const double* const rrow = p.ring ? p.ring + row0 * 8 : nullptr;
+#pragma unroll
+  for (int k0 = 0; k0 < 64; k0 += 16) {
+    uint32_t tw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tw[c] = trow[(size_t)(k0 + c) * NV];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = k0 + c;
+      const uint32_t seq = tw[c] >> 8;
+      const double* src = xrow + (size_t)k * NV;
+      if (rrow) {                                                          // uniform: the plane holds only entries 7+ stamps old
+        const uint32_t tk = drow[(size_t)k * NV + k] >> 8;
+        if (sub * 64 + k < N && tk - seq <= 7u) src = rrow + k * 8 + (seq & 7u);
+      }
+      v[k] = *src;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int k = k0 + c, kg = sub * 64 + k;
+      const uint32_t w = tw[c];
+      const double x1 = v[k];
+      const bool valid = live && kg < N && kg != t && (int)(w & 255u) < p.age_limit;
+      const double y1 = (w >> 8) ? s_py[kg] : 0.0;
+      const double d = pd_dist(x1, y1, xt, yt);
+      dmax = (valid && d > dmax) ? d : dmax;
+      v[k] = valid ? ((x1 - xt > 0.0) ? d : -d) : inf;
+      nvalid += valid ? 1 : 0;
+      asm volatile("" : "+v"(v[k]), "+v"(dmax), "+v"(nvalid));
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // norm and count of the whole viewer
+  {
+    double o = pd_quad_perm<kQuadXor1>(dmax);
+    dmax = o > dmax ? o : dmax;
+    nvalid += __builtin_amdgcn_mov_dpp(nvalid, kQuadXor1, 0xf, 0xf, true);
+    if constexpr (LPV == 4) {
+      o = pd_quad_perm<kQuadXor2>(dmax);
+      dmax = o > dmax ? o : dmax;
+      nvalid += __builtin_amdgcn_mov_dpp(nvalid, kQuadXor2, 0xf, 0xf, true);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k] = v[k] / dmax;
+  // every lane: its 64 values ascending
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double a = v[i], c = v[l];
+          const double mn = __builtin_fmin(a, c), mx = __builtin_fmax(a, c);
+          const bool asc = (i & k2) == 0;
+          v[i] = asc ? mn : mx;
+          v[l] = asc ? mx : mn;
+        }
+      }
+    }
+  }
+  // a lane's 64 values are a bitonic sequence: ascending by the last six steps of the network
+  auto merge_in_lane = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double a = v[i], c = v[l];
+          v[i] = __builtin_fmin(a, c);
+          v[l] = __builtin_fmax(a, c);
+        }
+      }
+    }
+  };
+  // two ascending runs X (low lanes) and Y (high lanes): min(X[i], Y[n-1-i]) stays with X, the max goes to Y's
+  // place n-1-i - both halves bitonic, every low value <= every high one
+  const bool odd = (sub & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const double t1 = pd_quad_perm<kQuadXor1>(v[63 - i]), t2 = pd_quad_perm<kQuadXor1>(v[i]);
+    v[i] = pd_pick(odd, v[i], t1);
+    v[63 - i] = pd_pick(odd, v[63 - i], t2);
+    asm volatile("" : "+v"(v[i]), "+v"(v[63 - i]));                       // (pair by pair: the permuted copies must not pile up)
+  }
+  merge_in_lane();
+  if constexpr (LPV == 4) {
+    const bool hi2 = (sub & 2) != 0;                                       // runs of 128: lanes 0,1 against lanes 3,2
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const double t1 = pd_quad_perm<kQuadXor3>(v[63 - i]), t2 = pd_quad_perm<kQuadXor3>(v[i]);
+      v[i] = pd_pick(hi2, v[i], t1);
+      v[63 - i] = pd_pick(hi2, v[63 - i], t2);
+      asm volatile("" : "+v"(v[i]), "+v"(v[63 - i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {                                         // stride 64 of the 128-sequence
+      v[i] = pd_pick(odd, v[i], pd_quad_perm<kQuadXor1>(v[i]));
+      asm volatile("" : "+v"(v[i]));
+    }
+    merge_in_lane();
+  }
+  // lane `sub` now holds ranks 64 sub .. 64 sub + 63 of the viewer's list; the histogram as in the one-lane kernel
+  double* const col = s_c + vw;
+  const int kUnsetHi = 0x7ff8dead;
+  if (sub == 0)
+    for (int j = 0; j <= K + 1; ++j) col[j * kPd1Stride] = __hiloint2double(kUnsetHi, 0);
+  const int nreal_all = dmax > 0.0 ? nvalid : 0;
+  const int nreal = nreal_all - 64 * sub;                                  // of this lane's 64 ranks (<= 0: none)
+  const double half_k = 0.5 * (double)K;
+  double acc = 0.0;
+#pragma unroll 1
+  for (int ph = 0; ph < LPV; ++ph) {
+    const double before = pd_quad_perm<kQuadShr1>(acc);                    // the running sum of the lane below
+    const bool active = sub == ph;
+    if (active && ph > 0) acc = before;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const bool real = active && i < nreal;
+      const double s = real ? v[i] : 0.0;
+      int est = (int)((s + 1.0) * half_k);
+      est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
+      const double e0 = s_e1[est], e1 = s_e1[est + 1];
+      const int c = est + 1 - (s < e0 ? 1 : 0) + ((est + 1 < K && !(s < e1)) ? 1 : 0);
+      acc = real ? acc + s : acc;
+      col[(real ? c : K + 1) * kPd1Stride] = acc;
+    }
+  }
+  if (sub == 0) {
+    double cur = 0.0;
+    for (int j = 0; j <= K; ++j) {
+      const double tt = col[j * kPd1Stride];
+      cur = __double2hiint(tt) == kUnsetHi ? cur : tt;
+      col[j * kPd1Stride] = cur;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < VW * K; e += 64) {
+    const int tv = e / K, j = e - tv * K, to = vb * VW + tv;
+    if (to < N) {
+      const double out = s_c[(j + 1) * kPd1Stride + tv] - s_c[j * kPd1Stride + tv];
+      store_out(p.state_out, (bN + to) * (size_t)p.S + p.off_hist + j, out, p.out_f64);
+    }
+  }
+}
+
+__host__ __device__ inline uint32_t posdist_type1_lanes_lds_bytes(int K, int lpv) {
+  return posdist_type1_lds_bytes(K) + 8u * 64u * (uint32_t)lpv;
 }
 
 __host__ inline uint32_t posdist_lds_bytes(int N, int K) {

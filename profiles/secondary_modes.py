@@ -14,7 +14,7 @@ from diral_amd.config import bench_config  # noqa: E402
 from diral_amd.vec_env import VecV2VEnv  # noqa: E402
 
 B = int(os.environ.get("B", 4096))
-SHAPES = {"c2": (64, 32, 2000.0), "c5": (128, 64, 4000.0)}
+SHAPES = {"c2": (64, 32, 2000.0), "c5": (128, 64, 4000.0), "c3": (256, 64, 4000.0)}   # batch B, B / 2, B / 4
 MODES = {
     "type-2 piggy histogram (metric)": {},
     "add_positional_dist (sorted true distances)": dict(add_positional_dist=True, add_positional_dist_piggy=False),
@@ -25,7 +25,7 @@ for wl in os.environ.get("WORKLOADS", "c2").split(","):
     N, A, L = SHAPES[wl]
     for name, st in MODES.items():
         cfg = bench_config(N, A, L, State=st) if st else bench_config(N, A, L)
-        env = VecV2VEnv(cfg, batch=B if wl == "c2" else B // 2, out_dtype=torch.float32)
+        env = VecV2VEnv(cfg, batch={"c2": B, "c5": B // 2, "c3": B // 4}[wl], out_dtype=torch.float32)
         env.reset_topology(seed=1)
         acts = [env.sample(seed=i) for i in range(32)]
         for t in range(200):

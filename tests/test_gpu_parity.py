@@ -1344,13 +1344,17 @@ def test_realnes_entry_records_round_trip_and_feed_the_step(N, A, L):
     (64, 32, 2000.0, 20, dict(add_positional_dist=True), True),                      # one x ranking per env, ties included
     (128, 64, 4000.0, 20, dict(add_positional_dist=True, add_index=True), False),
     (256, 64, 4000.0, 10, dict(add_positional_dist=True, add_action=False, add_positional_dist_piggy=True), False),
-    (90, 8, 3000.0, 12, dict(add_positional_dist_type=1, add_positional_dist=True), False),   # N > 64: the literal type-1 kernel
+    (90, 8, 3000.0, 12, dict(add_positional_dist_type=1, add_positional_dist=True), False),   # N > 64: two lanes per viewer
+    (128, 64, 4000.0, 20, dict(add_positional_dist_type=1), True),                   # ... every lane pair full, ties
+    (128, 16, 14000.0, 64, dict(add_positional_dist_type=1), False),                 # ... sparse: stale entries, plane + ring
+    (200, 40, 5000.0, 9, dict(add_positional_dist_type=1, add_channel_obs=True), False),      # four lanes per viewer, partial
+    (256, 64, 4000.0, 20, dict(add_positional_dist_type=1), True),                   # ... full
 ])
 def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
     """State.add_positional_dist (sorted signed true distances / norm, network.py:409-430) and
     add_positional_dist_type 1 (weighted np.histogram of the table distances, network.py:432-471) on the
     kernels built for them (csrc/posdist_kernel.hpp): the step on a specialised RICH instantiation, the
-    columns from posdist_sorted_flat_kernel / posdist_type1_n64_kernel (posdist_kernel at N > 64), bit for
+    columns from posdist_sorted_flat_kernel / posdist_type1_n64_kernel / posdist_type1_lanes_kernel<2 | 4>, bit for
     bit against the oracle over rollouts with velocity changes; the xpos ring feeds the type-1 kernel."""
     from diral_amd.config import KERNEL_FAST64, KERNEL_WIDE
     cfg = bench_config(N, A, L, mobility_vary=vary, communication_range=250.0 if L < 5000 else 160.0,
