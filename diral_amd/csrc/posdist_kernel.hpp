@@ -390,7 +390,7 @@ __device__ inline double pd_pick(bool upper, double a, double b) {        // the
 }
 
 template <int LPV>
-__global__ __launch_bounds__(64, 3) void posdist_type1_lanes_kernel(const PosdistParams p) {
+__global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const PosdistParams p) {
   static_assert(LPV == 2 || LPV == 4, "a viewer's lanes share a quad");
   constexpr int VW = 64 / LPV;                                           // viewers per wave
   extern __shared__ __align__(16) unsigned char smem[];
@@ -531,22 +531,33 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_lanes_kernel(const Posdis
   const int nreal_all = dmax > 0.0 ? nvalid : 0;
   const int nreal = nreal_all - 64 * sub;                                  // of this lane's 64 ranks (<= 0: none)
   const double half_k = 0.5 * (double)K;
+  // the slot of every value first, all lanes at once (four 8-bit slot numbers per register; the fillers get
+  // the spare slot and the value 0) - the passes below only add and store
+  uint32_t cpk[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) cpk[q] = 0u;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const bool real = i < nreal;
+    const double s = real ? v[i] : 0.0;
+    v[i] = s;
+    int est = (int)((s + 1.0) * half_k);
+    est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
+    const double e0 = s_e1[est], e1 = s_e1[est + 1];
+    const int c = est + 1 - (s < e0 ? 1 : 0) + ((est + 1 < K && !(s < e1)) ? 1 : 0);
+    cpk[i >> 2] |= (uint32_t)(real ? c : K + 1) << (8 * (i & 3));
+  }
   double acc = 0.0;
 #pragma unroll 1
   for (int ph = 0; ph < LPV; ++ph) {
-    const double before = pd_quad_perm<kQuadShr1>(acc);                    // the running sum of the lane below
+    const double before = pd_quad_perm<kQuadShr1>(acc);                    // the running sum of the lane below, complete by now
     const bool active = sub == ph;
-    if (active && ph > 0) acc = before;
+    if (active) acc = ph > 0 ? before : 0.0;                               // (what a lane adds outside its own pass goes to the spare slot)
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
-      const bool real = active && i < nreal;
-      const double s = real ? v[i] : 0.0;
-      int est = (int)((s + 1.0) * half_k);
-      est = est < 0 ? 0 : (est > K - 1 ? K - 1 : est);
-      const double e0 = s_e1[est], e1 = s_e1[est + 1];
-      const int c = est + 1 - (s < e0 ? 1 : 0) + ((est + 1 < K && !(s < e1)) ? 1 : 0);
-      acc = real ? acc + s : acc;
-      col[(real ? c : K + 1) * kPd1Stride] = acc;
+      acc = acc + v[i];
+      const int c = (int)((cpk[i >> 2] >> (8 * (i & 3))) & 255u);
+      col[(active ? c : K + 1) * kPd1Stride] = acc;
     }
   }
   if (sub == 0) {
