@@ -244,13 +244,6 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
   const double xt = live ? p.pos_x[bN + lane] : 0.0, yt = live ? p.pos_y[bN + lane] : 0.0;
   for (int j = lane; j <= K; j += 64) s_e1[j] = p.edges1[j];
   const double inf = __builtin_inf();
-#ifdef DIRAL_PD_TIMING
-  unsigned long long pd_t[6];
-#define DIRAL_PD_STAMP(i) pd_t[i] = __builtin_amdgcn_s_memtime()
-#else
-#define DIRAL_PD_STAMP(i) do {} while (0)
-#endif
-  DIRAL_PD_STAMP(0);
 
   // the viewer's signed table distances (dist_piggy, network.py:538-558): row k of the subject-major
   // table holds what every viewer knows about k - one coalesced row read per subject, in batches of
@@ -297,12 +290,10 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
-  DIRAL_PD_STAMP(1);
   // dist_sorted / norm before the sort instead of after it: dividing by the positive norm keeps the order
   // and yields the same 64 quotients (inf stays inf; all-zero distances give the reference's NaN)
 #pragma unroll
   for (int k = 0; k < 64; ++k) v[k] = v[k] / dmax;
-  DIRAL_PD_STAMP(2);
   // ascending bitonic network, compile-time indices: everything stays in registers.  Invalid entries are
   // +inf and end up behind the nvalid real ones; equal values need no tie rule.
 #pragma unroll
@@ -329,7 +320,6 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
   // uniform spacing and two compares against the real edges - later values overwrite earlier ones, and a
   // forward fill over the K + 1 slots completes the edges no value sits directly below.  (Values never
   // exceed e_K = 1 = |v| / max |v|, so C_K is the total; slot 0 stays empty: nothing is below -1.)
-  DIRAL_PD_STAMP(3);
   __syncthreads();                                                       // s_e1
   double* const col = s_c + lane;
   const int kUnsetHi = 0x7ff8dead;                                       // a NaN no sum can be
@@ -354,7 +344,6 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     cur = __double2hiint(t) == kUnsetHi ? cur : t;
     col[j * kPd1Stride] = cur;
   }
-  DIRAL_PD_STAMP(4);
   __syncthreads();
   // rows leave coalesced: consecutive lanes on consecutive bins of a viewer
   for (int e = lane; e < N * K; e += 64) {
@@ -362,11 +351,6 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     const double out = s_c[(j + 1) * kPd1Stride + t] - s_c[j * kPd1Stride + t];
     store_out(p.state_out, (bN + t) * (size_t)p.S + p.off_hist + j, out, p.out_f64);
   }
-#ifdef DIRAL_PD_TIMING
-  DIRAL_PD_STAMP(5);
-  if (lane == 0 && (b & 255) == 0)
-    for (int q = 0; q < 5; ++q) store_out(p.state_out, bN * (size_t)p.S + p.off_hist + q, (double)(pd_t[q + 1] - pd_t[q]), p.out_f64);
-#endif
 }
 
 // ---- a15, 64 < N <= 256: LPV = 2 or 4 lanes per viewer ----------------------------------------------
