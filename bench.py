@@ -307,6 +307,33 @@ def rollout_sps(device, envs=4096, slots=400, warm=80):
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
+def secondary_modes(device, envs=4096, slots=200, warm=100):
+    """the secondary observation modes of obtain_state at the c2 shapes - the
+    step on the specialised kernels plus the observation launch of csrc/posdist_kernel.hpp - per slot,
+    HIP events.  A reported side measurement (profiles/secondary_modes.py is the long form)."""
+    from diral_amd.config import bench_config
+    out = {}
+    for key, st in (("sorted_distances", dict(add_positional_dist=True)), ("type1_histogram", dict(add_positional_dist_type=1))):
+        cfg = bench_config(64, 32, 2000.0, State=st)
+        env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32)
+        env.reset_topology(seed=GLOBAL_SEED)
+        acts = [env.sample(seed=i) for i in range(16)]
+        for t in range(warm):
+            env.step(acts[t % 16], t)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for t in range(warm, warm + slots):
+            env.step(acts[t % 16], t)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        env.check()
+        ms = ev0.elapsed_time(ev1) / slots
+        out[key] = {"workload": "c2 shapes, batch=%d, State %s" % (envs, st), "state_space": cfg.state_space,
+                    "ms_per_slot": ms, "agent_steps_per_s": envs * 64 / (ms * 1e-3)}
+        del env
+    return out
+
+
 def short(res):
     """The keys of a secondary measurement that go into the JSON line."""
     return {"workload": "%s: %d-UE/%d-res, batch=%d" % (res["workload"], res["N"], res["A"], res["B"]),
@@ -446,6 +473,8 @@ def main() -> int:
                     also["c2_sticky_0.9"] = short(r2)
                     also["c2_sticky_0.9"]["emit_chobs"] = emit
                     also["rollout_sps"] = rollout_sps(device)
+                    torch.cuda.empty_cache()
+                    also["secondary_observation_modes"] = secondary_modes(device)
                     torch.cuda.empty_cache()
                 except Exception as exc:
                     also["rollout_sps"] = {"error": repr(exc)[:200]}
