@@ -162,6 +162,18 @@ __global__ __launch_bounds__(64 * kPdWaves) void posdist_kernel(const PosdistPar
   }
 }
 
+// dist2d with the general case in line (the kernels below): a call inside an unrolled sweep would force the
+// registers of the value array through the calling convention at every call site
+__device__ inline double pd_dist(double x1, double y1, double x2, double y2) {
+  const double dx = x2 - x1, dy = y2 - y1;
+  // |dx| in [2^-500, 2^501) or dx == 0, and dy == 0: sqrt(dx * dx) == |dx| exactly (the same test on the
+  // high word as step_fast64.hpp's fast_dist)
+  const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
+  const bool plain = (hi - 0x20b00000u <= 0x3e800000u) || (hi | (unsigned int)__double2loint(dx)) == 0u;
+  if (dy == 0.0 && plain) return __hiloint2double((int)hi, __double2loint(dx));
+  return __builtin_sqrt(dx * dx + dy * dy);
+}
+
 // ---- a16 on a flat highway ------------------------------------------------------------------------
 // v(w) = dist_sign(w, t) (network.py:334-349) is +d for x_w > x_t and -d otherwise, d = dist2d a
 // monotone function of |x_w - x_t| when the y coordinates agree - so v is monotone in x_w, the sorted
@@ -193,16 +205,20 @@ __global__ __launch_bounds__(256) void posdist_sorted_flat_kernel(const PosdistP
     s_dmax[t] = dlo > dhi ? dlo : dhi;
   }
   __syncthreads();
-  int t = tid / M, r = tid - t * M;
-  const int dt = 256 / M, dr = 256 - dt * M;
-  for (int e = tid; e < N * M; e += 256) {
+  // one wave per viewer at a time, lanes along its sorted list: the viewer's own values stay in registers,
+  // the row leaves coalesced
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int t = wave; t < N; t += 4) {
     const double xt = s_px[t], yt = s_py[t], dmax = s_dmax[t];
-    const int w = s_ord[r + (r >= s_rank[t] ? 1 : 0)];                   // the viewer itself is skipped
-    const double d = dist2d(s_px[w], s_py[w], xt, yt);
-    const double v = (s_px[w] - xt > 0.0) ? d : -d;
-    store_out(p.state_out, (bN + t) * (size_t)p.S + p.off_posdist + r, v / dmax, p.out_f64);
-    t += dt; r += dr;
-    if (r >= M) { r -= M; t += 1; }
+    const int rk = s_rank[t];
+    const size_t row = (bN + t) * (size_t)p.S + p.off_posdist;
+    for (int r = lane; r < M; r += 64) {
+      const int w = s_ord[r + (r >= rk ? 1 : 0)];                          // the viewer itself is skipped
+      const double xw = s_px[w];
+      const double d = pd_dist(xw, s_py[w], xt, yt);
+      const double v = (xw - xt > 0.0) ? d : -d;
+      store_out(p.state_out, row + r, v / dmax, p.out_f64);
+    }
   }
 }
 
@@ -216,18 +232,6 @@ __device__ inline double pd_readlane_f64(double v, int srclane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
   return __hiloint2double(hi, lo);
-}
-
-// dist2d with the general case in line: a call inside the unrolled sweep would force the 128 registers of
-// the value array through the calling convention at every call site
-__device__ inline double pd_dist(double x1, double y1, double x2, double y2) {
-  const double dx = x2 - x1, dy = y2 - y1;
-  // |dx| in [2^-500, 2^501) or dx == 0, and dy == 0: sqrt(dx * dx) == |dx| exactly (the same test on the
-  // high word as step_fast64.hpp's fast_dist)
-  const unsigned int hi = (unsigned int)__double2hiint(dx) & 0x7fffffffu;
-  const bool plain = (hi - 0x20b00000u <= 0x3e800000u) || (hi | (unsigned int)__double2loint(dx)) == 0u;
-  if (dy == 0.0 && plain) return __hiloint2double((int)hi, __double2loint(dx));
-  return __builtin_sqrt(dx * dx + dy * dy);
 }
 
 constexpr int kPd1Stride = 65;                         // doubles per row of edge sums: lane t at column t, rows 2 banks apart
