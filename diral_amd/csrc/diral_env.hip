@@ -213,9 +213,12 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
     r.plain_state = ((p.flags & (kRichFlags | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
     if (!has_hist2(p)) r.off_hist = -1;                         // (type 1: posdist_kernel writes those columns)
-    // the sorted-distance columns are posdist_kernel's, every one of them: not written here at all
-    const bool skip = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
-    r.off_skip = skip ? p.off_posdist : 0; r.len_skip = skip ? p.N - 1 : 0;
+    // the sorted-distance columns and the type-1 histogram are posdist_kernel.hpp's, every one of them (and
+    // neighbours in the state vector, state_offsets): not written here at all
+    const bool skip_full = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
+    const bool skip_t1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1 && p.state_out && p.off_hist >= 0;
+    r.off_skip = skip_full ? p.off_posdist : (skip_t1 ? p.off_hist : 0);
+    r.len_skip = (skip_full ? p.N - 1 : 0) + (skip_t1 ? p.K : 0);
     r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
