@@ -17,7 +17,7 @@
 //                                prefix sum - the literal reference statement, slow; serves a16 with
 //                                vehicles off the common lane only.
 //   posdist_sorted_flat_kernel   a16 on the one-lane highway (every pos_y equal - the reference draws
-//                                randint(0, 1), network.py:100): the signed distance is a monotone
+//                                randint(0, 1), network.py:104): the signed distance is a monotone
 //                                function of the other vehicle's x, so ONE ranking of the env's x serves
 //                                all N viewers.
 //   posdist_type1_n64_kernel     a15 for N <= 64: one wave per env, lane = viewer; the viewer's 64
