@@ -442,8 +442,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
   CREATE_TRY(hipMemset(e->vel, 0, bn * 8));
-  CREATE_TRY(hipMemset(e->tkey, 0, (tab + 256) * 4));
-  CREATE_TRY(hipMemset(e->tx, 0, (tab + 256) * 8));
+  CREATE_TRY(hipMemset(e->tkey, 0, (tab + 512 + 64 * 256) * 4));
+  CREATE_TRY(hipMemset(e->tx, 0, (tab + 512 + 64 * 256) * 8));
   CREATE_TRY(hipMemset(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(hipMemset(e->err, 0, 4));
   if (e->la) CREATE_TRY(hipMemset(e->la, 0xFF, bn * e->N * 4));
