@@ -7,6 +7,8 @@ of the fused kernel (stamp -> collide -> reward -> closest-tx -> gossip merge ->
 move -> observe), actions pre-generated in HBM, outputs written to HBM.
 
   python bench.py --gpus 1 --steps 200 --warmup 50
+  python bench.py --gpus N ...          (N > 1 without a launcher: re-executes itself as N ranks under
+                                         torch.distributed.run on 127.0.0.1 with a free port, diral_amd/spawn.py)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -43,6 +45,7 @@ from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_RIC
 from diral_amd.metrics import gather_metrics  # noqa: E402
 from diral_amd.roofline import (HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot,  # noqa: E402
                                 layout_bytes_per_env_slot)
+from diral_amd.spawn import check_visible_gpus, spawn_ranks, under_launcher  # noqa: E402
 from diral_amd.vec_env import VecV2VEnv  # noqa: E402
 
 WORKLOADS = {
@@ -177,16 +180,62 @@ def kernel_name(code: int, N: int, out_dtype: str) -> str:
     return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, b(out_dtype == "f32" and not ch))
 
 
-def load_traffic(workload: str):
-    """HBM bytes per launch from the committed PMC summary (profiles/pmc_traffic.json:
-    rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this bench command, separate runs), if any.
-    NOT measured in this run - rocprofv3 cannot attach to itself."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get(workload)
-    except Exception:
-        return None
+def load_pmc(workload: str):
+    """The committed PMC record of this bench command (profiles/pmc_counters.json, written by
+    profiles/make_pmc_json.py from the rocprofv3 summaries of separate --pmc passes): HBM bytes per
+    launch, VALU busy fraction and the shader clock measured in the same passes.  NOT measured in
+    this run - rocprofv3 cannot attach to the process it did not start."""
+    for fn in ("pmc_counters.json", "pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                rec = json.load(fh).get(workload)
+            if rec:
+                return rec
+        except Exception:
+            pass
+    return None
+
+
+def roofline_object(res, pmc):
+    """The `roofline` object of a measurement: what bounds the kernel and how far it is from it.
+
+    `achieved` / `frac`: the bytes this build's exact minimal state layout HAS to move per launch
+    (diral_amd/roofline.py layout_bytes_per_env_slot: every 4-byte table key read and written once, the
+    subjects' xpos rings, per-vehicle arrays, the outputs) over the kernel time measured in this run, over
+    the 8 TB/s HBM peak - a fraction of the HBM roofline, <= 1 by construction.  `counter_frac`: the same
+    with the HBM bytes the PMC counters saw (committed passes).  The kernels are VALU-bound: `valu_busy`
+    is busy VALU cycles over elapsed CU cycles, both counted in the committed PMC passes.
+    SURVEY 8d's canonical byte model (16-byte table entry) is reported as `model_*`: a throughput in the
+    model's units, not an HBM utilisation (this layout does not move two thirds of those bytes)."""
+    k_s = res["kernel_ms"] * 1e-3
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    pmc_ms = pmc.get("kernel_ms_profiled") if pmc else None
+    out = {
+        "bound": "valu" if (pmc and pmc.get("valu_busy", 0) >= 0.7) else "hbm",
+        "achieved": res["layout_rate_GBps"],
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
+        "bytes_per_launch": res["layout_bytes_per_launch"],
+        "bytes_note": "compulsory HBM bytes of this build's table layout per launch (4-byte key per entry read + written, "
+                      "per-subject xpos rings, per-vehicle arrays, outputs): diral_amd/roofline.py",
+        "kernel": res["kernel"],
+        "kernel_ms": res["kernel_ms"],
+        "traffic": traffic,
+        "counter_frac": (traffic / ((pmc_ms or res["kernel_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+        "valu_busy": pmc.get("valu_busy") if pmc else None,
+        "lds_busy": pmc.get("lds_busy") if pmc else None,
+        "clock_GHz": pmc.get("clock_GHz") if pmc else None,
+        "pmc_source": pmc.get("source") if pmc else None,
+        "pmc_note": "traffic / valu_busy / clock_GHz come from the committed rocprofv3 --pmc passes of this command "
+                    "(separate runs; counter_frac uses the kernel time of those passes), not from this run" if pmc else None,
+        "model_bytes_per_launch": res["algorithmic_bytes_per_launch"],
+        "model_throughput_TBps": res["algorithmic_bytes_per_launch"] / k_s / 1e12,
+        "model_note": "SURVEY 8d's canonical byte model (16-byte table entry read + written) over the kernel time: a throughput "
+                      "in the MODEL's units - this layout moves a 4-byte key per entry, so the figure can exceed the 8 TB/s "
+                      "peak without the HBM being near it; not a roofline fraction",
+    }
+    return out
 
 
 def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f32", step_mode="my_step",
@@ -250,6 +299,7 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         dist.barrier()
         torch.cuda.synchronize(device)
     wall = time.perf_counter() - t_start
+    wall_local = wall
     kernel_ms = ev0.elapsed_time(ev1) / steps       # HIP events on the launch stream
     env.check()
     if use_dist:
@@ -258,17 +308,16 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         wall = float(w.item())
     bytes_launch = algorithmic_bytes_per_env_slot(N, A, cfg.state_space) * B
     layout_launch = layout_bytes_per_env_slot(N, A, cfg.state_space, emit_chobs) * B
-    achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
     code = env.last_kernel()
     res = {
         "workload": name, "N": N, "A": A, "B": B, "L": L, "state_space": cfg.state_space, "cfg": cfg,
         "wall": wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": kernel_ms,
         "agent_steps_per_s": float(B) * N * steps * world / wall,
         "kernel": kernel_name(code, N, out_dtype), "kernel_code": code,
-        "algorithmic_bytes_per_launch": bytes_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_launch": bytes_launch, "emit_chobs": bool(emit_chobs),
         "layout_bytes_per_launch": layout_launch,
         "layout_rate_GBps": layout_launch / (kernel_ms * 1e-3) / 1e9,
-        "preroll_slots": preroll,
+        "preroll_slots": preroll, "wall_this_rank": wall_local,
     }
     return env, res
 
@@ -335,12 +384,24 @@ def secondary_modes(device, envs=4096, slots=200, warm=100):
 
 
 def short(res):
-    """The keys of a secondary measurement that go into the JSON line."""
+    """The keys of a secondary measurement that go into the JSON line (frac: this layout's compulsory
+    bytes over the kernel time over the HBM peak, as in the main roofline object)."""
     return {"workload": "%s: %d-UE/%d-res, batch=%d" % (res["workload"], res["N"], res["A"], res["B"]),
             "agent_steps_per_s": res["agent_steps_per_s"], "ms_per_step": res["ms_per_step"],
             "kernel_ms": res["kernel_ms"], "kernel": res["kernel"],
-            "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
-            "achieved_GBps": res["achieved"], "frac": res["frac"]}
+            "bytes_per_launch": res["layout_bytes_per_launch"],
+            "achieved_GBps": res["layout_rate_GBps"], "frac": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
+            "model_throughput_TBps": res["algorithmic_bytes_per_launch"] / (res["kernel_ms"] * 1e-3) / 1e12}
+
+
+def self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: N ranks of this script under torch.distributed.run."""
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    msg = check_visible_gpus(gpus, visible)
+    if msg:
+        print("bench.py: %s" % msg, file=sys.stderr)
+        return 2
+    return spawn_ranks(os.path.abspath(__file__), sys.argv[1:], gpus)
 
 
 def main() -> int:
@@ -362,16 +423,24 @@ def main() -> int:
                     help="only the timed run (profiling passes): no CPU baseline, PRR parity or secondary workloads")
     args = ap.parse_args()
 
+    if not under_launcher():
+        if args.gpus > 1:
+            return self_launch(args.gpus)                # N ranks of this script, one per GPU
+        if args.gpus < 1:
+            print("bench.py: --gpus must be >= 1", file=sys.stderr)
+            return 2
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus),
-                  file=sys.stderr)
-            return 2
+        print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    msg = check_visible_gpus(local_rank + 1, torch.cuda.device_count())
+    if msg:
+        print("bench.py: rank %d (local rank %d): %s" % (rank, local_rank, msg), file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -381,109 +450,107 @@ def main() -> int:
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rank == 0:
+            print("bench.py: RCCL process group up: backend=%s world=%d (rank 0 on %s)" % (
+                dist.get_backend(), dist.get_world_size(), torch.cuda.get_device_name(device)), file=sys.stderr)
 
     emit = bool(args.emit_chobs)
     env, res = run_workload(args.workload, device, rank, world, args.steps, args.warmup, args.batch, args.out_dtype,
                             args.step_mode, emit, args.sticky, use_dist)
     totals = gather_metrics(env)                         # RCCL all-reduce (metrics only)
+    per_rank = None
+    if use_dist:
+        # every rank's own wall time and kernel time of the timed region (value uses the MAX wall)
+        mine = torch.tensor([res["wall_this_rank"] / args.steps * 1e3, res["kernel_ms"]], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ms = [float(t[0].item()) for t in allr]
+        km = [float(t[1].item()) for t in allr]
+        per_rank = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "kernel_ms_min": min(km), "kernel_ms_max": max(km),
+                    "ms_per_step": ms}
     cfg = res["cfg"]
     del env
-
-    if rank == 0:
-        N, A, B, L = res["N"], res["A"], res["B"], res["L"]
-        tkey = args.workload + ("" if emit else "_nochobs")
-        tr = load_traffic(tkey if (args.batch in (0, WORKLOADS[args.workload][3]) and args.out_dtype == "f32"
-                                   and args.step_mode == "my_step" and args.sticky == 0) else "")
-        traffic = tr.get("hbm_bytes_per_launch") if tr else None
-        line = {
-            "metric": "agent-steps/sec (envs x vehicles), %d-UE/%d-res batched env" % (N, A),
-            "value": res["agent_steps_per_s"],
-            "unit": "agent-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "%s: %d-UE/%d-res, batch=%d envs per GPU x %d GPU, L=%g m, Rc=%g, K=%d bins, "
-                            "reward_design=2, %s+obtain_state fused (state + reward%s), %s actions, %s outputs" % (
-                                args.workload, N, A, B, world, L, cfg.communication_range,
-                                cfg.State.num_bins, args.step_mode, " + channel observation" if emit else "",
-                                "iid-uniform" if args.sticky == 0 else "sticky(p=%.2f)" % args.sticky, args.out_dtype),
-                "batch_per_gpu": B, "num_users": N, "num_channels": A, "state_space": cfg.state_space,
-                "emit_chobs": emit, "preroll_slots": res["preroll_slots"],
-                "parallelism": "env-shard x%d (no data-path collective; one global seed, rank r = envs [r*B, (r+1)*B))" % world,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": res["achieved"],
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": res["frac"],
-                "frac_note": "achieved = SURVEY 8d's ALGORITHMIC bytes (canonical 16-byte table entry, read + written) / kernel time; "
-                             "this build moves a 4-byte key per entry plus per-subject xpos rings (DESIGN.md 2), so frac can "
-                             "approach or pass 1.0 with the HBM far from saturated: see layout_frac_of_peak and limiter",
-                "traffic": traffic,
-                "traffic_source": ("committed PMC passes of this command, not measured in this run: %s" % tr.get("source")) if tr else None,
-                "traffic_rate_GBps": (traffic / (res["kernel_ms"] * 1e-3) / 1e9) if traffic else None,
-                "kernel": res["kernel"],
-                "kernel_ms": res["kernel_ms"],
-                "algorithmic_bytes_per_launch": res["algorithmic_bytes_per_launch"],
-                # what this build's packed layout moves at least (4-byte keys + the subjects' xpos rings instead of the
-                # canonical 16 B per entry of SURVEY 8d): its real HBM rate up to spill scratch.
-                # `frac` prices the CANONICAL bytes, so a layout that moves fewer can approach or pass 1.0 without
-                # the HBM being saturated - read it together with layout_frac_of_peak and the limiter
-                "layout_bytes_per_launch": res["layout_bytes_per_launch"],
-                "layout_rate_GBps": res["layout_rate_GBps"],
-                "layout_frac_of_peak": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
-                "limiter": "VALU issue (~0.9 busy); the xpos ring took the per-entry xpos plane - two thirds of the table bytes - "
-                           "off the HBM (real rate ~4 TB/s), see profiles/README.md",
-            },
-            "episode_metrics": totals,
-        }
-        if world == 1 and not args.lean:
-            # short same-run measurements of the other BASELINE.json configurations and of the
-            # opposite --emit-chobs setting (each: PREROLL untimed slots + a few timed ones)
-            also = {}
-            specs = [("c2_emit_chobs_%d" % (0 if emit else 1), "c2", dict(emit_chobs=not emit, steps=300)),
-                     ("c4shard", "c4shard", dict(emit_chobs=emit, steps=100)),
-                     ("c3", "c3", dict(emit_chobs=emit, steps=40)),
-                     ("c5", "c5", dict(emit_chobs=emit, steps=60))]
-            for key, wl, kw in specs:
-                if args.workload != "c2" or args.batch:
-                    break
-                try:
-                    e2, r2 = run_workload(wl, device, 0, 1, kw["steps"], 10, 0, args.out_dtype, args.step_mode,
-                                          kw["emit_chobs"], args.sticky, False)
-                    del e2
-                    torch.cuda.empty_cache()
-                    also[key] = short(r2)
-                    also[key]["emit_chobs"] = kw["emit_chobs"]
-                except Exception as exc:                      # a secondary measurement never fails the line
-                    also[key] = {"error": repr(exc)[:200]}
-            if args.workload == "c2" and not args.batch:
-                try:
-                    # SURVEY 8d's "converged" action distribution: each agent keeps its resource with p = 0.9
-                    e2, r2 = run_workload("c2", device, 0, 1, 300, 10, 0, args.out_dtype, args.step_mode, emit, 0.9, False)
-                    del e2
-                    also["c2_sticky_0.9"] = short(r2)
-                    also["c2_sticky_0.9"]["emit_chobs"] = emit
-                    also["rollout_sps"] = rollout_sps(device)
-                    torch.cuda.empty_cache()
-                    also["secondary_observation_modes"] = secondary_modes(device)
-                    torch.cuda.empty_cache()
-                except Exception as exc:
-                    also["rollout_sps"] = {"error": repr(exc)[:200]}
-            line["also_measured"] = also
-            line["cpu_baseline"] = cpu_baseline(cfg)
-            line["prr_parity"] = prr_parity(cfg, device)
-        print(json.dumps(line))
     if use_dist:
+        # the collective part of the job is over: the other ranks leave, rank 0 stays for the host-side legs
+        # (CPU baseline, PRR parity) so that nobody sits in a collective while the host cores are being timed
+        dist.barrier()
+        torch.cuda.synchronize(device)
         dist.destroy_process_group()
+    if rank != 0:
+        return 0
+
+    N, A, B, L = res["N"], res["A"], res["B"], res["L"]
+    tkey = args.workload + ("" if emit else "_nochobs")
+    pmc = load_pmc(tkey if (args.batch in (0, WORKLOADS[args.workload][3]) and args.out_dtype == "f32"
+                            and args.step_mode == "my_step" and args.sticky == 0) else "")
+    line = {
+        "metric": "agent-steps/sec (envs x vehicles), %d-UE/%d-res batched env" % (N, A),
+        "value": res["agent_steps_per_s"],
+        "unit": "agent-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d-UE/%d-res, batch=%d envs per GPU x %d GPU, L=%g m, Rc=%g, K=%d bins, "
+                        "reward_design=2, %s+obtain_state fused (state + reward%s), %s actions, %s outputs" % (
+                            args.workload, N, A, B, world, L, cfg.communication_range,
+                            cfg.State.num_bins, args.step_mode, " + channel observation" if emit else "",
+                            "iid-uniform" if args.sticky == 0 else "sticky(p=%.2f)" % args.sticky, args.out_dtype),
+            "batch_per_gpu": B, "num_users": N, "num_channels": A, "state_space": cfg.state_space,
+            "emit_chobs": emit, "preroll_slots": res["preroll_slots"],
+            "parallelism": "env-shard x%d (no data-path collective; one global seed, rank r = envs [r*B, (r+1)*B))" % world,
+            "launcher": "torch.distributed.run, RCCL group of %d" % world if use_dist else "single process, no process group",
+        },
+        "roofline": roofline_object(res, pmc),
+        "episode_metrics": totals,
+    }
+    if per_rank:
+        line["per_rank"] = per_rank
+    if world == 1 and not args.lean:
+        # short same-run measurements of the other BASELINE.json configurations and of the
+        # opposite --emit-chobs setting (each: PREROLL untimed slots + a few timed ones)
+        also = {}
+        specs = [("c2_emit_chobs_%d" % (0 if emit else 1), "c2", dict(emit_chobs=not emit, steps=300)),
+                 ("c4shard", "c4shard", dict(emit_chobs=emit, steps=100)),
+                 ("c3", "c3", dict(emit_chobs=emit, steps=40)),
+                 ("c5", "c5", dict(emit_chobs=emit, steps=60))]
+        for key, wl, kw in specs:
+            if args.workload != "c2" or args.batch:
+                break
+            try:
+                e2, r2 = run_workload(wl, device, 0, 1, kw["steps"], 10, 0, args.out_dtype, args.step_mode,
+                                      kw["emit_chobs"], args.sticky, False)
+                del e2
+                torch.cuda.empty_cache()
+                also[key] = short(r2)
+                also[key]["emit_chobs"] = kw["emit_chobs"]
+            except Exception as exc:                      # a secondary measurement never fails the line
+                also[key] = {"error": repr(exc)[:200]}
+        if args.workload == "c2" and not args.batch:
+            try:
+                # SURVEY 8d's "converged" action distribution: each agent keeps its resource with p = 0.9
+                e2, r2 = run_workload("c2", device, 0, 1, 300, 10, 0, args.out_dtype, args.step_mode, emit, 0.9, False)
+                del e2
+                also["c2_sticky_0.9"] = short(r2)
+                also["c2_sticky_0.9"]["emit_chobs"] = emit
+                also["rollout_sps"] = rollout_sps(device)
+                torch.cuda.empty_cache()
+                also["secondary_observation_modes"] = secondary_modes(device)
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                also["rollout_sps"] = {"error": repr(exc)[:200]}
+        line["also_measured"] = also
+    if not args.lean:
+        # host-side legs, on rank 0 at every N (the other ranks have left the job by now)
+        line["cpu_baseline"] = cpu_baseline(cfg)
+        line["prr_parity"] = prr_parity(cfg, device)
+    print(json.dumps(line), flush=True)
     return 0
 
 

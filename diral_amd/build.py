@@ -49,11 +49,26 @@ def _obj_stale(src: str, obj: str) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB, objdir: str = OBJDIR) -> str:
+def variant_objdir(lib: str, extra_flags=()) -> str:
+    """Object directory of a build: the product's own, or one per (library name, flag set) for a tuning
+    variant - a variant never reuses or overwrites objects compiled with other -D flags."""
+    if lib == LIB and not extra_flags:
+        return OBJDIR
+    import hashlib
+    tag = hashlib.sha256(("\0".join([os.path.abspath(lib)] + list(extra_flags))).encode()).hexdigest()[:12]
+    return os.path.join(OBJDIR, "variant_" + tag)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB, objdir: str = None) -> str:
     """Compile every translation unit (in parallel, one hipcc each) and link the .so.
-    `extra_flags` / `lib` / `objdir`: tuning variants (-D...) built next to the product."""
-    if not force and lib == LIB and not is_stale():
+    `extra_flags` / `lib` / `objdir`: tuning variants (-D...) built next to the product, objects in a
+    directory of their own (variant_objdir)."""
+    if not force and lib == LIB and not extra_flags and not is_stale():
         return lib
+    if objdir is None:
+        objdir = variant_objdir(lib, extra_flags)
+    if lib == LIB and extra_flags:
+        raise ValueError("a build with extra flags must not overwrite the product library: pass lib=")
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
     procs, objs = [], []

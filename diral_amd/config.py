@@ -70,6 +70,8 @@ ERR_HIP = -4
 ERR_NO_DEVICE = -5
 ERR_ACTION_RANGE = -6
 ERR_SEQ_OVERFLOW = -7
+ERR_CAPTURE = -8
+ERR_TABLE_CONFLICT = -9
 
 
 class DiralCfg(ctypes.Structure):

@@ -95,6 +95,23 @@ __global__ void ring_rebuild_kernel(int B, int N, int NV, int NR, const uint32_t
   const uint32_t seq = tkey[row * NV + u] >> 8, tk = tkey[row * NV + k] >> 8;
   if (tk - seq <= 7u) ring[row * 8 + (seq & 7u)] = tx[row * NV + u];
 }
+// After an import: every entry the ring answers for must find ITS xpos there.  Tables no run of the reference
+// produces (two entries about one subject with the same sequence number and different xpos) make the writers of
+// ring_rebuild_kernel race; the loser is found here and reported through the sticky error word
+// (diral_env_check: DIRAL_ERR_TABLE_CONFLICT).  Bitwise comparison: -0.0 / NaN payloads count as written.
+__global__ void ring_verify_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* tx, const double* ring,
+                                   uint32_t* err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * N * N) return;
+  const int u = (int)(i % N);
+  const int k = (int)((i / N) % N);
+  const int b = (int)(i / ((size_t)N * N));
+  const size_t row = (size_t)b * NR + k;
+  const uint32_t seq = tkey[row * NV + u] >> 8, tk = tkey[row * NV + k] >> 8;
+  if (tk - seq <= 7u &&
+      __double_as_longlong(ring[row * 8 + (seq & 7u)]) != __double_as_longlong(tx[row * NV + u]))
+    atomicOr(err, kErrTable);
+}
 __global__ void ring_materialize_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, const double* ring, double* tx) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)B * N * N) return;

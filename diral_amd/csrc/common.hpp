@@ -27,6 +27,7 @@ constexpr int kModeObserve = 3;  // internal: obtain_state only
 
 constexpr uint32_t kErrAction = 1u;
 constexpr uint32_t kErrSeq = 2u;
+constexpr uint32_t kErrTable = 4u;   // import: conflicting xpos for one (subject, sequence number)
 
 struct StepParams {
   // geometry

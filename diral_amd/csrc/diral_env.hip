@@ -52,6 +52,7 @@ struct DiralEnv {
   bool flat_y = true;      // every pos_y == 0 (random topologies, network.py:104): |dx| distance path
   uint32_t* yflag = nullptr;
   unsigned long long* dbg = nullptr;   // DIRAL_TIMING builds: [B][waves][8] timestamps
+  bool capture_violation = false;   // a ring <-> plane switch was asked for inside a stream capture
   std::string last_hip_error;
 };
 
@@ -61,6 +62,11 @@ bool has(const DiralCfg* c, uint32_t f) { return (c->flags & f) != 0; }
 
 int note_hip(DiralEnv* e, hipError_t st, const char* what) {
   if (st == hipSuccess) return DIRAL_OK;
+  if (e && e->capture_violation) {
+    e->capture_violation = false;
+    e->last_hip_error = std::string(what) + ": the call needs a ring <-> plane conversion launch, which cannot be part of a stream capture";
+    return DIRAL_ERR_CAPTURE;
+  }
   if (e) e->last_hip_error = std::string(what) + ": " + hipGetErrorString(st);
   return DIRAL_ERR_HIP;
 }
@@ -140,7 +146,7 @@ constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | 
 bool is_specialised_cfg(const StepParams& p) {
   const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY;
   const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
-                          DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | DIRAL_F_ADD_POSDIST | kRichFlags;
+                          DIRAL_F_TRACK_PRR | DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | DIRAL_F_ADD_POSDIST | kRichFlags;
   return (p.flags & ~ignore) == want &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN);
 }
@@ -155,9 +161,39 @@ bool is_plain_cfg(const StepParams& p) {
 
 int blocks(size_t total, int threads) { return (int)((total + threads - 1) / threads); }
 
+// The handle-less entry points (diral_sps_*, diral_driver_shape) take device pointers only: they run on the
+// device that owns `p` (their first mandatory buffer), whatever device is current in the calling thread.
+int device_of_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (p && hipPointerGetAttributes(&a, p) == hipSuccess) return a.device;
+  (void)hipGetLastError();
+  return -1;
+}
+struct PtrDeviceGuard {
+  int prev = -1, dev = -1;
+  bool ok = true;
+  explicit PtrDeviceGuard(const void* p) : dev(device_of_ptr(p)) {
+    if (dev < 0) return;                                        // not a device allocation HIP knows: current device
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~PtrDeviceGuard() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
+// A switch between the xpos ring and the per-entry plane (ring_rebuild / ring_materialize) is a launch that
+// depends on HOST-side validity flags: recorded into a hipGraph it would replay against tables it no longer
+// describes.  Such a call fails with DIRAL_ERR_CAPTURE instead (do the first step of a new kernel path, or the
+// export / observe, outside the capture).
+bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+
 // every consumer of the per-entry xpos plane other than step_fast64 goes through here first
 hipError_t ensure_plane(DiralEnv* e, hipStream_t s) {
   if (e->plane_valid || !e->ring) { e->plane_valid = true; return hipSuccess; }
+  if (stream_is_capturing(s)) { e->capture_violation = true; return hipErrorStreamCaptureUnsupported; }
   const size_t total = (size_t)e->B * e->N * e->N;
   hipLaunchKernelGGL(ring_materialize_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                      e->ring, e->tx);
@@ -166,10 +202,19 @@ hipError_t ensure_plane(DiralEnv* e, hipStream_t s) {
 }
 hipError_t ensure_ring(DiralEnv* e, hipStream_t s) {
   if (e->ring_valid) return hipSuccess;
+  if (stream_is_capturing(s)) { e->capture_violation = true; return hipErrorStreamCaptureUnsupported; }
   const size_t total = (size_t)e->B * e->N * e->N;
   hipLaunchKernelGGL(ring_rebuild_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                      e->tx, e->ring);
   e->ring_valid = true;
+  return hipGetLastError();
+}
+
+// after an import: the ring must answer every young entry with that entry's own xpos (aux_kernels.hpp)
+hipError_t verify_ring(DiralEnv* e, hipStream_t s) {
+  const size_t total = (size_t)e->B * e->N * e->N;
+  hipLaunchKernelGGL(ring_verify_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey, e->tx,
+                     e->ring, e->err);
   return hipGetLastError();
 }
 
@@ -199,6 +244,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
     f.done_now = ((p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226
+    f.prr = ((p.flags & DIRAL_F_TRACK_PRR) && p.mode == DIRAL_STEP_MY_STEP) ? 1 : 0;
     f.chobs_mode = (p.chobs_out ? 1 : 0) | ((p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ? 2 : 0);
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
@@ -223,7 +269,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
-    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr;   // EXTRA instantiation: the run-time switches compiled in
+    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr || f.prr != 0;   // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
@@ -314,6 +360,8 @@ const char* diral_env_strerror(int status) {
     case DIRAL_ERR_NO_DEVICE: return "no usable HIP device";
     case DIRAL_ERR_ACTION_RANGE: return "action outside [0, num_channels)";
     case DIRAL_ERR_SEQ_OVERFLOW: return "more than DIRAL_MAX_SLOTS steps since reset";
+    case DIRAL_ERR_CAPTURE: return "call needs a ring <-> plane conversion and the stream is being captured into a hipGraph";
+    case DIRAL_ERR_TABLE_CONFLICT: return "imported tables hold entries about one subject with equal sequence numbers but different xpos";
     default: return "unknown status";
   }
 }
@@ -656,7 +704,7 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
     HIP_TRY(e, hipGetLastError());
     // the ring again, right away (not at the next step: a step sequence captured into a hipGraph must not
     // contain a rebuild from a plane that later replays find stale)
-    if (e->ring) HIP_TRY(e, ensure_ring(e, s));
+    if (e->ring) { HIP_TRY(e, ensure_ring(e, s)); HIP_TRY(e, verify_ring(e, s)); }
   }
   if (last_arrival) {
     if (!e->la) return DIRAL_ERR_BAD_CONFIG;
@@ -687,7 +735,7 @@ int diral_env_import_entries(DiralEnv* e, const DiralNeighborEntry* entries, voi
   hipLaunchKernelGGL(import_entries_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, entries,
                      e->tkey, e->tx);
   HIP_TRY(e, hipGetLastError());
-  if (e->ring) HIP_TRY(e, ensure_ring(e, s));                    // as in diral_env_import_state
+  if (e->ring) { HIP_TRY(e, ensure_ring(e, s)); HIP_TRY(e, verify_ring(e, s)); }   // as in diral_env_import_state
   return DIRAL_OK;
 }
 
@@ -724,14 +772,18 @@ int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
   return DIRAL_OK;
 }
 
-// DIRAL_TIMING builds only (not part of the ABI header): copy the phase
+#ifdef DIRAL_TIMING
+// -DDIRAL_TIMING tuning builds only (profiles/phase_timing.py binds it by name); compiled out of the
+// release library, so the release symbol table is exactly include/diral_env.h: copy the phase
 // timestamps [B][waves][8] to a host buffer.
 int diral_env_debug_timing(DiralEnv* e, unsigned long long* host_out, int waves) {
   if (!e || !e->dbg || !host_out) return DIRAL_ERR_BAD_ARG;
+  DeviceGuard guard(e->device);
   if (hipDeviceSynchronize() != hipSuccess) return DIRAL_ERR_HIP;
   if (hipMemcpy(host_out, e->dbg, (size_t)e->B * waves * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return DIRAL_ERR_HIP;
   return DIRAL_OK;
 }
+#endif
 
 int diral_sps_step(int agents, int num_channels, const double* selection_window, int32_t* prev_action,
                    int32_t* counter, double rssi_threshold, double inc_db, double keep_prob,
@@ -739,6 +791,8 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
                    int32_t* actions_out, void* stream) {
   if (agents < 1 || num_channels < 1 || !selection_window || !prev_action || !counter || !actions_out)
     return DIRAL_ERR_BAD_ARG;
+  PtrDeviceGuard guard(prev_action);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const hipStream_t st = (hipStream_t)stream;
   const dim3 g(blocks((size_t)agents, 256)), t(256);
 #define DIRAL_SPS_WAVE(NC)                                                                                           \
@@ -765,6 +819,8 @@ int diral_driver_shape(int envs, int num_users, int num_channels, const void* re
   if (dtype != DIRAL_F32 && dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
   if ((flags & 4) && (!actions || !pen_counter || !prev_actions)) return DIRAL_ERR_BAD_ARG;
   if ((flags & 2) && (!ia || !sum_ia_prev)) return DIRAL_ERR_BAD_ARG;
+  PtrDeviceGuard guard(reward_in);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const dim3 g(blocks((size_t)envs, kShapeEnvsPerBlock)), t(256);
   if (dtype == DIRAL_F64)
     hipLaunchKernelGGL(driver_shape_kernel<double>, g, t, 0, (hipStream_t)stream, envs, num_users, num_channels,
@@ -785,6 +841,8 @@ int diral_sps_window_from_chobs(int agents, int num_channels, const void* chobs,
                                 const int32_t* actions, double* window_out, void* stream) {
   if (agents < 1 || num_channels < 1 || !chobs || !actions || !window_out) return DIRAL_ERR_BAD_ARG;
   if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  PtrDeviceGuard guard(chobs);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const size_t total = (size_t)agents * num_channels;
   if (chobs_dtype == DIRAL_F64)
     hipLaunchKernelGGL(sps_window_kernel<double>, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
@@ -803,6 +861,8 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
     return DIRAL_ERR_BAD_ARG;
   if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
   if (num_channels > kSpsWaveMaxA) return DIRAL_ERR_UNSUPPORTED;   // use window_from_chobs + sps_step
+  PtrDeviceGuard guard(prev_action);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const hipStream_t st = (hipStream_t)stream;
   const dim3 g(blocks((size_t)agents, 256)), t(256);
 #define DIRAL_SPS_WAVE(NC, T)                                                                                          \
@@ -825,6 +885,8 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
 int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32_t* counter, uint64_t seed,
                    void* stream) {
   if (agents < 1 || selection_window < 0 || !prev_action || !counter) return DIRAL_ERR_BAD_ARG;
+  PtrDeviceGuard guard(prev_action);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipLaunchKernelGGL(sps_init_kernel, dim3(blocks((size_t)agents, 256)), dim3(256), 0, (hipStream_t)stream, agents,
                      selection_window, seed, prev_action, counter);
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
@@ -839,6 +901,7 @@ int diral_env_check(DiralEnv* e, void* stream) {
   if (flags) HIP_TRY(e, hipMemsetAsync(e->err, 0, 4, (hipStream_t)stream));
   if (flags & kErrAction) return DIRAL_ERR_ACTION_RANGE;
   if (flags & kErrSeq) return DIRAL_ERR_SEQ_OVERFLOW;
+  if (flags & kErrTable) return DIRAL_ERR_TABLE_CONFLICT;
   return DIRAL_OK;
 }
 

@@ -55,6 +55,8 @@ struct FastParams {
   int reward_design, age_limit, episode_interval;
   int design;                    // 1: my_step_design (test_env.py:269-349) - runtime switch of the non-CH instantiation
   int done_now;                  // t % episode_interval == episode_interval - 1 (main_test.py:226), evaluated on the host
+  int prr;                       // 1: my_step also accumulates the PRR metric columns (DIRAL_F_TRACK_PRR, a build extension:
+                                 // the reception ratio of test_env.py:384-405 per colliding transmitter) - EXTRA instantiations
   int chobs_mode;                // RICH: bit 0 = chobs_out is set; bit 1 = the channel observation is the distance to the
                                  // closest in-range transmitter (my_step with State.type 2) instead of the constant 1
                                  // (my_step_ch, my_step_design, State.type 1).  Host-folded: P1 touches no RichParams field
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       const bool bt = inr && (d < best);
       best = bt ? d : best;
       bid = bt ? w : bid;
-      if (CH && c > 1) {                                      // in_range[tx] (test_env.py:395-397)
+      if ((CH || (EXTRA && p.prr)) && c > 1) {                // in_range[tx] (test_env.py:395-397)
         const int n_in = __popcll(__ballot(live && (myact != i) && inr));
         if (lane == 0) s_inr[w] = n_in;
       }
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
     }
     if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
-    if (CH) {
+    if (CH || (EXTRA && p.prr)) {
       if (c > 1) {
         // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
         wave_lds_order();
@@ -407,7 +409,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           }
         }
       }
-    } else if (c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
+    }
+    if (!CH && c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
       double rw;
       if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
         // inlined common case (reward_design 2, network.py:291-295 weight): a pair
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
+      if (!CH && EXTRA && p.prr) prr = (c > 1) ? s_rtx[lane] : 1.0;   // the metric only: the reward stays my_step's
       if constexpr (RICH && !CH) {
         // proportional fairness (test_env.py:215-222, my_step only): a transmitter that collided more than
         // pf_threshold slots in a row is paid pf_penalty; a successful transmission resets its counter
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       vr += __shfl_down(vr, off);
-      if (CH) vp += __shfl_down(vp, off);
+      if (CH || EXTRA) vp += __shfl_down(vp, off);
       vs += __shfl_down(vs, off);
       vc += __shfl_down(vc, off);
     }
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       mt[DIRAL_M_SUM_REWARD] += vr;
       mt[DIRAL_M_TX_SOLE] += (double)vs;
       mt[DIRAL_M_TX_COLLIDED] += (double)vc;
-      if (CH) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
+      if (CH || (EXTRA && p.prr)) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
       uint8_t* const done_out = lp->done_out;
       if (done_out) done_out[b] = (uint8_t)lp->done_now;
     }

@@ -407,12 +407,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             bid[j] = bt ? w : bid[j];
             if (EXTRA && p.la && (FULL || lane + 64 * j < N) && (myact[j] != i) && !inr)
               p.la[(bN + w) * N + lane + 64 * j] = -1;          // find_closest_tx side effect (network.py:394)
-            if (CH && c > 1)                                    // in_range[tx] (test_env.py:395-397)
+            if ((CH || (EXTRA && p.prr)) && c > 1)              // in_range[tx] (test_env.py:395-397)
               n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
             if (EXTRA && !CH && p.design && c > 1)              // my_step_design: tx of this resource within 2 Rc
               n_in += __popcll(__ballot((myact[j] == i) && (lane + 64 * j != w) && (d < 2.0 * p.Rc)));
           }
-          if (CH && c > 1 && lane == 0) *inr_of(w) = n_in;
+          if ((CH || (EXTRA && p.prr)) && c > 1 && lane == 0) *inr_of(w) = n_in;
           if (EXTRA && !CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
         }
       }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
       }
       s_mtab[i * MT + lane] = (mword_t)mw;
-      if (CH) {
+      if (CH || (EXTRA && p.prr)) {
         if (c > 1) {
           // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
           wave_lds_order();
@@ -446,7 +446,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             }
           }
         }
-      } else if (c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
+      }
+      if (!CH && c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
         double rw;
         if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
           if (c == 2) {
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { rw = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
+      if (!CH && EXTRA && p.prr) prr = (c > 1) ? *rtx_of(u) : 1.0;            // DIRAL_F_TRACK_PRR: the metric only
       if constexpr (RICH && !CH) {                                             // proportional fairness, as in step_fast64.hpp
         const LateRichArgs lr = (LateRichArgs)(late2 + kRichArgOffset);
         int32_t* const pf = lr->pf;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       vr += __shfl_down(vr, off);
-      if (CH) vp += __shfl_down(vp, off);
+      if (CH || EXTRA) vp += __shfl_down(vp, off);
       vs += __shfl_down(vs, off);
       vc += __shfl_down(vc, off);
     }
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     mt[DIRAL_M_SUM_REWARD] += sr;
     mt[DIRAL_M_TX_SOLE] += ss;
     mt[DIRAL_M_TX_COLLIDED] += sc;
-    if (CH) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
+    if (CH || (EXTRA && lp->prr)) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
   }
   if constexpr (RICH) {
     const RichParams rr = load_rich_args(late);

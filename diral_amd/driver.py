@@ -164,7 +164,7 @@ class DriverLoop:
             shaped, sum_r, collision, pen, ia_sum = self._shape_on_device(reward, a, out.get("ia"))
             if ia_sum is not None:
                 out["ia_sum"] = ia_sum
-            if self.ia_averaging:
+            if pen is not None:
                 out["ia_penalty"] = pen
             episode_end = (time_step % self.episode_interval) == self.episode_interval - 1   # :226
             out.update(next_state=next_state, reward=shaped, raw_reward=raw, sum_r=sum_r, collision=collision,
@@ -210,15 +210,18 @@ class DriverLoop:
         shaped = torch.empty_like(reward)
         sum_r = torch.empty((B,), dtype=reward.dtype, device=dev)
         coll = torch.empty((B,), dtype=reward.dtype, device=dev)
-        pen = torch.zeros((B,), dtype=torch.int32, device=dev) if self.ia_averaging else None
+        pen = torch.zeros((B,), dtype=torch.int32, device=dev) if (self.ia_averaging and ia is not None) else None
         ia32 = None if ia is None else ia.to(torch.int32).contiguous()
         ia_sum = None if ia is None else torch.empty((B,), dtype=torch.int64, device=dev)
-        flags = (1 if self.global_reward_avg else 0) | (2 if self.ia_averaging else 0) | (4 if self.ia_penalty_enable else 0)
+        # (the information-age term only when this slot fetched the histogram: slot(..., want_ia=False) with
+        # ia_averaging skips it, exactly like the torch statement in slot())
+        use_ia = self.ia_averaging and ia is not None
+        flags = (1 if self.global_reward_avg else 0) | (2 if use_ia else 0) | (4 if self.ia_penalty_enable else 0)
 
         def p(t):
             return None if t is None else t.data_ptr()
         st = env.lib.diral_driver_shape(B, N, self.A, p(reward), 1 if reward.dtype == torch.float64 else 0, p(a32), p(ia32),
-                                        p(self._sum_ia_prev) if self.ia_averaging else None,
+                                        p(self._sum_ia_prev) if use_ia else None,
                                         p(self._pen_counter) if self.ia_penalty_enable else None,
                                         p(self._prev_actions) if self.ia_penalty_enable else None, flags,
                                         int(self.ia_penalty_threshold), float(self.ia_penalty_value), p(shaped), p(sum_r),

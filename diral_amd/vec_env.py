@@ -214,6 +214,7 @@ class VecV2VEnv:
                                           self._stream()), "diral_env_reset")
         self.t = 0
         self._spec = None
+        self._vel_calls = 0                     # default-seed velocity draws after a reset == those of a fresh env
 
     def reset(self, x0=None, y0=None, v0=None, seed: int = 0, actions=None) -> torch.Tensor:
         """``reset() -> obs``.  The reference has no reset(); its driver
@@ -293,8 +294,9 @@ class VecV2VEnv:
         if self.speculate_state and self.S > 0:
             # the state vector built in the same launch is what obtain_state(chobs, actions, rew)
             # would build now; remember what it is valid for (tensor identity + version counters)
-            self._spec = (actions if isinstance(actions, torch.Tensor) else None, a, a._version,
-                          self._chobs._version, self._rew._version)
+            given = actions if isinstance(actions, torch.Tensor) else None
+            self._spec = (given, a, a._version, self._chobs._version, self._rew._version,
+                          None if given is None else given._version)
         return self._chobs, self._rew
 
     def my_step(self, actions, timestep: int = 0):
@@ -312,7 +314,7 @@ class VecV2VEnv:
         sp = self._spec
         if sp is None:
             return None
-        given, a, a_ver, c_ver, r_ver = sp
+        given, a, a_ver, c_ver, r_ver, g_ver = sp
         st = self.cfg.State
         # `obs` / `rewards` only matter to the state through their own sections (test_env.py:540, 563)
         if st.add_channel_obs and (obs is not self._chobs or self._chobs._version != c_ver):
@@ -321,7 +323,9 @@ class VecV2VEnv:
             return None
         if a._version != a_ver:
             return None
-        if not (acts is a or (given is not None and acts is given)):
+        # (`a` may be a converted COPY of the caller's tensor: an in-place edit of that tensor between my_step
+        # and obtain_state must miss, so its own version counter is part of the key)
+        if not (acts is a or (given is not None and acts is given and given._version == g_ver)):
             t = torch.as_tensor(acts, device=self.device)
             if t.shape != a.shape and t.dim() == 1:
                 t = t.unsqueeze(0).expand(self.B, self.N)

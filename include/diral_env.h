@@ -47,7 +47,16 @@ typedef enum DiralStatus {
   DIRAL_ERR_NO_DEVICE = -5,    /* no gfx950 device / device index out of range */
   DIRAL_ERR_ACTION_RANGE = -6, /* an action outside [0, A) was seen (sticky flag
                                   raised by the step kernel; test_env.py:592)   */
-  DIRAL_ERR_SEQ_OVERFLOW = -7  /* more than DIRAL_MAX_SLOTS steps since reset   */
+  DIRAL_ERR_SEQ_OVERFLOW = -7, /* more than DIRAL_MAX_SLOTS steps since reset   */
+  DIRAL_ERR_CAPTURE = -8,      /* the call would launch a ring <-> plane conversion
+                                  (first step after a kernel-path switch, export /
+                                  observe after ring steps) while `stream` is being
+                                  captured into a hipGraph: do it outside the capture */
+  DIRAL_ERR_TABLE_CONFLICT = -9 /* imported tables: two entries about one subject carry
+                                  the same sequence number but different xpos - no
+                                  run of the reference produces that (an entry IS the
+                                  subject's stamp at that number, vehicle.py:35-63);
+                                  raised by diral_env_check after an import      */
 } DiralStatus;
 
 /* ---- config flags: the booleans of the `EnvironmentTest` YAML block -------- */
@@ -260,10 +269,13 @@ int diral_env_set_trace(DiralEnv* env, const double* x_positions, int T, int per
  * exported state qualifies).  The kernels build on it: N <= 64 keeps the xpos of
  * entries at most 7 stamps old in a per-subject ring instead of the per-entry
  * plane, N > 64 routes xpos through a rank-indexed table; export / observe /
- * other consumers see the plane completed first (no caller-visible difference;
- * inside ONE captured hipGraph do not switch DIRAL_OPT_KERNEL_PATH between steps:
- * the ring is rebuilt lazily after a step of the general kernel, and a captured
- * rebuild would replay against a plane that is no longer complete). */
+ * other consumers see the plane completed first (no caller-visible difference).
+ * An import that violates the requirement is detected: the next
+ * diral_env_check() returns DIRAL_ERR_TABLE_CONFLICT.  A call that needs the
+ * plane <-> ring conversion launch (the first step after a kernel-path switch,
+ * export / observe after ring steps) while `stream` is being captured into a
+ * hipGraph returns DIRAL_ERR_CAPTURE and launches nothing: a captured
+ * conversion would replay against tables it no longer describes. */
 int diral_env_export_state(DiralEnv* env, double* pos_x, double* pos_y,
                            double* vel, int32_t* tab_seq, int32_t* tab_age,
                            double* tab_x, double* tab_y, int32_t* last_arrival,

@@ -1,0 +1,91 @@
+"""Full-size parity of the BENCHMARKED instantiations (BASELINE.json configs[1], [2], [4]): the exact kernel,
+output dtype and outputs bench.py times - f32 state + reward + channel observation from ONE launch, device-drawn
+topology from the bench's seed - at the bench's batch sizes.  Size-independent properties on EVERY env, and
+sampled envs compared bit for bit with the oracle (state, reward AND channel observation; the f32 outputs are
+the float32 cast of the reference's float64 values)."""
+import numpy as np
+import pytest
+import torch
+
+from diral_amd.config import KERNEL_FAST64, KERNEL_RICH, KERNEL_RING, KERNEL_WIDE, STEP_MY_STEP, bench_config
+
+pytestmark = pytest.mark.gpu
+
+GLOBAL_SEED = 1234      # bench.py's
+
+
+def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None):
+    from diral_amd.vec_env import VecV2VEnv
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(N, A, L, mobility_vary=vary)
+    K = cfg.State.num_bins
+    env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32)
+    env.reset_topology(seed=GLOBAL_SEED)                    # the device draws bench.py uses
+    st0 = env.export_state(tables=False)
+    rng = np.random.default_rng(N * 1000 + A)
+    sample = np.sort(rng.choice(B, size=n_sample, replace=False))
+    sample_t = torch.as_tensor(sample, device="cuda:0")
+    orc = Oracle(cfg, batch=n_sample, sq_mode=SQ_IEEE, threads=8)
+    orc.reset(st0["pos_x"][sample_t].cpu().numpy(), st0["pos_y"][sample_t].cpu().numpy(), st0["vel"][sample_t].cpu().numpy())
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    for t in range(T):
+        a_t = torch.randint(0, A, (B, N), device="cuda:0", dtype=torch.int32, generator=g)
+        obs, rew, done = env._step(STEP_MY_STEP, a_t, t, want_chobs=True)     # what bench.py's timed step calls
+        chobs = env._chobs
+        assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_RING, env.last_kernel()
+        al = a_t.long()
+        # (1) one-hot section == actions
+        assert torch.equal(obs[..., :A].argmax(-1), al) and torch.all(obs[..., :A].sum(-1) == 1)
+        # (2) histogram rows sum to 1 (or are all zero); every bin is a multiple of 1/n
+        hs = obs[..., A:].double().sum(-1)
+        assert torch.all(((hs - 1).abs() < 1e-5) | (hs == 0))
+        # (3) rewards against collision counts recomputed in torch (reward_design 2)
+        cnt = torch.zeros((B, A), dtype=torch.long, device="cuda:0").scatter_add_(1, al, torch.ones_like(al))
+        c = cnt.gather(1, al)
+        assert torch.all(rew[c == 1] == 1)
+        assert torch.all(rew[c > 2] == -c[c > 2].float())
+        assert torch.all((rew[c == 2] == 0) | (rew[c == 2] == -2))
+        # (4) channel observation: 0 on the own resource and on unused ones, else a distance < Rc or the 100000 sentinel
+        own = torch.gather(chobs, 2, al.unsqueeze(-1))
+        assert torch.all(own == 0)
+        used = (cnt > 0).unsqueeze(1).expand(B, N, A)
+        assert torch.all(chobs[~used] == 0)
+        v = chobs[used]
+        assert torch.all((v == 0) | (v == 100000.0) | ((v > 0) & (v < cfg.communication_range)))
+        assert torch.all(done == (1 if t % cfg.episode_interval == cfg.episode_interval - 1 else 0))
+        # (5) sampled envs bit for bit vs the oracle
+        acts_s = a_t[sample_t].cpu().numpy()
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, acts_s, t)
+        o_state = orc.obtain_state(acts_s, o_chobs, o_rew)
+        assert np.array_equal(obs[sample_t].cpu().numpy(), o_state.astype(np.float32)), t
+        assert np.array_equal(rew[sample_t].cpu().numpy(), o_rew.astype(np.float32)), t
+        assert np.array_equal(chobs[sample_t].cpu().numpy(), o_chobs.astype(np.float32)), t
+        if vel_slot is not None and t == vel_slot:
+            draws = torch.randint(1, 4, (B, N), device="cuda:0", dtype=torch.uint8, generator=g)
+            env.update_velocity(draws)
+            orc.update_velocity(draws[sample_t].cpu().numpy())
+    # (6) tables: own sequence number == slot count, nobody ahead of the subject; sampled envs' planes vs the oracle
+    st = env.export_state()
+    assert st["pos_x"].min() >= 0 and st["pos_x"].max() < L
+    diag = torch.diagonal(st["seq"], dim1=1, dim2=2)
+    assert torch.all(diag == T) and torch.all(st["seq"] <= T)
+    oe = orc.export()
+    for k in ("pos_x", "vel", "seq", "x"):
+        assert np.array_equal(st[k][sample_t].cpu().numpy(), oe[k]), k
+    assert np.array_equal(st["age"][sample_t].cpu().numpy(), np.minimum(oe["age"], 255))
+    env.check()
+
+
+def test_c2_benchmarked_instantiation_full_size():
+    """configs[1]: 64 UE / 32 res, B = 4096 - step_fast64_kernel<true,false,false,false,true>."""
+    _run(64, 32, 2000.0, 4096, False, n_sample=48, T=32, fam=KERNEL_FAST64)
+
+
+def test_c3_benchmarked_instantiation_full_size():
+    """configs[2]: 256 UE / 64 res congested, B = 8192 - step_wide_kernel<4,false,true,false,false,true>."""
+    _run(256, 64, 4000.0, 8192, False, n_sample=8, T=30, fam=KERNEL_WIDE)
+
+
+def test_c5_benchmarked_instantiation_full_size():
+    """configs[4]: 128 UE / 64 res, mobility_vary, B = 16384 - step_wide_kernel<2,...>; one update_velocity."""
+    _run(128, 64, 4000.0, 16384, True, n_sample=10, T=32, fam=KERNEL_WIDE, vel_slot=24)

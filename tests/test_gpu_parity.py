@@ -115,13 +115,13 @@ def test_golden_replay_on_gpu(name):
     env.check()
 
 
-def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8, track_prr=True,
-                   expect_kernel=None):
+def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8, track_prr=False,
+                   expect_kernel=None, force_general=False):
     """GPU vs oracle (IEEE squares) on B different random envs, T slots; returns
     the number of compared slots.  Everything must match bit for bit (exp()
-    rewards within EXP_ATOL).  track_prr (PRR metrics also in my_step, a build extension)
-    keeps the run on the general kernel; without it the specialised kernels serve every
-    configuration they can (`expect_kernel`: assert which family ran)."""
+    rewards within EXP_ATOL).  The specialised kernels serve every configuration they can
+    (`expect_kernel`: assert which family ran); `force_general` pins the run to the general
+    kernel (DIRAL_OPT_KERNEL_PATH); track_prr: PRR metrics also in my_step (a build extension)."""
     from oracle.oracle import Oracle, SQ_IEEE
     rng = np.random.default_rng(seed)
     N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
@@ -130,6 +130,7 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
     y0 = np.zeros((B, N))
     v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
     env = make_env(cfg, B)
+    env.force_general_kernel(force_general)
     env.reset_topology(x0, y0, v0)
     orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=threads)
     orc.reset(x0, y0, v0)
@@ -181,8 +182,21 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
     return T
 
 
+def _fam(N):
+    from diral_amd.config import KERNEL_FAST64, KERNEL_WIDE
+    return KERNEL_FAST64 if N <= 64 else KERNEL_WIDE
+
+
 def test_c2_random_vs_oracle():
-    random_rollout(c2_config(), B=96, T=70, seed=1)
+    """The headline configuration on the kernel the bench runs (step_fast64, RICH: the rollout asks for
+    the channel observation too), PRR metrics tracked in my_step as well."""
+    random_rollout(c2_config(), B=96, T=70, seed=1, expect_kernel=_fam(64))
+    random_rollout(c2_config(), B=32, T=40, seed=21, track_prr=True, expect_kernel=_fam(64))
+
+
+def test_c2_random_vs_oracle_general_kernel():
+    from diral_amd.config import KERNEL_GENERAL
+    random_rollout(c2_config(), B=48, T=50, seed=1, track_prr=True, force_general=True, expect_kernel=KERNEL_GENERAL)
 
 
 def test_c2_ch_mode_vs_oracle():
@@ -201,11 +215,23 @@ def test_c2_channel_obs_and_flags_vs_oracle():
 
 
 def test_c3_congested_vs_oracle():
-    random_rollout(bench_config(256, 64, 4000.0), B=6, T=26, seed=5)
+    random_rollout(bench_config(256, 64, 4000.0), B=6, T=26, seed=5, expect_kernel=_fam(256))
+    random_rollout(bench_config(256, 64, 4000.0), B=4, T=26, seed=25, track_prr=True, expect_kernel=_fam(256))
 
 
 def test_c5_dynamic_density_vs_oracle():
-    random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True), B=10, T=55, seed=6, vel_every=25)
+    random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True), B=10, T=55, seed=6, vel_every=25,
+                   expect_kernel=_fam(128))
+    random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True), B=6, T=30, seed=26, vel_every=25, track_prr=True,
+                   expect_kernel=_fam(128))
+
+
+def test_c3_c5_vs_oracle_general_kernel():
+    from diral_amd.config import KERNEL_GENERAL
+    random_rollout(bench_config(256, 64, 4000.0), B=4, T=20, seed=5, track_prr=True, force_general=True,
+                   expect_kernel=KERNEL_GENERAL)
+    random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True), B=6, T=30, seed=6, vel_every=25, track_prr=True,
+                   force_general=True, expect_kernel=KERNEL_GENERAL)
 
 
 @pytest.mark.parametrize("N,A,L", [(1, 1, 50.0), (2, 5, 100.0), (63, 7, 900.0), (65, 3, 900.0),
@@ -1182,6 +1208,8 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
                                (dict(action_index="real", add_channel_obs=True), {}, fam | KERNEL_RICH),
                                (dict(add_action=False), {}, fam | KERNEL_RICH),
                                (flags, dict(track_arrival=True), fam | KERNEL_RICH | KERNEL_EXTRA),
+                               # PRR metrics in my_step (DIRAL_F_TRACK_PRR): a run-time switch of the EXTRA instantiations
+                               ({}, dict(track_prr=True), fam | KERNEL_EXTRA),
                                # the secondary observation modes: the step on a RICH instantiation, their
                                # columns from posdist_kernel right after it
                                (dict(add_positional_dist=True), {}, fam | KERNEL_RICH),
@@ -1193,48 +1221,13 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         assert (e2.last_kernel() & ~KERNEL_RING) == want, (state, extra, e2.last_kernel())
         e2.check()
     # what stays on the general kernel
-    for state, extra in (({}, dict(track_prr=True)), (dict(add_positional_dist_piggy=False), {}),
+    for state, extra in ((dict(add_positional_dist_piggy=False), {}),
                          (dict(add_positional_dist=True, add_positional_dist_piggy=False), {})):
         c3 = bench_config(N, A, L, State=state, **extra)
         e3 = make_env(c3, 4, dtype=torch.float64)
         e3.reset_topology(seed=5)
         e3.step(e3.sample(seed=2), 0)
         assert e3.last_kernel() == KERNEL_GENERAL, (state, extra)
-
-
-@pytest.mark.parametrize("N,A,B", [(64, 32, 2048), (256, 64, 1024), (128, 64, 2048)])
-def test_specialised_kernels_are_faster_than_the_general_kernel(N, A, B):
-    """The point of the dispatch: plain `step` and the reference call pattern (my_step with the
-    channel observation + obtain_state) both run well ahead of the general kernel."""
-    import time
-    cfg = bench_config(N, A, 2000.0 if N <= 64 else 4000.0)
-
-    def run(force_general, two_call):
-        env = make_env(cfg, B, dtype=torch.float32)
-        env.reset_topology(seed=3)
-        env.force_general_kernel(force_general)
-        acts = [env.sample(seed=i) for i in range(4)]
-
-        def slot(t):
-            if two_call:
-                chobs, rew = env.my_step(acts[t % 4], t)
-                env.obtain_state(chobs, acts[t % 4], rew)
-            else:
-                env.step(acts[t % 4], t)
-        for t in range(40):
-            slot(t)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(40, 140):
-            slot(t)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
-
-    fast, general = min(run(False, False), run(False, False)), min(run(True, False), run(True, False))
-    assert general > 1.4 * fast, (fast, general)
-    fast2, general2 = min(run(False, True), run(False, True)), min(run(True, True), run(True, True))
-    assert general2 > 1.4 * fast2, (fast2, general2)
-    assert fast2 < 1.35 * fast, (fast, fast2)       # the channel-observation output costs little
 
 
 @pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 9, 1500.0), (64, 16, 9000.0)])
@@ -1361,3 +1354,127 @@ def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
                        State=dict(num_bins=K, **state))
     random_rollout(cfg, B=5 if N <= 128 else 3, T=40, seed=700 + N + K, sticky=0.5, vel_every=9, track_prr=False,
                    expect_kernel=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE)
+
+
+@pytest.mark.parametrize("N,A,L,Rc", [(128, 64, 4000.0, 250.0), (256, 64, 4000.0, 250.0), (200, 24, 30000.0, 140.0),
+                                      (96, 12, 20000.0, 120.0)])
+def test_wide_xpos_ring_agrees_with_the_oracle_through_every_consumer(N, A, L, Rc):
+    """The N > 64 kernels keep the xpos of young entries in the per-subject ring as well (csrc/step_wide.hpp);
+    there is no plane-only build of them to compare with, so the comparator is the oracle: a rollout with
+    general-kernel steps, stand-alone obtain_state calls with foreign arguments (diral_env_observe), export /
+    import round trips and velocity updates mixed in must match it slot by slot (state, reward, channel
+    observation) and plane by plane at every export.  The last two topologies are sparse enough for entries
+    beyond the ring (byte-rank / 32-bit passes, plane hand-over at lag 7)."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    from diral_amd.config import KERNEL_GENERAL, KERNEL_RING, KERNEL_WIDE
+    cfg = bench_config(N, A, L, mobility_vary=True, communication_range=Rc)
+    B = 4
+    rng = np.random.default_rng(N * 7 + A)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    v0 = np.full((B, N), 1.7)
+    env = make_env(cfg, B)
+    env.reset_topology(x0, 0.0, v0)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    orc.reset(x0, np.zeros((B, N)), v0)
+
+    def same_tables(t):
+        st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        oe = orc.export()
+        for k in ("seq", "x", "pos_x", "vel"):
+            assert np.array_equal(st[k], oe[k]), (k, t)
+        assert np.array_equal(st["age"], np.minimum(oe["age"], 255)), t
+
+    max_lag = 0
+    for t in range(75):
+        acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        general = t in (13, 14, 37) or 55 <= t < 58                  # the general kernel takes over for some slots
+        env.force_general_kernel(general)
+        obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, acts, t)
+        assert (env.last_kernel() & (15 | KERNEL_RING)) == (KERNEL_GENERAL if general else KERNEL_WIDE | KERNEL_RING)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, t)
+        o_state = orc.obtain_state(acts, o_chobs, o_rew)
+        assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
+        assert np.array_equal(rew, o_rew) and np.array_equal(chobs, o_chobs), t
+        if t % 7 == 3:
+            same_tables(t)                                           # export: the plane completed from the ring
+        if t % 9 == 5:                                               # foreign arguments: a diral_env_observe launch
+            other = rng.integers(0, A, size=(B, N)).astype(np.int32)
+            fake = np.full((B, N), 0.25)
+            s1 = env.obtain_state(None, other, fake).cpu().numpy()
+            s2 = orc.obtain_state(other, np.zeros((B, N, A)), fake)
+            assert np.array_equal(s1, s2), t
+        if t in (26, 60):                                            # checkpoint round trip through import_state
+            st = env.export_state()
+            lag = torch.diagonal(st["seq"], dim1=1, dim2=2).unsqueeze(1) - st["seq"]
+            max_lag = max(max_lag, int(lag[st["seq"] > 0].max().item()))
+            env.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"], x=st["x"])
+        if t % 25 == 24:
+            draws = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
+            env.update_velocity(draws)
+            orc.update_velocity(draws)
+    same_tables(75)
+    if Rc < 200:
+        assert max_lag > 7, max_lag                                  # the sparse topologies do leave the ring
+    env.check()
+
+
+def test_import_of_conflicting_tables_is_reported():
+    """diral_env_import_state / import_entries accept any tables; the ring-based kernels need entries about one
+    subject with equal sequence numbers to carry equal xpos (no run of the reference violates it).  A violation is
+    detected at import and surfaces in diral_env_check as DIRAL_ERR_TABLE_CONFLICT."""
+    from diral_amd.config import ERR_TABLE_CONFLICT
+    from diral_amd.vec_env import DiralError
+    for N, A in ((64, 32), (128, 64)):
+        cfg = bench_config(N, A, 3000.0)
+        env = make_env(cfg, 3)
+        env.reset_topology(seed=9)
+        for t in range(12):
+            env.step(env.sample(seed=t), t)
+        st = env.export_state()
+        env.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"], x=st["x"])
+        env.check()                                                  # a reachable state imports cleanly
+        seq, x = st["seq"].clone(), st["x"].clone()
+        # two viewers of env 1 hold subject 5 at the SAME sequence number ...
+        own = int(seq[1, 5, 5].item())
+        seq[1, 2, 5] = own - 1
+        seq[1, 3, 5] = own - 1
+        x[1, 2, 5] = 111.0
+        x[1, 3, 5] = 222.0                                           # ... with different xpos
+        env.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=seq, age=st["age"], x=x)
+        with pytest.raises(DiralError) as ei:
+            env.check()
+        assert ei.value.status == ERR_TABLE_CONFLICT
+        env.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"], x=st["x"])
+        env.check()
+
+
+def test_kernel_path_switch_inside_a_graph_capture_is_an_error():
+    """A ring <-> plane conversion is a launch that depends on host-side validity flags; recorded into a hipGraph it
+    would replay against tables it no longer describes.  The call fails with DIRAL_ERR_CAPTURE instead (and the
+    capture of plain steps keeps working: test_step_is_capturable_in_a_hip_graph)."""
+    from diral_amd.config import ERR_CAPTURE
+    from diral_amd.vec_env import DiralError
+    cfg = c2_config()
+    env = make_env(cfg, 4, dtype=torch.float32)
+    env.reset_topology(seed=2)
+    acts = env.sample(seed=1)
+    for t in range(3):
+        env.step(acts, t)                                            # ring steps: the plane is now incomplete
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    env.force_general_kernel(True)                                   # the next step needs the plane materialised
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        try:
+            keep = acts + 0                                          # (the captured graph is not empty)
+            with pytest.raises(DiralError) as ei:
+                env.step(acts, 3)
+            assert ei.value.status == ERR_CAPTURE
+        finally:
+            g.capture_end()
+    torch.cuda.synchronize()
+    env.force_general_kernel(False)
+    env.step(acts, 3)                                                # nothing was launched or recorded: the env goes on
+    env.check()
