@@ -55,3 +55,19 @@ for f in find("*counter_collection.csv"):
         tail = [x[1] for x in v[-LAST:]]
         print("%-24s mean=%.6g  n=%d of %d  (%s; %s)" % (cn, sum(tail) / len(tail), len(tail), len(v),
                                                         os.path.basename(os.path.dirname(f)), kn))
+
+# kernel duration INSIDE each PMC pass (every pass also carries --kernel-trace): the clock and busy
+# fractions derived from a counter use the duration of the launches that counter was read on
+print("\n== step-kernel duration inside each PMC pass (mean over the same last %d dispatches) ==" % LAST)
+for f in find("*kernel_trace.csv"):
+    if os.sep + "trace" + os.sep in f:
+        continue
+    durs = []
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "step_" in row.get("Kernel_Name", ""):
+                durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    if durs:
+        durs.sort()
+        tail = [x[1] for x in durs[-LAST:]]
+        print("PASS_NS %-12s mean=%.6g  n=%d of %d" % (os.path.basename(os.path.dirname(f)), sum(tail) / len(tail), len(tail), len(durs)))
