@@ -50,6 +50,7 @@ PATH_GENERAL = 1
 KERNEL_GENERAL = 0
 KERNEL_FAST64 = 1
 KERNEL_WIDE = 2
+KERNEL_OBSERVE = 3
 KERNEL_RICH = 16
 KERNEL_EXTRA = 32
 KERNEL_CH = 64

@@ -13,6 +13,7 @@
 #include "aux_kernels.hpp"
 #include "common.hpp"
 #include "launch.hpp"
+#include "observe_kernel.hpp"
 #include "step_kernel.hpp"
 #include "step_fast64.hpp"
 #include "step_wide.hpp"
@@ -141,11 +142,12 @@ constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | 
 // fairness.  The type-2 piggybacked histogram is part of the kernels; the secondary observation modes
 // (a15/a16: sorted true distances, type-1 weighted histogram) are columns posdist_kernel fills right
 // after the step, so the step itself runs here all the same (RICH instantiation, histogram columns off
-// unless type 2).  Without State.add_positional_dist_piggy the reference keeps no tables (test_env.py:
-// 138, 231-238): that step, PRR tracking in my_step and static topologies stay on the general kernel.
+// unless type 2).  A State block without piggybacked tables (test_env.py:138, 231-238: no gossip at all), PRR
+// tracking in my_step and static topologies are run-time switches of the EXTRA instantiations.  What is left
+// for the general kernel: A > 64, and vehicles off the common lane at N > 64 (nothing the reference draws).
 bool is_specialised_cfg(const StepParams& p) {
-  const uint32_t want = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY;
-  const uint32_t ignore = DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
+  const uint32_t want = 0u;
+  const uint32_t ignore = DIRAL_F_MOBILITY | DIRAL_F_ADD_POSDIST_PIGGY | DIRAL_F_TOY_WEIGHTS | DIRAL_F_MOBILITY_VARY | DIRAL_F_DESIGN_TOPOLOGY | DIRAL_F_TRACK_ARRIVAL |
                           DIRAL_F_TRACK_PRR | DIRAL_F_ADD_ACTION | DIRAL_F_PROPORTIONAL_FAIR | DIRAL_F_ADD_POSDIST | kRichFlags;
   return (p.flags & ~ignore) == want &&
          (p.mode == DIRAL_STEP_MY_STEP || p.mode == DIRAL_STEP_MY_STEP_CH || p.mode == DIRAL_STEP_DESIGN);
@@ -210,6 +212,44 @@ hipError_t ensure_ring(DiralEnv* e, hipStream_t s) {
   return hipGetLastError();
 }
 
+// The RICH output-tail description of one call: section layout of the state vector, and which of its columns
+// belong to the observation launch that follows (posdist_kernel.hpp) and are left alone here.
+RichParams rich_for(const DiralEnv* e, const StepParams& p) {
+  RichParams r = e->rich;
+  r.chobs_out = nullptr; r.episode = p.episode; r.eps = p.eps;
+  r.plain_state = ((p.flags & (kRichFlags | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
+  if (!has_hist2(p)) r.off_hist = -1;                         // (type 1: posdist_kernel writes those columns)
+  // the sorted-distance columns and the type-1 histogram are posdist_kernel.hpp's, every one of them (and
+  // neighbours in the state vector, state_offsets): not written here at all
+  const bool skip_full = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
+  const bool skip_t1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1 && p.state_out && p.off_hist >= 0;
+  r.off_skip = skip_full ? p.off_posdist : (skip_t1 ? p.off_hist : 0);
+  r.len_skip = (skip_full ? p.N - 1 : 0) + (skip_t1 ? p.K : 0);
+  r.pf = nullptr;
+  return r;
+}
+
+// TestEnv.obtain_state as its own launch (observe_kernel.hpp): reads the tables as they are - young entries'
+// xpos from the ring when it is valid, so no plane materialisation is needed - and changes nothing
+hipError_t launch_observe_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
+  const bool use_ring = e->ring != nullptr && e->ring_valid;
+  if (!use_ring) {
+    const hipError_t st = ensure_plane(e, s);
+    if (st != hipSuccess) return st;
+  }
+  ObserveParams o;
+  o.N = p.N; o.A = p.A; o.K = p.K; o.NV = p.NV; o.NR = p.NR; o.flags = p.flags; o.age_limit = p.age_limit;
+  o.want_hist = (has_hist2(p) && p.off_hist >= 0) ? 1 : 0;
+  o.L = p.L; o.Rb = p.Rb; o.inv_w = p.hist_inv_width;
+  o.actions = p.actions; o.chobs_in = p.chobs_in; o.rew_in = p.rew_in;
+  o.pos_x = p.pos_x; o.pos_y = p.pos_y; o.vel = p.vel; o.tkey = p.tkey; o.tx = p.tx;
+  o.ring = use_ring ? e->ring : nullptr;
+  o.edges = p.edges; o.err = p.err; o.state_out = p.state_out;
+  const RichParams r = rich_for(e, p);
+  e->last_kernel = DIRAL_KERNEL_OBSERVE | (use_ring ? DIRAL_KERNEL_RING : 0);
+  return launch_observe(o, r, e->flat_y, p.out_f64 != 0, p.B, s);
+}
+
 // after an import: the ring must answer every young entry with that entry's own xpos (aux_kernels.hpp)
 hipError_t verify_ring(DiralEnv* e, hipStream_t s) {
   const size_t total = (size_t)e->B * e->N * e->N;
@@ -245,6 +285,9 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
     f.done_now = ((p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226
     f.prr = ((p.flags & DIRAL_F_TRACK_PRR) && p.mode == DIRAL_STEP_MY_STEP) ? 1 : 0;
+    f.notab = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) ? 0 : 1;     // no piggybacked tables: test_env.py:138-139, 231-238
+    f.nomove = (p.flags & DIRAL_F_MOBILITY) ? 0 : 1;             // static (design) topology: network.py:302-305
+    f.trace = f.nomove ? nullptr : p.trace;
     f.chobs_mode = (p.chobs_out ? 1 : 0) | ((p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ? 2 : 0);
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
@@ -252,24 +295,16 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.ring = use_ring ? e->ring : nullptr;
     if (use_ring) e->plane_valid = false;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
-    f.trace = p.trace; f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
+    f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
-    RichParams r = e->rich;
-    r.chobs_out = p.chobs_out; r.episode = p.episode; r.eps = p.eps;
-    r.plain_state = ((p.flags & (kRichFlags | DIRAL_F_ADD_POSDIST)) == 0 && has_hist2(p) && (p.flags & DIRAL_F_ADD_ACTION)) ? 1 : 0;
-    if (!has_hist2(p)) r.off_hist = -1;                         // (type 1: posdist_kernel writes those columns)
-    // the sorted-distance columns and the type-1 histogram are posdist_kernel.hpp's, every one of them (and
-    // neighbours in the state vector, state_offsets): not written here at all
-    const bool skip_full = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
-    const bool skip_t1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1 && p.state_out && p.off_hist >= 0;
-    r.off_skip = skip_full ? p.off_posdist : (skip_t1 ? p.off_hist : 0);
-    r.len_skip = (skip_full ? p.N - 1 : 0) + (skip_t1 ? p.K : 0);
+    RichParams r = rich_for(e, p);
+    r.chobs_out = p.chobs_out;
     r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
-    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr || f.prr != 0;   // EXTRA instantiation: the run-time switches compiled in
+    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr || f.prr != 0 || f.notab != 0 || f.nomove != 0;   // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
@@ -624,7 +659,8 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   p.actions = actions; p.state_out = state_out;
   p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
   p.chobs_in = chobs_in; p.rew_in = rew_in;
-  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
+  if (e->kernel_path == DIRAL_PATH_GENERAL) HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));   // (tests: the general kernel's observe mode)
+  else HIP_TRY(e, launch_observe_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
 }

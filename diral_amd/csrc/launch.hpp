@@ -12,6 +12,7 @@
 namespace diral {
 
 struct FastParams;   // step_fast64.hpp
+struct ObserveParams;   // observe_kernel.hpp
 
 // which instantiation of a specialised kernel to launch
 struct KernelSel {
@@ -28,6 +29,7 @@ hipError_t launch_wide2(const FastParams& f, const RichParams& r, const KernelSe
 hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t set_attr_wide2(int A, int K);
 hipError_t set_attr_wide4(int A, int K);
+hipError_t launch_observe(const ObserveParams& p, const RichParams& r, bool flat, bool out64, int B, hipStream_t s);
 hipError_t launch_general(int vpl, bool fast, const StepParams& p, uint32_t lds, hipStream_t s);
 hipError_t set_attr_general(int vpl, uint32_t lds);
 

@@ -1,0 +1,157 @@
+// observe_kernel.hpp - TestEnv.obtain_state (test_env.py:527-583) as a launch of its own, any
+// configuration this build accepts (N <= 256, any State flags).
+//
+// The step kernels build the state vector of the slot they just advanced (`step()`, and the
+// speculative state of `my_step*`).  A stand-alone obtain_state - called with actions, channel
+// observation or rewards other than what the step returned (diral_env_observe) - changes nothing
+// in the env: it reads the tables and positions as they are and writes [B][N][S].  Until round 3
+// that call ran the general step kernel in an observe-only mode (C2: ~230 us); this kernel does
+// just the finalize + output work:
+//   * one workgroup per env, wave w sweeps the subject rows k = w, w + 4, ... of the subject-major
+//     table: a row is "what every viewer knows about k", lane = viewer (+ 64 j), one coalesced
+//     4-byte load per lane;
+//   * the xpos of an entry that lags its subject by at most 7 stamps comes from the subject's
+//     ring row (one 64-byte line per row), older ones from the per-entry plane - the
+//     plane does not have to be materialised first;
+//   * Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) per entry,
+//     histogram rows in LDS, then the generic state writer of rich_out.hpp with the caller's
+//     `obs` / `rewards` arrays as the channel-observation and reward sections.
+// The secondary observation columns (sorted true distances, type-1 histogram) stay with
+// posdist_kernel.hpp, which diral_env_observe launches right after this one, as after a step.
+#pragma once
+#include "common.hpp"
+#include "rich_out.hpp"
+#include "step_fast64.hpp"
+#include "step_kernel.hpp"
+
+namespace diral {
+
+struct ObserveParams {
+  int N, A, K, NV, NR;
+  uint32_t flags;
+  int age_limit;
+  int want_hist;                 // the state carries the type-2 piggybacked histogram
+  double L, Rb, inv_w;
+  const int32_t* actions;        // [B][N] the `acts` argument
+  const double* chobs_in;        // [B][N][A] the `obs` argument (f64) or null: zeros
+  const double* rew_in;          // [B][N] the `rewards` argument (f64) or null: zeros
+  const double* pos_x;
+  const double* pos_y;
+  const double* vel;
+  const uint32_t* tkey;
+  const double* tx;
+  const double* ring;            // [B][NR][8] or null: every xpos from the plane
+  const double* edges;
+  uint32_t* err;
+  void* state_out;
+};
+
+struct ObserveLds {
+  uint32_t px, py, edges, act, cnt, hist, total;
+};
+__host__ __device__ inline ObserveLds observe_lds_layout(int N, int K) {
+  const uint32_t npad = (uint32_t)align_up((uint32_t)N, 64);
+  ObserveLds l;
+  uint32_t o = 0;
+  l.px = o;    o += 8u * npad;
+  l.py = o;    o += 8u * npad;
+  l.edges = o; o += 8u * (K + 2);
+  l.act = o;   o += 4u * npad;
+  l.cnt = o;   o += 4u * npad;
+  l.hist = o;  o += 4u * (uint32_t)(K | 1) * npad;   // [viewer][K | 1]: odd row stride
+  l.total = align_up(o, 16);
+  return l;
+}
+
+constexpr int kObserveThreads = 256;
+
+template <bool FLAT, bool OUT64>
+__global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveParams p, const RichParams r) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const ObserveLds lay = observe_lds_layout(p.N, p.K);
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);
+  double* s_py = reinterpret_cast<double*>(smem + lay.py);
+  double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
+  int* s_act = reinterpret_cast<int*>(smem + lay.act);
+  unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
+  unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, A = p.A, K = p.K, NV = p.NV;
+  const int KP = K | 1;
+  const size_t bN = (size_t)b * N, bR = (size_t)b * p.NR;
+
+  for (int u = tid; u < N; u += kObserveThreads) {
+    int a = p.actions[bN + u];
+    if (a < 0 || a >= A) { atomicOr(p.err, kErrAction); a = -1; }
+    s_act[u] = a;
+    s_px[u] = p.pos_x[bN + u];
+    s_py[u] = FLAT ? 0.0 : p.pos_y[bN + u];
+    s_cnt[u] = 0u;
+  }
+  if (p.want_hist) {
+    for (int j = tid; j < KP * N; j += kObserveThreads) s_hist[j] = 0u;
+    if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+  }
+  __syncthreads();
+
+  if (p.want_hist) {
+    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513): viewer u against its
+    // entry about k, own position as it is NOW (obtain_state runs after the move)
+    const double inv_w = p.inv_w;
+    for (int u0 = lane; u0 < N; u0 += 64) {
+      const int u = u0;
+      const double mx = s_px[u], my = s_py[u];
+      unsigned int mycnt = 0u;
+      unsigned int* const hrow = s_hist + u * KP;
+#pragma unroll 2
+      for (int k = wave; k < N; k += kObserveThreads / 64) {
+        const size_t row = bR + k;
+        const unsigned int wn = p.tkey[row * NV + u];
+        const unsigned int tk_own = p.tkey[row * NV + k] >> 8;       // wave-uniform: a scalar load
+        const unsigned int seq = wn >> 8;
+        double xg;
+        if (p.ring && tk_own - seq <= 7u) xg = p.ring[row * 8 + (seq & 7u)];
+        else xg = p.tx[row * NV + u];
+        double d, v;
+        if constexpr (FLAT) {
+          v = xg - mx;                                                // all y == 0: x1 - x2 IS d * sign, d = |v|
+          const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+          d = __hiloint2double((int)vh, __double2loint(v));
+          if (vh < 0x20b00000u) {                                     // |v| below 2^-500 (its square underflows) or 0
+            d = dist_general(mx - xg, 0.0);
+            v = (xg - mx > 0.0) ? d : -d;
+          }
+        } else {
+          d = fast_dist<false>(xg, seq ? s_py[k] : 0.0, mx, my);      // ypos: the subject's lane once heard
+          v = (xg - mx > 0.0) ? d : -d;
+        }
+        if (u != k && (int)(wn & 255u) < p.age_limit && d < p.Rb) {
+          int est = (int)((v + p.Rb) * inv_w);
+          est = est > K - 1 ? K - 1 : est;
+          const double e0 = s_edges[est], e1 = s_edges[est + 1];
+          const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+          atomicAdd(&hrow[bin], 1u);
+          mycnt += 1u;
+        }
+      }
+      if (mycnt) atomicAdd(&s_cnt[u], mycnt);
+    }
+    __syncthreads();
+  }
+
+  const double* const chobs_in = p.chobs_in;
+  const double* const rew_in = p.rew_in;
+  rich_write_state<OUT64>(
+      r, p.flags, N, A, K, p.L, p.state_out, bN, tid, kObserveThreads, [&](int u) { return s_act[u]; },
+      [&](int u, int i) { return chobs_in ? chobs_in[(bN + u) * A + i] : 0.0; },
+      [&](int u, int bin) {
+        const unsigned int n = s_cnt[u];
+        return n ? (double)s_hist[u * KP + bin] / (double)n : 0.0;     // network.py:501
+      },
+      [&](int u) { return rew_in ? rew_in[bN + u] : 0.0; }, [&](int u) { return s_px[u]; },
+      [&](int u) { return s_py[u]; }, [&](int u) { return r.vel[bN + u]; });
+}
+
+}  // namespace diral

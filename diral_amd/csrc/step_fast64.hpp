@@ -55,6 +55,11 @@ struct FastParams {
   int reward_design, age_limit, episode_interval;
   int design;                    // 1: my_step_design (test_env.py:269-349) - runtime switch of the non-CH instantiation
   int done_now;                  // t % episode_interval == episode_interval - 1 (main_test.py:226), evaluated on the host
+  int notab;                     // 1: State.add_positional_dist_piggy is off - the reference keeps no neighbour tables at all
+                                 // (test_env.py:138-139, 231-238: no periodic_update, no received_update): stamp, merge and
+                                 // histogram are skipped - EXTRA + RICH instantiations
+  int nomove;                    // 1: static topology (`mobility: False` with the design topology, network.py:54-60, 302-305):
+                                 // update_mobility does nothing - EXTRA instantiations
   int prr;                       // 1: my_step also accumulates the PRR metric columns (DIRAL_F_TRACK_PRR, a build extension:
                                  // the reception ratio of test_env.py:384-405 per colliding transmitter) - EXTRA instantiations
   int chobs_mode;                // RICH: bit 0 = chobs_out is set; bit 1 = the channel observation is the distance to the
@@ -317,10 +322,15 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // scalar-base addressing form instead of 64-bit per-lane pointer arithmetic
   unsigned int* const tk = p.tkey + ((size_t)b * p.NR + wave * 16) * NV;
   double* const txp = p.tx + ((size_t)b * p.NR + wave * 16) * NV;
-  const bool has_cols = wave * 16 < p.NR;      // uniform: idle waves of a small env
+  // A State block without piggybacked tables (test_env.py:138-139, 231-238: no periodic_update, no received_update,
+  // no histogram) has no P3: every wave then behaves like the idle wave of a small env - no columns, no ring, no
+  // active resource in the merge loops (a branch around the whole phase trips the backend: "illegal VGPR to SGPR copy")
+  const bool notab = EXTRA && RICH && p.notab != 0;
+  const bool has_cols = wave * 16 < p.NR && !notab;      // uniform: idle waves of a small env
   // (unconditional: a branch around the loads would make the compiler wait for
   // ALL of them at the first use of the per-vehicle values - the waitcnt pass
   // merges both paths conservatively; idle waves of a small env re-read row 0)
+  // (a table-less step - `notab` below - never looks at the words: every env re-reads the first rows, L2 hits)
   const unsigned int* const tk_ld = has_cols ? tk : p.tkey + (size_t)b * p.NR * NV;
   unsigned int w1[16];
 #pragma unroll
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
     mynpx = p.trace[(base + (size_t)tt) * N + lane];
   }
+  if (EXTRA && p.nomove) mynpx = mypx;                                         // network.py:302-305: no mobility, no move
   if (wave == 0) {
     s_act[lane] = myact; s_cnt[lane] = 0u;
     if constexpr (RICH) {
@@ -558,12 +569,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // merged with v_pk_max_u16 - exact iff no entry of the wave has lag >= 1023 with seq != 0 (never-heard
   // entries, seq == 0, all share rank 0) - or, for imported / very stale tables, 32-bit keys.
   // resources with at least one transmitter, as a wave-uniform bit word: the merge visits only those
-  const unsigned long long actw = __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
+  const unsigned long long actw = notab ? 0ull : __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
   // the xpos rings of this wave's 16 subjects: lane l holds slot l & 7 of subject l >> 3 (ringv0) / 8 + (l >> 3)
   // (ringv1); loaded here, first needed after the codes are built
   const LateFastArgs lpr = (LateFastArgs)late_kernarg_base();
   double* const ring = lpr->ring;
-  const bool use_ring = ring != nullptr;       // uniform
+  const bool use_ring = ring != nullptr && !notab;       // uniform
   double* const ringp = ring + ((size_t)b * p.NR + (has_cols ? wave * 16 : 0)) * 8;
   double ringv0 = 0.0, ringv1 = 0.0;
   if (use_ring) { ringv0 = ringp[lane]; ringv1 = ringp[64 + lane]; }

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
       nx = p.trace[(base + (size_t)tt) * N + u];
     }
+    if (EXTRA && p.nomove) nx = x;                           // network.py:302-305: no mobility, no move
     s_npx[u] = nx;
     s_cnt[u] = 0u;
   }
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
     if (kbase >= p.NR) break;
+    if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
     // One packed pass, ONE body for both packed representations (two copies of it cost 12 more spilled
     // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
     // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are

@@ -189,6 +189,7 @@ enum {
   DIRAL_KERNEL_GENERAL = 0,   /* csrc/step_kernel.hpp  */
   DIRAL_KERNEL_FAST64  = 1,   /* csrc/step_fast64.hpp, N <= 64       */
   DIRAL_KERNEL_WIDE    = 2,   /* csrc/step_wide.hpp,  64 < N <= 256  */
+  DIRAL_KERNEL_OBSERVE = 3,   /* csrc/observe_kernel.hpp: diral_env_observe (stand-alone obtain_state) */
   DIRAL_KERNEL_RICH    = 16,  /* channel-obs output / cheap State flags (csrc/rich_out.hpp) */
   DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
   DIRAL_KERNEL_CH      = 64,  /* my_step_ch */

@@ -47,19 +47,21 @@ def test_random_configuration_vs_oracle(i):
         # design topology (network.py:54-60).  Anything else validate() raises is a regression.
         with pytest.raises(ConfigError, match="mobility"):
             cfg.validate()
-        pytest.skip("no-mobility configuration: the reference builds no vehicles (network.py:54-60)")
+        # ... with the design topology the same draw is a STATIC topology (network.py:302-305: update_mobility
+        # does nothing): a run-time switch of the specialised kernels' EXTRA instantiations
+        cfg = cfg.replace(enable_design_topology=True)
     cfg.validate()
     B = 4 if cfg.num_users > 64 else 12
-    # the general kernel (PRR tracking in my_step, a build extension, keeps the run there) ...
+    # the general kernel (DIRAL_OPT_KERNEL_PATH), PRR metrics tracked in my_step as well ...
     random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
-                   expect_kernel=KERNEL_GENERAL)
-    # ... and whatever the dispatch picks without it: step_fast64 / step_wide for every State block with
-    # piggybacked tables and A <= 64 (the secondary observation modes get their columns from posdist_kernel
-    # afterwards)
-    special = cfg.State.add_positional_dist_piggy and cfg.num_channels <= 64
+                   track_prr=True, force_general=True, expect_kernel=KERNEL_GENERAL)
+    # ... and whatever the dispatch picks: step_fast64 / step_wide for EVERY State block at A <= 64 on the one-lane
+    # highway - with or without piggybacked tables (no tables: the table-less step), mobile or static, PRR metrics
+    # or not (the secondary observation modes get their columns from posdist_kernel afterwards)
+    special = cfg.num_channels <= 64
     want = (KERNEL_FAST64 if cfg.num_users <= 64 else KERNEL_WIDE) if special else KERNEL_GENERAL
     random_rollout(cfg, B=B, T=26, seed=100 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
-                   track_prr=False, expect_kernel=want)
+                   track_prr=bool(i & 1), expect_kernel=want)
 
 
 def draw_fast_case(i):

@@ -152,6 +152,17 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
             assert exp_close(obs, o_state), t
         else:
             assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
+        if t % 6 == 4 and env.S > 0:
+            # a stand-alone obtain_state with FOREIGN arguments (test_env.py:527-583 on the current tables):
+            # diral_env_observe -> observe_kernel.hpp (the general kernel's observe mode when forced)
+            from diral_amd.config import KERNEL_GENERAL, KERNEL_OBSERVE
+            fa = rng.integers(0, A, size=(B, N)).astype(np.int32)
+            fc = rng.uniform(0.0, 300.0, size=(B, N, A))
+            fr = rng.uniform(-3.0, 1.0, size=(B, N))
+            s1 = env.obtain_state(fc, fa, fr, 3.0, 0.25).cpu().numpy()
+            assert (env.last_kernel() & 15) == (KERNEL_GENERAL if force_general else KERNEL_OBSERVE)
+            s2 = orc.obtain_state(fa, fc, fr, 3.0, 0.25)
+            assert np.array_equal(s1, s2), (t, np.argwhere(s1 != s2)[:5])
         if vel_every and t % vel_every == vel_every - 1:
             draws = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
             env.update_velocity(draws)
@@ -1220,14 +1231,32 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         e2.step(e2.sample(seed=2), 0)
         assert (e2.last_kernel() & ~KERNEL_RING) == want, (state, extra, e2.last_kernel())
         e2.check()
-    # what stays on the general kernel
+    # a State block without piggybacked tables (test_env.py:138-139, 231-238: the table-less step), a static
+    # topology (network.py:302-305) - run-time switches of the EXTRA instantiations - and a stand-alone
+    # obtain_state with foreign arguments (observe_kernel.hpp)
+    from diral_amd.config import KERNEL_OBSERVE
     for state, extra in ((dict(add_positional_dist_piggy=False), {}),
-                         (dict(add_positional_dist=True, add_positional_dist_piggy=False), {})):
+                         (dict(add_positional_dist=True, add_positional_dist_piggy=False), {}),
+                         ({}, dict(mobility=False, enable_design_topology=True))):
         c3 = bench_config(N, A, L, State=state, **extra)
         e3 = make_env(c3, 4, dtype=torch.float64)
         e3.reset_topology(seed=5)
-        e3.step(e3.sample(seed=2), 0)
-        assert e3.last_kernel() == KERNEL_GENERAL, (state, extra)
+        a3 = e3.sample(seed=2)
+        e3.step(a3, 0)
+        assert (e3.last_kernel() & ~KERNEL_RING) == fam | KERNEL_RICH | KERNEL_EXTRA, (state, extra, e3.last_kernel())
+        e3.obtain_state(None, e3.sample(seed=3), None)
+        assert (e3.last_kernel() & 15) == KERNEL_OBSERVE, (state, extra, e3.last_kernel())
+        e3.check()
+    # what is left for the general kernel: more than 64 resources, vehicles off the common lane at N > 64
+    e4 = make_env(bench_config(N, 65, L), 4, dtype=torch.float64)
+    e4.reset_topology(seed=5)
+    e4.step(e4.sample(seed=2), 0)
+    assert e4.last_kernel() == KERNEL_GENERAL
+    if N > 64:
+        e5 = make_env(bench_config(N, A, L), 4, dtype=torch.float64)
+        e5.reset_topology(np.arange(N, dtype=np.float64), np.ones(N), np.full(N, 1.5))
+        e5.step(e5.sample(seed=2), 0)
+        assert e5.last_kernel() == KERNEL_GENERAL
 
 
 @pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 9, 1500.0), (64, 16, 9000.0)])
@@ -1478,3 +1507,38 @@ def test_kernel_path_switch_inside_a_graph_capture_is_an_error():
     env.force_general_kernel(False)
     env.step(acts, 3)                                                # nothing was launched or recorded: the env goes on
     env.check()
+
+
+@pytest.mark.parametrize("N,A,y", [(64, 32, False), (40, 7, True), (128, 64, False), (256, 16, False), (200, 33, True)])
+def test_observe_kernel_f32_is_the_cast_of_f64_and_leaves_the_env_alone(N, A, y):
+    """diral_env_observe (observe_kernel.hpp): float32 output == float32(float64 output); the call changes nothing
+    in the env (tables, positions, metrics); vehicles off the common lane take the non-FLAT instantiation."""
+    from diral_amd.config import KERNEL_OBSERVE
+    cfg = bench_config(N, A, 25.0 * N + 100, State=dict(add_channel_obs=True, add_reward=True, add_position=True,
+                                                        add_velocity=True, add_index=True), enable_fingerprint=True)
+    rng = np.random.default_rng(N + A)
+    B = 5
+    x0 = rng.integers(0, int(cfg.highway_length), size=(B, N)).astype(np.float64)
+    y0 = rng.integers(0, 2, size=(B, N)).astype(np.float64) if y else np.zeros((B, N))
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    e64, e32 = make_env(cfg, B, dtype=torch.float64), make_env(cfg, B, dtype=torch.float32)
+    for e in (e64, e32):
+        e.reset_topology(x0, y0, v0)
+    for t in range(14):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        e64.step(a, t)
+        e32.step(a, t)
+    before = {k: v.clone() for k, v in e64.export_state().items()}
+    m0 = e64.metrics().clone()
+    fa = rng.integers(0, A, size=(B, N)).astype(np.int32)
+    fc = rng.uniform(0.0, 300.0, size=(B, N, A))
+    fr = rng.uniform(-3.0, 1.0, size=(B, N))
+    s64 = e64.obtain_state(fc, fa, fr, 7.0, 0.5).clone()
+    s32 = e32.obtain_state(fc, fa, fr, 7.0, 0.5).clone()
+    assert (e64.last_kernel() & 15) == KERNEL_OBSERVE and (e32.last_kernel() & 15) == KERNEL_OBSERVE
+    assert torch.equal(s64.to(torch.float32), s32)
+    after = e64.export_state()
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    assert torch.equal(m0, e64.metrics())
+    e64.check(); e32.check()
