@@ -244,7 +244,7 @@ hipError_t launch_observe_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   o.actions = p.actions; o.chobs_in = p.chobs_in; o.rew_in = p.rew_in;
   o.pos_x = p.pos_x; o.pos_y = p.pos_y; o.vel = p.vel; o.tkey = p.tkey; o.tx = p.tx;
   o.ring = use_ring ? e->ring : nullptr;
-  o.edges = p.edges; o.err = p.err; o.state_out = p.state_out;
+  o.edges = p.edges; o.inv_tab = e->inv_tab; o.err = p.err; o.state_out = p.state_out;
   const RichParams r = rich_for(e, p);
   e->last_kernel = DIRAL_KERNEL_OBSERVE | (use_ring ? DIRAL_KERNEL_RING : 0);
   return launch_observe(o, r, e->flat_y, p.out_f64 != 0, p.B, s);

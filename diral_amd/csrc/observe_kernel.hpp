@@ -11,8 +11,9 @@
 //     table: a row is "what every viewer knows about k", lane = viewer (+ 64 j), one coalesced
 //     4-byte load per lane;
 //   * the xpos of an entry that lags its subject by at most 7 stamps comes from the subject's
-//     ring row (one 64-byte line per row), older ones from the per-entry plane - the
-//     plane does not have to be materialised first;
+//     ring row (the env's rows and the subjects' own sequence numbers are staged in LDS
+//     first, so the sweep has one global load per entry, eight rows in flight per lane), older ones
+//     from the per-entry plane - the plane does not have to be materialised first;
 //   * Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) per entry,
 //     histogram rows in LDS, then the generic state writer of rich_out.hpp with the caller's
 //     `obs` / `rewards` arrays as the channel-observation and reward sections.
@@ -42,12 +43,13 @@ struct ObserveParams {
   const double* tx;
   const double* ring;            // [B][NR][8] or null: every xpos from the plane
   const double* edges;
+  const double* inv_tab;         // [256] 1.0 / n (0 for n = 0), as in step_fast64.hpp
   uint32_t* err;
   void* state_out;
 };
 
 struct ObserveLds {
-  uint32_t px, py, edges, act, cnt, hist, total;
+  uint32_t px, py, edges, ring, act, cnt, tk, hist, total;
 };
 __host__ __device__ inline ObserveLds observe_lds_layout(int N, int K) {
   const uint32_t npad = (uint32_t)align_up((uint32_t)N, 64);
@@ -56,8 +58,10 @@ __host__ __device__ inline ObserveLds observe_lds_layout(int N, int K) {
   l.px = o;    o += 8u * npad;
   l.py = o;    o += 8u * npad;
   l.edges = o; o += 8u * (K + 2);
+  l.ring = o;  o += 8u * 8u * npad;                  // the env's ring rows [subject][8]
   l.act = o;   o += 4u * npad;
   l.cnt = o;   o += 4u * npad;
+  l.tk = o;    o += 4u * npad;                       // the subjects' own sequence numbers
   l.hist = o;  o += 4u * (uint32_t)(K | 1) * npad;   // [viewer][K | 1]: odd row stride
   l.total = align_up(o, 16);
   return l;
@@ -72,6 +76,8 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
   double* s_px = reinterpret_cast<double*>(smem + lay.px);
   double* s_py = reinterpret_cast<double*>(smem + lay.py);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
+  double* s_ring = reinterpret_cast<double*>(smem + lay.ring);
+  unsigned int* s_tk = reinterpret_cast<unsigned int*>(smem + lay.tk);
   int* s_act = reinterpret_cast<int*>(smem + lay.act);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
@@ -90,9 +96,16 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
     s_py[u] = FLAT ? 0.0 : p.pos_y[bN + u];
     s_cnt[u] = 0u;
   }
+  const bool use_ring = p.ring != nullptr;
   if (p.want_hist) {
     for (int j = tid; j < KP * N; j += kObserveThreads) s_hist[j] = 0u;
     if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+    // the env's ring rows (coalesced) and the subjects' own sequence numbers (the table's diagonal) into LDS:
+    // the sweep below then has ONE global load per entry - the table word - and nothing that depends on it
+    // except LDS reads (the xpos of the rare entry older than the ring reaches comes from the plane)
+    if (use_ring)
+      for (int j = tid; j < 8 * N; j += kObserveThreads) s_ring[j] = p.ring[bR * 8 + j];
+    for (int k = tid; k < N; k += kObserveThreads) s_tk[k] = p.tkey[(bR + k) * NV + k] >> 8;
   }
   __syncthreads();
 
@@ -100,40 +113,50 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
     // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513): viewer u against its
     // entry about k, own position as it is NOW (obtain_state runs after the move)
     const double inv_w = p.inv_w;
-    for (int u0 = lane; u0 < N; u0 += 64) {
-      const int u = u0;
+    constexpr int RW = kObserveThreads / 64;         // waves: wave w sweeps rows w, w + RW, ...
+    constexpr int G = 8;                             // rows whose table words a lane has in flight together
+    for (int u = lane; u < N; u += 64) {
       const double mx = s_px[u], my = s_py[u];
       unsigned int mycnt = 0u;
       unsigned int* const hrow = s_hist + u * KP;
-#pragma unroll 2
-      for (int k = wave; k < N; k += kObserveThreads / 64) {
-        const size_t row = bR + k;
-        const unsigned int wn = p.tkey[row * NV + u];
-        const unsigned int tk_own = p.tkey[row * NV + k] >> 8;       // wave-uniform: a scalar load
-        const unsigned int seq = wn >> 8;
-        double xg;
-        if (p.ring && tk_own - seq <= 7u) xg = p.ring[row * 8 + (seq & 7u)];
-        else xg = p.tx[row * NV + u];
-        double d, v;
-        if constexpr (FLAT) {
-          v = xg - mx;                                                // all y == 0: x1 - x2 IS d * sign, d = |v|
-          const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-          d = __hiloint2double((int)vh, __double2loint(v));
-          if (vh < 0x20b00000u) {                                     // |v| below 2^-500 (its square underflows) or 0
-            d = dist_general(mx - xg, 0.0);
+#pragma unroll 1
+      for (int k0 = wave; k0 < N; k0 += RW * G) {
+        unsigned int wv[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int k = k0 + RW * i;
+          wv[i] = p.tkey[(bR + (k < N ? k : k0)) * NV + u];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int k = k0 + RW * i;
+          if (k >= N) break;                                          // wave-uniform
+          const unsigned int wn = wv[i];
+          const unsigned int seq = wn >> 8;
+          double xg;
+          if (use_ring && s_tk[k] - seq <= 7u) xg = s_ring[k * 8 + (seq & 7u)];
+          else xg = p.tx[(bR + k) * NV + u];
+          double d, v;
+          if constexpr (FLAT) {
+            v = xg - mx;                                              // all y == 0: x1 - x2 IS d * sign, d = |v|
+            const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+            d = __hiloint2double((int)vh, __double2loint(v));
+            if (vh < 0x20b00000u) {                                   // |v| below 2^-500 (its square underflows) or 0
+              d = dist_general(mx - xg, 0.0);
+              v = (xg - mx > 0.0) ? d : -d;
+            }
+          } else {
+            d = fast_dist<false>(xg, seq ? s_py[k] : 0.0, mx, my);    // ypos: the subject's lane once heard
             v = (xg - mx > 0.0) ? d : -d;
           }
-        } else {
-          d = fast_dist<false>(xg, seq ? s_py[k] : 0.0, mx, my);      // ypos: the subject's lane once heard
-          v = (xg - mx > 0.0) ? d : -d;
-        }
-        if (u != k && (int)(wn & 255u) < p.age_limit && d < p.Rb) {
-          int est = (int)((v + p.Rb) * inv_w);
-          est = est > K - 1 ? K - 1 : est;
-          const double e0 = s_edges[est], e1 = s_edges[est + 1];
-          const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
-          atomicAdd(&hrow[bin], 1u);
-          mycnt += 1u;
+          if (u != k && (int)(wn & 255u) < p.age_limit && d < p.Rb) {
+            int est = (int)((v + p.Rb) * inv_w);
+            est = est > K - 1 ? K - 1 : est;
+            const double e0 = s_edges[est], e1 = s_edges[est + 1];
+            const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+            atomicAdd(&hrow[bin], 1u);
+            mycnt += 1u;
+          }
         }
       }
       if (mycnt) atomicAdd(&s_cnt[u], mycnt);
@@ -141,6 +164,44 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
     __syncthreads();
   }
 
+  if (r.plain_state && ((A | K) & 3) == 0) {
+    // the toy YAML's state vector [one-hot(action) | histogram]: 16 bytes per lane, consecutive lanes on
+    // consecutive pieces of a row (the vectorised writer of step_fast64.hpp's P4; values identical)
+    const int S = A + K;
+    const int q_per_row = S >> 2, total = N * q_per_row;
+    const int du = kObserveThreads / q_per_row, dq = kObserveThreads - du * q_per_row;
+    int u = tid / q_per_row, qr = tid - u * q_per_row;
+    for (int q = tid; q < total; q += kObserveThreads) {
+      const int s0 = qr << 2;
+      double v0, v1, v2, v3;
+      if (s0 < A) {
+        const int a = s_act[u] - s0;
+        v0 = a == 0 ? 1.0 : 0.0; v1 = a == 1 ? 1.0 : 0.0; v2 = a == 2 ? 1.0 : 0.0; v3 = a == 3 ? 1.0 : 0.0;
+      } else {
+        const unsigned int n = s_cnt[u];
+        const unsigned int* h = s_hist + u * KP + (s0 - A);
+        if constexpr (OUT64) {
+          const double dn = (double)n;                               // network.py:501: one IEEE division per bin
+          v0 = n ? (double)h[0] / dn : 0.0; v1 = n ? (double)h[1] / dn : 0.0;
+          v2 = n ? (double)h[2] / dn : 0.0; v3 = n ? (double)h[3] / dn : 0.0;
+        } else {
+          // (float)((double)h * fl(1.0 / n)) == (float)((double)h / (double)n) for 0 <= h <= n <= 255 (step_fast64.hpp)
+          const double inv = p.inv_tab[n < 256u ? n : 0u];
+          v0 = (double)h[0] * inv; v1 = (double)h[1] * inv; v2 = (double)h[2] * inv; v3 = (double)h[3] * inv;
+        }
+      }
+      if constexpr (OUT64) {
+        double* out = static_cast<double*>(p.state_out) + bN * S + 4 * (size_t)q;
+        stream_store2(out, make_double2(v0, v1));
+        stream_store2(out + 2, make_double2(v2, v3));
+      } else {
+        stream_store4(static_cast<float*>(p.state_out) + bN * S + 4 * (size_t)q, make_float4((float)v0, (float)v1, (float)v2, (float)v3));
+      }
+      u += du; qr += dq;
+      if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
+    }
+    return;
+  }
   const double* const chobs_in = p.chobs_in;
   const double* const rew_in = p.rew_in;
   rich_write_state<OUT64>(

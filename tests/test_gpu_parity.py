@@ -1235,15 +1235,15 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     # topology (network.py:302-305) - run-time switches of the EXTRA instantiations - and a stand-alone
     # obtain_state with foreign arguments (observe_kernel.hpp)
     from diral_amd.config import KERNEL_OBSERVE
-    for state, extra in ((dict(add_positional_dist_piggy=False), {}),
-                         (dict(add_positional_dist=True, add_positional_dist_piggy=False), {}),
-                         ({}, dict(mobility=False, enable_design_topology=True))):
+    for state, extra, want in ((dict(add_positional_dist_piggy=False), {}, fam | KERNEL_RICH | KERNEL_EXTRA),
+                               (dict(add_positional_dist=True, add_positional_dist_piggy=False), {}, fam | KERNEL_RICH | KERNEL_EXTRA),
+                               ({}, dict(mobility=False, enable_design_topology=True), fam | KERNEL_EXTRA)):
         c3 = bench_config(N, A, L, State=state, **extra)
         e3 = make_env(c3, 4, dtype=torch.float64)
         e3.reset_topology(seed=5)
         a3 = e3.sample(seed=2)
         e3.step(a3, 0)
-        assert (e3.last_kernel() & ~KERNEL_RING) == fam | KERNEL_RICH | KERNEL_EXTRA, (state, extra, e3.last_kernel())
+        assert (e3.last_kernel() & ~KERNEL_RING) == want, (state, extra, e3.last_kernel())
         e3.obtain_state(None, e3.sample(seed=3), None)
         assert (e3.last_kernel() & 15) == KERNEL_OBSERVE, (state, extra, e3.last_kernel())
         e3.check()
