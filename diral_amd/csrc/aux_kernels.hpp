@@ -123,6 +123,68 @@ __global__ void ring_materialize_kernel(int B, int N, int NV, int NR, const uint
   if (tk - seq <= 7u) tx[row * NV + u] = ring[row * 8 + (seq & 7u)];
 }
 
+// The PACKED table of step_fast64 (step_fast64.hpp: codes, ages, own sequence numbers, old-quad flags) from the
+// planes and back.  One thread per (env, row-quad, viewer): four table entries.
+//   pack: after an import or a step of another kernel family (`told` zeroed by the caller beforehand).  An entry
+//   is coded if it was heard (seq != 0) and lags its subject by at most 7; one that lags 7 or more flags its
+//   quad - from the next slot on it is beyond the codes, and the planes hold it (they are complete right now).
+//   unpack: before anything reads the planes.  A coded entry's sequence number is the subject's own minus its lag,
+//   its xpos the subject's stamp of that number in the ring; a code-0 entry keeps the plane's sequence number
+//   (0: never heard) and xpos; every entry's age comes from the age words.
+__global__ void pack_codes_kernel(int B, int N, int NV, int NR, const uint32_t* tkey, uint32_t* tcode, uint32_t* tage,
+                                  uint32_t* tseq, uint32_t* told) {
+  const int NQ = NR >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * NQ * NV) return;
+  const int u = (int)(i % NV);
+  const int q = (int)((i / NV) % NQ);
+  const int b = (int)(i / ((size_t)NV * NQ));
+  uint32_t code = 0u, age = 0u;
+  bool flag = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * q + c;
+    const size_t row = (size_t)b * NR + k;
+    const bool ex = k < N && u < N;
+    const uint32_t w = ex ? tkey[row * NV + u] : 0u;
+    const uint32_t tk = k < N ? tkey[row * NV + k] >> 8 : 0u;
+    const uint32_t seq = w >> 8, lag = tk - seq;
+    const bool coded = seq != 0u && lag <= 7u;
+    code |= (coded ? ((0xffu << lag) & 0xffu) : 0u) << (8 * c);
+    age |= (w & 255u) << (8 * c);
+    flag = flag || (seq != 0u && lag >= 7u);
+    if (u == k || (k >= N && u == 0)) tseq[row] = tk;
+  }
+  tcode[i] = code;
+  tage[i] = age;
+  if (flag) atomicOr(&told[(size_t)b * NQ + q], 1u);
+}
+__global__ void unpack_codes_kernel(int B, int N, int NV, int NR, const uint32_t* tcode, const uint32_t* tage,
+                                    const uint32_t* tseq, const double* ring, uint32_t* tkey, double* tx) {
+  const int NQ = NR >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * NQ * NV) return;
+  const int u = (int)(i % NV);
+  const int q = (int)((i / NV) % NQ);
+  const int b = (int)(i / ((size_t)NV * NQ));
+  if (u >= N) return;
+  const uint32_t code = tcode[i], age = tage[i];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = 4 * q + c;
+    if (k >= N) break;
+    const size_t row = (size_t)b * NR + k;
+    const uint32_t r = (code >> (8 * c)) & 255u, a = (age >> (8 * c)) & 255u;
+    if (r) {
+      const uint32_t seq = tseq[row] - 8u + (uint32_t)__popc(r);
+      tkey[row * NV + u] = (seq << 8) | a;
+      tx[row * NV + u] = ring[row * 8 + (seq & 7u)];
+    } else {
+      tkey[row * NV + u] = (tkey[row * NV + u] & ~255u) | a;
+    }
+  }
+}
+
 __global__ void import_tables_kernel(int B, int N, int NV, int NR, const int32_t* seq, const int32_t* age,
                                      const double* x, uint32_t* tkey, double* tx) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -40,6 +40,13 @@ struct DiralEnv {
   // kept for entries older than the ring reaches; `plane_valid` / `ring_valid` say which of the two is complete
   double* ring = nullptr;
   bool plane_valid = true, ring_valid = false;
+  // the packed table of step_fast64 (N <= 64; step_fast64.hpp): thermometer codes of the entries' lags and their ages,
+  // four per word, the subjects' own sequence numbers, the old-quad flags.  It travels with the ring: `ring_valid`
+  // = ring AND packed words are current; `plane_valid` = the planes tkey / tx are complete and current
+  uint32_t* tcode = nullptr;
+  uint32_t* tage = nullptr;
+  uint32_t* tseq = nullptr;
+  uint32_t* told = nullptr;
   int32_t* la = nullptr;
   int32_t* pf = nullptr;
   double* metrics = nullptr;
@@ -196,9 +203,15 @@ bool stream_is_capturing(hipStream_t s) {
 hipError_t ensure_plane(DiralEnv* e, hipStream_t s) {
   if (e->plane_valid || !e->ring) { e->plane_valid = true; return hipSuccess; }
   if (stream_is_capturing(s)) { e->capture_violation = true; return hipErrorStreamCaptureUnsupported; }
-  const size_t total = (size_t)e->B * e->N * e->N;
-  hipLaunchKernelGGL(ring_materialize_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
-                     e->ring, e->tx);
+  if (e->tcode) {
+    const size_t total = (size_t)e->B * (e->NR / 4) * e->NV;
+    hipLaunchKernelGGL(unpack_codes_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tcode,
+                       e->tage, e->tseq, e->ring, e->tkey, e->tx);
+  } else {
+    const size_t total = (size_t)e->B * e->N * e->N;
+    hipLaunchKernelGGL(ring_materialize_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
+                       e->ring, e->tx);
+  }
   e->plane_valid = true;
   return hipGetLastError();
 }
@@ -208,6 +221,13 @@ hipError_t ensure_ring(DiralEnv* e, hipStream_t s) {
   const size_t total = (size_t)e->B * e->N * e->N;
   hipLaunchKernelGGL(ring_rebuild_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                      e->tx, e->ring);
+  if (e->tcode) {
+    const size_t nq = (size_t)e->B * (e->NR / 4);
+    hipError_t st = hipMemsetAsync(e->told, 0, nq * 4, s);
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL(pack_codes_kernel, dim3(blocks(nq * e->NV, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
+                       e->tcode, e->tage, e->tseq, e->told);
+  }
   e->ring_valid = true;
   return hipGetLastError();
 }
@@ -244,6 +264,8 @@ hipError_t launch_observe_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   o.actions = p.actions; o.chobs_in = p.chobs_in; o.rew_in = p.rew_in;
   o.pos_x = p.pos_x; o.pos_y = p.pos_y; o.vel = p.vel; o.tkey = p.tkey; o.tx = p.tx;
   o.ring = use_ring ? e->ring : nullptr;
+  const bool packed = use_ring && e->tcode != nullptr;           // N <= 64: codes, ages, own sequence numbers
+  o.tcode = packed ? e->tcode : nullptr; o.tage = packed ? e->tage : nullptr; o.tseq = packed ? e->tseq : nullptr;
   o.edges = p.edges; o.inv_tab = e->inv_tab; o.err = p.err; o.state_out = p.state_out;
   const RichParams r = rich_for(e, p);
   e->last_kernel = DIRAL_KERNEL_OBSERVE | (use_ring ? DIRAL_KERNEL_RING : 0);
@@ -293,6 +315,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges; f.inv_tab = e->inv_tab;
     f.ring = use_ring ? e->ring : nullptr;
+    f.tcode = e->tcode; f.tage = e->tage; f.tseq = e->tseq; f.told = e->told;
     if (use_ring) e->plane_valid = false;
     f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
     f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
@@ -331,6 +354,10 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   q.off_posdist = p.off_posdist; q.off_hist = p.off_hist;
   q.pos_x = p.pos_x; q.pos_y = p.pos_y; q.tkey = p.tkey; q.tx = p.tx; q.edges1 = e->edges1; q.state_out = p.state_out;
   q.do_full = 0; q.do_type1 = 0; q.ring = nullptr;
+  if (type1 && e->tcode) {                                      // N <= 64: the packed table -> planes first
+    const hipError_t st = ensure_plane(e, s);
+    if (st != hipSuccess) return st;
+  }
   const bool full_flat = full && e->flat_y;                     // one ranking of the env's x serves every viewer
   const bool type1_n64 = type1 && p.NV == 64;                   // lane = viewer, sort in registers
   const bool type1_lanes = type1 && !type1_n64;                 // 2 / 4 lanes per viewer (N <= 128 / 256)
@@ -492,10 +519,21 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->tx, (tab + 512 + 64 * 256) * 8));
   // the xpos ring of the specialised kernels (DIRAL_NO_RING: test hook, N <= 64 only - that kernel also runs
   // from the plane alone, the N > 64 kernels are built for the ring)
-  if ((e->vpl == 1 && e->NV == 64 && !std::getenv("DIRAL_NO_RING")) || (e->vpl > 1 && e->A <= kWideMaxA)) {
+  if ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
-    e->ring_valid = true;                                       // all tables zero: seq 0 -> slot 0 -> xpos 0
+    if (e->vpl == 1) {                                          // the packed table of step_fast64
+      const size_t nq = (size_t)e->B * (e->NR / 4);
+      CREATE_TRY(alloc((void**)&e->tcode, nq * e->NV * 4));
+      CREATE_TRY(alloc((void**)&e->tage, nq * e->NV * 4));
+      CREATE_TRY(alloc((void**)&e->tseq, (size_t)e->B * e->NR * 4));
+      CREATE_TRY(alloc((void**)&e->told, nq * 4));
+      CREATE_TRY(hipMemset(e->tcode, 0, nq * e->NV * 4));
+      CREATE_TRY(hipMemset(e->tage, 0, nq * e->NV * 4));
+      CREATE_TRY(hipMemset(e->tseq, 0, (size_t)e->B * e->NR * 4));
+      CREATE_TRY(hipMemset(e->told, 0, nq * 4));
+    }
+    e->ring_valid = true;                                       // all tables zero: never heard, age 0, xpos 0
   }
   CREATE_TRY(alloc((void**)&e->metrics, (size_t)e->B * DIRAL_M_COLUMNS * 8));
   CREATE_TRY(alloc((void**)&e->err, 4));
@@ -552,8 +590,8 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   p.off_act = off.act; p.off_chobs = off.chobs; p.off_posdist = off.posdist; p.off_hist = off.hist;
   p.off_rew = off.rew; p.off_idx = off.idx; p.off_pos = off.pos; p.off_vel = off.vel; p.off_fp = off.fp;
   p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel = e->vel; p.tkey = e->tkey; p.tx = e->tx;
-#ifdef DIRAL_TIMING
-  if (hipMalloc((void**)&e->dbg, (size_t)e->B * 16 * 8 * 8) == hipSuccess) (void)hipMemset(e->dbg, 0, (size_t)e->B * 16 * 8 * 8);
+#if defined(DIRAL_TIMING) || defined(DIRAL_DEBUG_XG)
+  if (hipMalloc((void**)&e->dbg, (size_t)e->B * 4096 * 8) == hipSuccess) (void)hipMemset(e->dbg, 0, (size_t)e->B * 4096 * 8);
 #endif
   p.dbg = e->dbg;
   p.la = e->la; p.pf = e->pf; p.metrics = e->metrics; p.err = e->err; p.edges = e->edges;
@@ -574,7 +612,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
@@ -613,6 +651,13 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   HIP_TRY(e, hipMemsetAsync(e->tkey, 0, tab * 4, s));
   HIP_TRY(e, hipMemsetAsync(e->tx, 0, tab * 8, s));
   if (e->ring) HIP_TRY(e, hipMemsetAsync(e->ring, 0, (size_t)e->B * e->NR * 8 * 8, s));
+  if (e->tcode) {
+    const size_t nq = (size_t)e->B * (e->NR / 4);
+    HIP_TRY(e, hipMemsetAsync(e->tcode, 0, nq * e->NV * 4, s));
+    HIP_TRY(e, hipMemsetAsync(e->tage, 0, nq * e->NV * 4, s));
+    HIP_TRY(e, hipMemsetAsync(e->tseq, 0, (size_t)e->B * e->NR * 4, s));
+    HIP_TRY(e, hipMemsetAsync(e->told, 0, nq * 4, s));
+  }
   e->plane_valid = true; e->ring_valid = e->ring != nullptr;
   HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
   if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));
@@ -706,7 +751,7 @@ int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* ve
   if (vel) HIP_TRY(e, hipMemcpyAsync(vel, e->vel, bn * 8, hipMemcpyDeviceToDevice, s));
   if (tab_seq || tab_age || tab_x || tab_y) {
     const size_t total = bn * e->N;
-    if (tab_x) HIP_TRY(e, ensure_plane(e, s));
+    HIP_TRY(e, ensure_plane(e, s));                               // (sequence numbers and ages too: the packed table of N <= 64)
     hipLaunchKernelGGL(export_tables_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, e->B, e->N, e->NV, e->NR, e->tkey,
                        e->tx, e->pos_y, tab_seq, tab_age, tab_x, tab_y);
     HIP_TRY(e, hipGetLastError());
@@ -808,7 +853,7 @@ int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
   return DIRAL_OK;
 }
 
-#ifdef DIRAL_TIMING
+#if defined(DIRAL_TIMING) || defined(DIRAL_DEBUG_XG)
 // -DDIRAL_TIMING tuning builds only (profiles/phase_timing.py binds it by name); compiled out of the
 // release library, so the release symbol table is exactly include/diral_env.h: copy the phase
 // timestamps [B][waves][8] to a host buffer.

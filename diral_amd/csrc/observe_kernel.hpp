@@ -42,6 +42,9 @@ struct ObserveParams {
   const uint32_t* tkey;
   const double* tx;
   const double* ring;            // [B][NR][8] or null: every xpos from the plane
+  const uint32_t* tcode;         // the packed table of step_fast64 (N <= 64, step_fast64.hpp) or null: sequence numbers and
+  const uint32_t* tage;          // ages from `tkey`.  Set together with `ring`: codes, ages, own sequence numbers;
+  const uint32_t* tseq;          // `tkey` / `tx` then only answer for the code-0 entries (never heard, or older than 7)
   const double* edges;
   const double* inv_tab;         // [256] 1.0 / n (0 for n = 0), as in step_fast64.hpp
   uint32_t* err;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
     // except LDS reads (the xpos of the rare entry older than the ring reaches comes from the plane)
     if (use_ring)
       for (int j = tid; j < 8 * N; j += kObserveThreads) s_ring[j] = p.ring[bR * 8 + j];
-    for (int k = tid; k < N; k += kObserveThreads) s_tk[k] = p.tkey[(bR + k) * NV + k] >> 8;
+    for (int k = tid; k < N; k += kObserveThreads) s_tk[k] = p.tseq ? p.tseq[bR + k] : p.tkey[(bR + k) * NV + k] >> 8;
   }
   __syncthreads();
 
@@ -113,8 +116,71 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
     // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513): viewer u against its
     // entry about k, own position as it is NOW (obtain_state runs after the move)
     const double inv_w = p.inv_w;
-    constexpr int RW = kObserveThreads / 64;         // waves: wave w sweeps rows w, w + RW, ...
+    constexpr int RW = kObserveThreads / 64;         // waves: wave w sweeps rows (or row-quads) w, w + RW, ...
     constexpr int G = 8;                             // rows whose table words a lane has in flight together
+    // one entry: viewer u (position mx, my) against its entry about k - age, xpos xg, heard at all
+    auto entry = [&](int u, int k, double mx, double my, unsigned int age, bool heard, double xg, unsigned int* hrow,
+                     unsigned int& mycnt) {
+      double d, v;
+      if constexpr (FLAT) {
+        v = xg - mx;                                                  // all y == 0: x1 - x2 IS d * sign, d = |v|
+        const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+        d = __hiloint2double((int)vh, __double2loint(v));
+        if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
+          d = dist_general(mx - xg, 0.0);
+          v = (xg - mx > 0.0) ? d : -d;
+        }
+      } else {
+        d = fast_dist<false>(xg, heard ? s_py[k] : 0.0, mx, my);      // ypos: the subject's lane once heard
+        v = (xg - mx > 0.0) ? d : -d;
+      }
+      if (u != k && (int)age < p.age_limit && d < p.Rb) {
+        int est = (int)((v + p.Rb) * inv_w);
+        est = est > K - 1 ? K - 1 : est;
+        const double e0 = s_edges[est], e1 = s_edges[est + 1];
+        const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+        atomicAdd(&hrow[bin], 1u);
+        mycnt += 1u;
+      }
+    };
+    if (p.tcode) {
+      // the packed table (N <= 64): one code word + one age word per row-quad and viewer = four entries
+      const size_t bQ = (size_t)b * (p.NR >> 2);
+      const int nq = (N + 3) >> 2;
+      for (int u = lane; u < N; u += 64) {
+        const double mx = s_px[u], my = s_py[u];
+        unsigned int mycnt = 0u;
+        unsigned int* const hrow = s_hist + u * KP;
+        unsigned int cv[4], av[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = wave + RW * i;
+          cv[i] = p.tcode[(bQ + (q < nq ? q : 0)) * NV + u];
+          av[i] = p.tage[(bQ + (q < nq ? q : 0)) * NV + u];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = wave + RW * i;
+          if (q >= nq) break;                                          // wave-uniform
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = 4 * q + c;
+            if (k >= N) break;
+            const unsigned int rcode = (cv[i] >> (8 * c)) & 255u, age = (av[i] >> (8 * c)) & 255u;
+            double xg;
+            bool heard = true;
+            if (rcode) {
+              xg = s_ring[k * 8 + ((s_tk[k] - 8u + (unsigned int)__popc(rcode)) & 7u)];
+            } else {                                                   // never heard, or older than the codes reach
+              xg = p.tx[(bR + k) * NV + u];
+              if constexpr (!FLAT) heard = (p.tkey[(bR + k) * NV + u] >> 8) != 0u;
+            }
+            entry(u, k, mx, my, age, heard, xg, hrow, mycnt);
+          }
+        }
+        if (mycnt) atomicAdd(&s_cnt[u], mycnt);
+      }
+    } else {
     for (int u = lane; u < N; u += 64) {
       const double mx = s_px[u], my = s_py[u];
       unsigned int mycnt = 0u;
@@ -136,30 +202,11 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
           double xg;
           if (use_ring && s_tk[k] - seq <= 7u) xg = s_ring[k * 8 + (seq & 7u)];
           else xg = p.tx[(bR + k) * NV + u];
-          double d, v;
-          if constexpr (FLAT) {
-            v = xg - mx;                                              // all y == 0: x1 - x2 IS d * sign, d = |v|
-            const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-            d = __hiloint2double((int)vh, __double2loint(v));
-            if (vh < 0x20b00000u) {                                   // |v| below 2^-500 (its square underflows) or 0
-              d = dist_general(mx - xg, 0.0);
-              v = (xg - mx > 0.0) ? d : -d;
-            }
-          } else {
-            d = fast_dist<false>(xg, seq ? s_py[k] : 0.0, mx, my);    // ypos: the subject's lane once heard
-            v = (xg - mx > 0.0) ? d : -d;
-          }
-          if (u != k && (int)(wn & 255u) < p.age_limit && d < p.Rb) {
-            int est = (int)((v + p.Rb) * inv_w);
-            est = est > K - 1 ? K - 1 : est;
-            const double e0 = s_edges[est], e1 = s_edges[est + 1];
-            const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
-            atomicAdd(&hrow[bin], 1u);
-            mycnt += 1u;
-          }
+          entry(u, k, mx, my, wn & 255u, seq != 0u, xg, hrow, mycnt);
         }
       }
       if (mycnt) atomicAdd(&s_cnt[u], mycnt);
+    }
     }
     __syncthreads();
   }

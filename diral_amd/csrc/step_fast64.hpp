@@ -73,7 +73,13 @@ struct FastParams {
   const double* vel;
   uint32_t* tkey;
   double* tx;
-  double* ring;                  // [B][NR][8] xpos ring, or null: every xpos from the plane `tx`
+  double* ring;                  // [B][NR][8] xpos ring (always set for step_fast64; step_wide: null = every xpos from the plane)
+  // the PACKED table of step_fast64: what the merge works on is what is stored.  Row-quad q = k / 4:
+  uint32_t* tcode;               // [B][NR/4][64]: byte c = thermometer code of the lag of viewer u's entry about subject 4q + c
+                                 // (0xff << lag for lag 0..7; 0 = never heard, or older than 7: then `tkey` holds its sequence number)
+  uint32_t* tage;                // [B][NR/4][64]: byte c = last_updated (saturating at 255) of the same entry - EVERY entry
+  uint32_t* tseq;                // [B][NR]: the subjects' own sequence numbers
+  uint32_t* told;                // [B][NR/4]: != 0: the quad holds an entry older than the codes reach -> keyed path
   int32_t* la;                   // last_arrival_time[tx][rx] (network.py:39-42) or null: not tracked
   const double* trace;           // replayed x positions (network.py:171-178, 194-199) or null
   int trace_len, trace_per_env;
@@ -327,16 +333,32 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // active resource in the merge loops (a branch around the whole phase trips the backend: "illegal VGPR to SGPR copy")
   const bool notab = EXTRA && RICH && p.notab != 0;
   const bool has_cols = wave * 16 < p.NR && !notab;      // uniform: idle waves of a small env
-  // (unconditional: a branch around the loads would make the compiler wait for
-  // ALL of them at the first use of the per-vehicle values - the waitcnt pass
-  // merges both paths conservatively; idle waves of a small env re-read row 0)
-  // (a table-less step - `notab` below - never looks at the words: every env re-reads the first rows, L2 hits)
-  const unsigned int* const tk_ld = has_cols ? tk : p.tkey + (size_t)b * p.NR * NV;
-  unsigned int w1[16];
+  // The packed table words of this wave's 16 subject columns = 4 row-quads: FOUR code words and FOUR age words per
+  // lane (a byte per column) where the (seq, age) plane took sixteen.  (Unconditional: a branch around the loads
+  // would make the compiler wait for ALL of them at the first use of the per-vehicle values - the waitcnt pass
+  // merges both paths conservatively; idle waves of a small env re-read quads 0..3, which always exist: NR >= 16.)
+  const int NQ = p.NR >> 2;
+  const size_t qbase = (size_t)b * NQ + (has_cols ? wave * 4 : 0);
+  unsigned int* const tc = p.tcode + qbase * NV;
+  unsigned int* const ta = p.tage + qbase * NV;
+  unsigned int cw[4], ag[4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) w1[c] = tk_ld[c * NV + lane];
+  for (int q = 0; q < 4; ++q) { cw[q] = tc[q * NV + lane]; ag[q] = ta[q * NV + lane]; }
+  // lane c (and c + 16, ...): the own sequence number of column c's subject
+  unsigned int* const tsq = p.tseq + (size_t)b * p.NR + (has_cols ? wave * 16 : 0);
+  const unsigned int ts_own = tsq[lane & 15];
   __builtin_amdgcn_sched_barrier(0);
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
+  // P1 measures |x_w - x_u| for every (transmitter, vehicle) pair; |dx| IS the reference's sqrt(fl(dx^2)) iff dx == 0
+  // or |dx| >= 2^-500 (fast_dist).  If every position of the env is 0 or at least 2^-447 in magnitude, every NONZERO
+  // difference of two of them is at least one ulp of the smaller one, 2^-499: the per-pair exponent test is then
+  // decided once per env (always, outside imported corner cases) and the search loop runs without it.
+  bool p1_fast = false;
+  if constexpr (FLAT) {
+    const unsigned int xh = (unsigned int)__double2hiint(mypx) & 0x7fffffffu;
+    const bool xsafe = xh >= 0x24000000u || (xh | (unsigned int)__double2loint(mypx)) == 0u;   // 2^-447: exponent field 0x240
+    p1_fast = __ballot(!xsafe) == 0ull;
+  }
   double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;             // network.py:203
   if (EXTRA && p.trace && live) {                                              // replay branch, network.py:194-199
     long long tt = p.t % p.trace_len;
@@ -368,29 +390,40 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // Network.find_closest_tx (network.py:378-398): ascending id, strict '<'
     double best = 100000.0;
     int bid = -1;
-    unsigned long long m = mk;
-    while (m) {
-      const int w = __builtin_ctzll(m);
-      m &= m - 1;
-      const double d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
-      const bool inr = d < p.Rc;
-      const bool bt = inr && (d < best);
-      best = bt ? d : best;
-      bid = bt ? w : bid;
-      if ((CH || (EXTRA && p.prr)) && c > 1) {                // in_range[tx] (test_env.py:395-397)
-        const int n_in = __popcll(__ballot(live && (myact != i) && inr));
-        if (lane == 0) s_inr[w] = n_in;
+    auto search = [&](auto fast_tag) {
+      constexpr bool ABS = decltype(fast_tag)::value;     // |dx| without the per-pair exponent test (p1_fast)
+      unsigned long long m = mk;
+      while (m) {
+        const int w = __builtin_ctzll(m);
+        m &= m - 1;
+        double d;
+        if constexpr (ABS) {
+          const double dx = mypx - readlane_f64(mypx, w);
+          d = __hiloint2double(__double2hiint(dx) & 0x7fffffff, __double2loint(dx));
+        } else {
+          d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
+        }
+        const bool inr = d < p.Rc;
+        const bool bt = inr && (d < best);
+        best = bt ? d : best;
+        bid = bt ? w : bid;
+        if ((CH || (EXTRA && p.prr)) && c > 1) {                // in_range[tx] (test_env.py:395-397)
+          const int n_in = __popcll(__ballot(live && (myact != i) && inr));
+          if (lane == 0) s_inr[w] = n_in;
+        }
+        // find_closest_tx side effect (network.py:394): an out-of-range transmitter's arrival
+        // stamp at this receiver becomes -1
+        if (EXTRA && p.la && live && (myact != i) && !inr) p.la[(bN + w) * N + lane] = -1;
+        if (EXTRA && !CH && p.design && c > 1) {
+          // my_step_design: reward by the number of transmitters of this resource within 2 Rc
+          // of this one (network.py:122-157): alone 1, else -n (a pair inside 2 Rc gets -2)
+          const int n = 1 + __popcll(__ballot((myact == i) && (lane != w) && (d < 2.0 * p.Rc)));
+          if (lane == 0) s_rtx[w] = (n == 1) ? 1.0 : -(double)n;
+        }
       }
-      // find_closest_tx side effect (network.py:394): an out-of-range transmitter's arrival
-      // stamp at this receiver becomes -1
-      if (EXTRA && p.la && live && (myact != i) && !inr) p.la[(bN + w) * N + lane] = -1;
-      if (EXTRA && !CH && p.design && c > 1) {
-        // my_step_design: reward by the number of transmitters of this resource within 2 Rc
-        // of this one (network.py:122-157): alone 1, else -n (a pair inside 2 Rc gets -2)
-        const int n = 1 + __popcll(__ballot((myact == i) && (lane != w) && (d < 2.0 * p.Rc)));
-        if (lane == 0) s_rtx[w] = (n == 1) ? 1.0 : -(double)n;
-      }
-    }
+    };
+    if (FLAT && p1_fast) search(std::true_type{});
+    else search(std::false_type{});
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
     if constexpr (RICH) {
@@ -429,7 +462,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         if (c == 2) {
           const int a = __builtin_ctzll(mk);
           const int bb = __builtin_ctzll(mk & (mk - 1));
-          const double dab = fast_dist<true>(readlane_f64(mypx, a), 0.0, readlane_f64(mypx, bb), 0.0);
+          const double dxab = readlane_f64(mypx, bb) - readlane_f64(mypx, a);
+          const double dab = p1_fast ? __hiloint2double(__double2hiint(dxab) & 0x7fffffff, __double2loint(dxab))
+                                     : fast_dist<true>(readlane_f64(mypx, a), 0.0, readlane_f64(mypx, bb), 0.0);
           rw = 2.0 * (double)(dab > p.Rc) - (double)c;       // (0 + d) / 1 == d exactly
         } else {
           rw = 0.0 - (double)c;
@@ -530,89 +565,68 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   DIRAL_FSTAMP(3);
 
   // ---- P3a: stamp + gossip merge over this wave's 16 subject columns -------------
-  unsigned int key[16];
-  {
-    // Vehicle.periodic_update (vehicle.py:56-70), branch-free: the own entry gets
-    // seq+1 / age 0, every other entry age+1 (saturating at 255)
-    const int own_c = live ? lane - wave * 16 : -1;            // column of this lane's own entry, if in this wave
-    unsigned int wmax = 0u;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const unsigned int w = w1[c];
-      const bool own = (own_c == c);
-      const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
-      const unsigned int a0 = w & 255u;
-      const unsigned int age = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
-      w1[c] = (seq << 8) | age;
-      wmax = max(wmax, w1[c]);
-    }
-    // sequence-number overflow: no entry exceeds its subject's own number, so the largest
-    // word seen reaches the limit exactly when some own stamp does
-    if ((wmax >> 8) >= (1u << 24) - 1u) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
-  }
-  // Vehicle.received_update for every (resource, rx), resources ascending: per column the entry of
-  // viewer u becomes the fresher of its own and that of its gather source m_i(u).
   //
-  // RING path.  In steady state an entry lags its subject's own sequence number by a handful of
-  // slots (C2: <= 5, profiles/lag_distribution.py).  (a) The 16 columns then travel as 8-level
-  // thermometer codes, four per register: ONE ds_bpermute + ONE v_or per four columns and resource,
-  // no gather source to track.  (b) An entry's xpos is a function of (subject, sequence number), and
-  // the xpos ring keeps every subject's 8 latest stamps: the xpos of EVERY entry that lags at most 7
-  // is one lookup in the subject's ring row (two ds_bpermute from the lanes that hold it) - the
-  // per-entry xpos plane, two thirds of the table bytes, is neither read nor written.  Only an entry
-  // that reaches lag 7 saves its xpos to the plane, where it lives from lag 8 on.  Exact iff every
-  // entry of the wave lags at most 7 or was never heard (seq 0, at least 12 slots behind); otherwise
-  // the wave takes the KEYED path below, which reads the xpos of young entries from the ring, of old
-  // ones from the plane, and leaves the plane complete for its columns.
-  //
-  // KEYED path: two columns share one register as 16-bit keys (rank << 6) | source, rank = 1023 - lag,
-  // merged with v_pk_max_u16 - exact iff no entry of the wave has lag >= 1023 with seq != 0 (never-heard
-  // entries, seq == 0, all share rank 0) - or, for imported / very stale tables, 32-bit keys.
-  // resources with at least one transmitter, as a wave-uniform bit word: the merge visits only those
+  // The table is stored the way the merge wants it (round 3): per row-quad and viewer ONE word of four
+  // thermometer codes c(lag) = (0xff << lag) & 0xff of the entries' lags behind their subjects' own sequence
+  // numbers (0 = never heard), and one word of four ages.  In steady state an entry lags its subject by a handful
+  // of slots (C2: <= 5, profiles/lag_distribution.py), so:
+  //  * Vehicle.periodic_update (vehicle.py:56-70) is a shift: every subject takes a fresh number each slot, every
+  //    lag grows by one - c' = (c << 1) & 0xfe per byte, two instructions per FOUR entries; the own entry becomes
+  //    0xff / age 0; the ages take one packed saturating increment;
+  //  * Vehicle.received_update for every (resource, rx), resources ascending: the codes are a chain under bit
+  //    inclusion, the fresher entry's code is the bitwise OR - ONE ds_bpermute + ONE v_or per four columns and
+  //    resource, no gather source to track (the alias of transmitted / live table, SURVEY Q1, is what makes the
+  //    in-place form exact);
+  //  * an entry's xpos is a function of (subject, sequence number) and the xpos ring keeps every subject's 8
+  //    latest stamps: the xpos of EVERY coded entry is one lookup in the subject's ring row (two ds_bpermute from
+  //    the lanes that hold it); the per-entry planes `tkey` / `tx` are neither read nor written;
+  //  * what goes back to HBM is the merged code word and the age word (ages of updated entries cleared with a
+  //    byte mask): 4 + 4 stores per lane.
+  // An entry that reaches lag 7 hands over: its sequence number goes to `tkey`, its xpos to `tx`, and the quad is
+  // flagged in `told`; from the next slot on (code 0, like a never-heard entry, but tkey.seq != 0) the quad takes
+  // the KEYED path below - 32-bit keys (seq << 8) | source lane, sequence numbers rebuilt from the codes or read
+  // from `tkey` - until the entry is refreshed.  Never-heard entries (seq 0) are code 0 with tkey.seq == 0; their
+  // ghost xpos (0, or whatever was imported) lives in `tx`, their ages in the age words like everybody's.
   const unsigned long long actw = notab ? 0ull : __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
-  // the xpos rings of this wave's 16 subjects: lane l holds slot l & 7 of subject l >> 3 (ringv0) / 8 + (l >> 3)
-  // (ringv1); loaded here, first needed after the codes are built
   const LateFastArgs lpr = (LateFastArgs)late_kernarg_base();
-  double* const ring = lpr->ring;
-  const bool use_ring = ring != nullptr && !notab;       // uniform
-  double* const ringp = ring + ((size_t)b * p.NR + (has_cols ? wave * 16 : 0)) * 8;
-  double ringv0 = 0.0, ringv1 = 0.0;
-  if (use_ring) { ringv0 = ringp[lane]; ringv1 = ringp[64 + lane]; }
-  // thermo_ok: the coded merge serves the wave's columns - all sixteen, or (qkey >= 0) all but the four of code
-  // word qkey, which hold an entry older than the codes reach and are merged as 32-bit keys in a loop of their
-  // own in P3b (a straggler is usually ONE subject, sticky policies produce them: profiles/lag_distribution*.py).
-  // Two stale words or more: the whole wave takes 32-bit keys.  (Serving every stale word with such a loop was
-  // measured: 20 % slower on waves without any.)
-  bool thermo_ok = false;
-  int qkey = -1;
-  // codes after / before the merge and ages, column c in byte c & 3 of word c >> 2; lane c of `tkov`: the
-  // fresh sequence number of column c's subject
-  unsigned int cw[4], cold[4], agw[4] = {0u, 0u, 0u, 0u}, tkov = 0u;
-  if (use_ring) {
-    unsigned int lw[4] = {0u, 0u, 0u, 0u};
-    bool bad8[4] = {false, false, false, false};
+  // the xpos rings of this wave's 16 subjects: lane l holds slot l & 7 of subject l >> 3 (ringv0) / 8 + (l >> 3)
+  // (ringv1); loaded here, first needed after the merge
+  double* const ringp = lpr->ring + ((size_t)b * p.NR + (has_cols ? wave * 16 : 0)) * 8;
+  double ringv0 = ringp[lane], ringv1 = ringp[64 + lane];
+  // quads with an entry older than the codes reach (a straggler is usually ONE subject; sticky policies produce
+  // them: profiles/lag_distribution*.py): bit q of `badq`, from the flags the previous slot left
+  unsigned int badq = 0u;
+  {
+    const unsigned int* const toldp = lpr->told + qbase;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const unsigned int seq = w1[c] >> 8;
-      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)seq, (wave * 16 + c) & 63);
-      tkov = (lane == c) ? tk_own : tkov;
-      // lag byte 0..7, or 12 = never heard; anything else: not exact in this representation
-      const unsigned int lagc = min(tk_own - seq, 12u);
-      bad8[c >> 2] = bad8[c >> 2] || (lagc >= 8u && (lagc < 12u || seq != 0u));
-      lw[c >> 2] |= lagc << (8 * (c & 3));
-      agw[c >> 2] |= (w1[c] & 255u) << (8 * (c & 3));
-    }
-    int nstale = 0;
+    for (int q = 0; q < 4; ++q) badq |= (toldp[q] != 0u ? 1u : 0u) << q;
+    badq = has_cols ? (unsigned int)__builtin_amdgcn_readfirstlane((int)badq) : 0u;
+  }
+  const int own_col = live ? lane - wave * 16 : -1;            // column of this lane's own entry, if in this wave
+  const bool own_here = has_cols && (unsigned int)own_col < 16u;
+  // fresh sequence numbers of the 16 subjects: lane c holds column c's (lanes >= 16 repeat them)
+  const unsigned int tkov = ts_own + 1u;
+  if (has_cols && lane < 16) tsq[lane] = tkov;
+  // sequence-number overflow (24 bits: the keyed path packs (seq << 8) | lane)
+  if (tkov >= (1u << 24) - 1u) atomicOr(lpr->err, kErrSeq);
+  unsigned int cold[4];                                         // the codes after the stamp, before the merge
+  {
+    // Vehicle.periodic_update (vehicle.py:56-70)
+    const unsigned int own_byte = own_here ? (0xffu << (8 * (own_col & 3))) : 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (__ballot(bad8[q]) != 0ull) { ++nstale; qkey = q; }
+      const unsigned int om = (own_col >> 2) == q ? own_byte : 0u;
+      cw[q] = ((cw[q] << 1) & 0xfefefefeu) | om;               // every lag + 1; the own entry: lag 0
+      // ages + 1, saturating at 255, four per word (no carry crosses a byte: the low 7 bits are added alone)
+      const unsigned int a = ag[q];
+      const unsigned int hi = a & 0x80808080u;
+      const unsigned int lo = (a & 0x7f7f7f7fu) + 0x01010101u;
+      const unsigned int sat = lo & hi;                        // 0x80 where the byte was 0xff
+      ag[q] = ((lo ^ hi) | sat | (sat - (sat >> 7))) & ~om;    // own entry: age 0
+      cold[q] = cw[q];
     }
-    thermo_ok = nstale <= 1;
-    if (nstale != 1) qkey = -1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cw[q] = cold[q] = thermo_codes(lw[q]);
-    // this slot's stamps (vehicle.py:61-63: the subject's pre-move position under its fresh sequence
-    // number) into the ring rows, in registers and in memory
+    // this slot's stamps (vehicle.py:61-63: the subject's pre-move position under its fresh sequence number) into
+    // the ring rows, in registers and in memory
     const int cl = lane >> 3;
     const unsigned int tk0 = (unsigned int)__builtin_amdgcn_ds_bpermute(cl << 2, (int)tkov);
     const unsigned int tk1 = (unsigned int)__builtin_amdgcn_ds_bpermute((cl + 8) << 2, (int)tkov);
@@ -629,8 +643,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (h1) ringp[64 + lane] = px1;
     }
   }
-  if (thermo_ok) {
-    // (qkey >= 0: the codes of that word are merged along - meaningless, never read)
+  {
+    // the coded merge (the words of a bad quad are merged along - meaningless, never read)
     unsigned long long rem = actw;
     int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
 #pragma unroll 1
@@ -644,14 +658,13 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   }
   DIRAL_FSTAMP(4);
 
-  // ---- P3b: the entry's xpos, the table word, the histogram ------------------------
+  // ---- P3b: the entry's xpos, the table words, the histogram -----------------------
   unsigned int mycnt = 0u;
   const double inv_w = p.inv_w;
   unsigned int* const hrow = s_hist + lane * KP;
-  const int ncol = has_cols ? 16 : 0;
   // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) of one entry:
   // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
-  auto tally = [&](int k, unsigned int wn, double xg) {
+  auto tally = [&](int k, bool heard, unsigned int age, double xg) {
     double d, v;
     if constexpr (FLAT) {
       // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v|
@@ -664,10 +677,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
     } else {
       const double pyk = readlane_f64(mypy, k);
-      d = fast_dist<false>(xg, (wn >> 8) ? pyk : 0.0, mynpx, mypy);
+      d = fast_dist<false>(xg, heard ? pyk : 0.0, mynpx, mypy);
       v = (xg - mynpx > 0.0) ? d : -d;
     }
-    const bool ok = live && (k < N) && (lane != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    const bool ok = live && (k < N) && (lane != k) && ((int)age < p.age_limit) && (d < p.Rb);
     if (ok) {
       // |v| < Rb, so the estimate is in [0, K] and the edge correction needs no bounds
       // tests: edges[0] = -Rb <= v and v < Rb = edges[K] hold by construction
@@ -685,123 +698,131 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(rv)),
                             __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
   };
-  // one column with a 32-bit key kf = (final seq << 8) | source lane: wr its table word as loaded, x_pl its xpos in the plane
-  const int own_col = live ? lane - wave * 16 : -1;
-  auto keyed_column = [&](int c, unsigned int kf, unsigned int wr, double x_pl) {
-    const int k = wave * 16 + c;
-    const int off = c * NV + lane;
-    // Vehicle.periodic_update again (vehicle.py:56-70)
-    const bool own = (own_col == c);
-    const unsigned int a0 = wr & 255u;
-    const unsigned int w = (((wr >> 8) + (own ? 1u : 0u)) << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
-    const bool upd = ((kf ^ w) >> 8) != 0u;
-    double x_cur = x_pl;
-    if (use_ring) {
-      // a young entry's xpos is in the ring, not (necessarily) in the plane
-      const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-      const double xr = ring_x(c < 8 ? ringv0 : ringv1, c, w >> 8);
-      x_cur = (tk_own - (w >> 8) <= 7u) ? xr : x_cur;
-    }
-    const double xs = (lane == k) ? mypx : x_cur;               // own stamp (vehicle.py:63)
-    const int src4 = (int)(kf & 255u) << 2;
-    const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
-    const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
-    const double xg = upd ? __hiloint2double(hi, lo) : xs;
-    const unsigned int wn = upd ? (kf & ~255u) : w;
-    tk[off] = wn;
-    if (use_ring || upd || lane == k) txp[off] = xg;            // with the ring: the plane complete for these columns
-    tally(k, wn, xg);
-  };
-  if (thermo_ok) {
-    if (qkey >= 0 && has_cols) {
-      // the stale word's four columns: 32-bit keys (seq << 8) | source lane from the table words as loaded,
-      // a merge loop of their own, then column by column (the keys rotate through kq[0])
-      unsigned int kq[4], wr4[4];
-      double xp4[4];                              // (all eight loads in flight together: one round trip, not four)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = 4 * qkey + i;
-        wr4[i] = tk[c * NV + lane];
-        xp4[i] = txp[c * NV + lane];
-        kq[i] = (((wr4[i] >> 8) + (own_col == c ? 1u : 0u)) << 8) | (unsigned int)lane;
-      }
-      unsigned long long rem = actw;
-      int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-      while (rem) {
-        rem &= rem - 1;
-        const int m4 = m_next;
-        if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) keyed_column(4 * qkey + i, kq[i], wr4[i], xp4[i]);
-    }
-    // (four rolled loops of four columns, one per packed word: a dynamically indexed word array would live
-    // in scratch memory, a register rotation costs a dozen moves per column)
+  if (has_cols) {
+    // -- coded quads: ages of updated entries cleared (a byte mask of the code bytes that changed), the two words
+    //    stored, then column by column: xpos from the ring, hand-over at lag 7, histogram.
+    //    (four rolled loops of four columns, one per packed word: a dynamically indexed word array would live
+    //    in scratch memory, a register rotation costs a dozen moves per column)
+    unsigned int handed = 0u;                                     // bit q: a lane of quad q handed an entry over
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q == qkey) continue;
+      if ((badq >> q) & 1u) continue;                              // (uniform)
+      const unsigned int cnq = cw[q];
+      unsigned int agq;
+      {
+        const unsigned int x = cnq ^ cold[q];
+        const unsigned int nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // 0x80 per changed byte
+        agq = ag[q] & ~(nz | (nz - (nz >> 7)));                  // a fresh copy has age 0
+      }
+      tc[q * NV + lane] = cnq;
+      ta[q * NV + lane] = agq;
       const double rv = q >= 2 ? ringv1 : ringv0;
-      const unsigned int cnq = cw[q], coq = cold[q], agq = agw[q];
+      bool hand = false;
 #pragma unroll 1
-      for (int cc = 0; cc < (ncol >> 2); ++cc) {
+      for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * q + cc;
         const int k = wave * 16 + c;
         const int off = c * NV + lane;
         const unsigned int sh = 8u * (unsigned int)cc;
-        const unsigned int rf = (cnq >> sh) & 255u, r0 = (coq >> sh) & 255u, age = (agq >> sh) & 255u;
-        const bool upd = rf != r0;
+        const unsigned int rf = (cnq >> sh) & 255u, age = (agq >> sh) & 255u;
         const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        // sequence number back from the code: lag = 8 - popcount (code 0: never heard, seq 0)
+        // sequence number back from the code: lag = 8 - popcount
         const unsigned int seqn = tk_own - 8u + (unsigned int)__popc(rf);
         double xg = ring_x(rv, c, seqn);
         if (rf == 0u) xg = txp[off];                                // never heard: the ghost xpos lives in the plane
-        const unsigned int wn = (rf ? (seqn << 8) : 0u) | (upd ? 0u : age);   // a fresh copy has age 0
-        tk[off] = wn;
-        if (rf == 0x80u) txp[off] = xg;                            // lag 7: next slot it may be beyond the ring
-        tally(k, wn, xg);
-      }
-    }
-  } else {
-    // 32-bit keys (seq << 8) | source lane, one ds_bpermute + max per column and resource (the 16-bit packed
-    // keys of the build without the ring are not worth their registers on a path this rare)
-    unsigned int key[16];
-    {
-      const int own_c = live ? lane - wave * 16 : -1;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const unsigned int w = tk_ld[c * NV + lane];             // (re-read: keeping w1[] alive for this path would spill it in front of the other)
-        key[c] = (((w >> 8) + (own_c == c ? 1u : 0u)) << 8) | (unsigned int)lane;
-      }
-    }
-    {
-      unsigned long long rem = actw;
-      int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-      while (rem) {
-        rem &= rem - 1;
-        const int m4 = m_next;
-        if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const unsigned int v = (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)key[c]);
-          key[c] = max(key[c], v);
+        if (rf == 0x80u) {                                          // lag 7: from the next slot on beyond the codes
+          txp[off] = xg;
+          tk[off] = (seqn << 8) | age;
+          hand = true;
         }
+#ifdef DIRAL_DEBUG_XG
+        if (p.dbg) p.dbg[((size_t)b * 64 + k) * 64 + lane] = (unsigned long long)__double_as_longlong(xg);
+#endif
+        tally(k, rf != 0u, age, xg);
+      }
+      handed |= (__ballot(hand) != 0ull ? 1u : 0u) << q;
+    }
+    // -- keyed quads: 32-bit keys (seq << 8) | source lane.  Sequence numbers from the (stamped) codes, or from
+    //    `tkey` where the code is 0; one ds_bpermute + max per column and resource; then column by column the
+    //    xpos (young entries' from the ring, old ones' from the plane) through ONE gather from the recorded
+    //    source, and the entry goes back coded if it came back within reach of the codes, else into `tkey`.
+    //    The plane `tx` and `tkey` are left complete for these columns.  (Rolled over the quads with the words
+    //    rotating through element 0: rare, and four unrolled copies cost the coded path registers.)
+    unsigned int still = 0u;                                      // bit q: quad q keeps an entry beyond the codes
+    if (badq) {
+      unsigned int rc0 = cold[0], rc1 = cold[1], rc2 = cold[2], rc3 = cold[3];
+      unsigned int ra0 = ag[0], ra1 = ag[1], ra2 = ag[2], ra3 = ag[3];
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        if ((badq >> q) & 1u) {
+          const double rv = q >= 2 ? ringv1 : ringv0;
+          unsigned int kq[4], k0[4];
+          double xp4[4];                            // (all eight loads in flight together: one round trip, not four)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            const unsigned int wr = tk[c * NV + lane];
+            xp4[i] = txp[c * NV + lane];
+            const unsigned int r = (rc0 >> (8 * i)) & 255u;
+            const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+            const unsigned int seq = r ? tk_own - 8u + (unsigned int)__popc(r) : (wr >> 8);
+            k0[i] = kq[i] = (seq << 8) | (unsigned int)lane;
+          }
+          unsigned long long rem = actw;
+          int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
+#pragma unroll 1
+          while (rem) {
+            rem &= rem - 1;
+            const int m4 = m_next;
+            if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
+          }
+          unsigned int ncode = 0u, nage = 0u;
+          bool keep = false;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * q + i;
+            const int k = wave * 16 + c;
+            const int off = c * NV + lane;
+            const unsigned int r = (rc0 >> (8 * i)) & 255u, a0 = (ra0 >> (8 * i)) & 255u;
+            const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+            const unsigned int seq0 = k0[i] >> 8, seqf = kq[i] >> 8;
+            const bool upd = seqf != seq0;
+            // a coded entry's xpos is in the ring, not (necessarily) in the plane.  (The lookup is unconditional: under a
+            // branch the ds_bpermute would run with the code-0 lanes switched off - and read 0 from them.)
+            const double xr = ring_x(rv, c, seq0);
+            const double x_cur = r ? xr : xp4[i];
+            const double xs = (lane == k) ? mypx : x_cur;             // own stamp (vehicle.py:63)
+            const int src4 = (int)(kq[i] & 255u) << 2;
+            const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(xs));
+            const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(xs));
+            const double xg = upd ? __hiloint2double(hi, lo) : xs;
+            const unsigned int age = upd ? 0u : a0;                   // (the own entry's age is 0 since the stamp)
+            const unsigned int lagf = tk_own - seqf;
+            const bool coded = seqf != 0u && lagf <= 7u;
+            ncode |= (coded ? ((0xffu << lagf) & 0xffu) : 0u) << (8 * i);
+            nage |= age << (8 * i);
+            keep = keep || (seqf != 0u && lagf >= 7u);                // beyond the codes from the next slot on
+            tk[off] = (seqf << 8) | age;
+            txp[off] = xg;
+#ifdef DIRAL_DEBUG_XG
+            if (p.dbg) p.dbg[((size_t)b * 64 + k) * 64 + lane] = (unsigned long long)__double_as_longlong(-xg - 1e6);
+#endif
+            tally(k, seqf != 0u, age, xg);
+          }
+          tc[q * NV + lane] = ncode;
+          ta[q * NV + lane] = nage;
+          still |= (__ballot(keep) != 0ull ? 1u : 0u) << q;
+        }
+        rc0 = rc1; rc1 = rc2; rc2 = rc3;
+        ra0 = ra1; ra1 = ra2; ra2 = ra3;
       }
     }
-    // (a rolled loop with uniform register indexing of key[]; the table word is re-read - it is what
-    // w1[c] held before the stamp - rather than indexed: a second dynamically indexed array would put
-    // both in scratch memory.  The next column's xpos and word are loaded one iteration ahead.)
-    double x_next = has_cols ? txp[lane] : 0.0;
-    unsigned int w_next = has_cols ? tk[lane] : 0u;
-#pragma unroll 1
-    for (int c = 0; c < ncol; ++c) {
-      const unsigned int wr = w_next;
-      const double x_pl = x_next;
-      if (c + 1 < ncol) { x_next = txp[(c + 1) * NV + lane]; w_next = tk[(c + 1) * NV + lane]; }
-      keyed_column(c, key[c], wr, x_pl);
+    // the flags of the next slot: quads that handed an entry over, keyed quads that still hold one
+    const unsigned int newf = (handed & ~badq) | still;
+    if (newf != badq || handed) {
+      if (lane < 4) lpr->told[qbase + lane] = (newf >> lane) & 1u;
     }
   }
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   DIRAL_WSTAMP(0);
 
   // ---- P0: per-vehicle state and the post-move position into LDS --------------
+  int x_unsafe = 0;      // a position that is neither 0 nor at least 2^-447 in magnitude (see p1_fast, step_fast64.hpp)
   if (tid < NPAD) {
     const int u = tid;
     const bool lv = u < N;
@@ -350,6 +351,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     if (lv && (a < 0 || a >= A)) { atomicOr(p.err, kErrAction); a = -1; }
     s_act[u] = a;
     s_px[u] = x;
+    {
+      const unsigned int xh = (unsigned int)__double2hiint(x) & 0x7fffffffu;
+      x_unsafe = !(xh >= 0x24000000u || (xh | (unsigned int)__double2loint(x)) == 0u);
+    }
     double nx = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;     // network.py:203
     if (EXTRA && p.trace && lv) {                            // replay branch, network.py:194-199
       long long tt = p.t % p.trace_len;
@@ -363,7 +368,18 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   }
   for (int j = tid; j < KP * NPAD; j += THREADS) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+  // (the barrier P1 needs anyway, carrying one bit: every position of the env is 0 or >= 2^-447, so every nonzero
+  // |x_w - x_u| is >= 2^-499 and IS the reference's sqrt(fl(dx^2)) - the search runs without the per-pair exponent test)
+  // (carried through the `s_red` slots, free until P2: __syncthreads_or would bring static LDS, and the merge loop
+  // relies on the dynamic segment starting at LDS address 0)
+  if (tid < NPAD) {
+    const unsigned long long uns = __ballot(x_unsafe != 0);
+    if (lane == 0) reinterpret_cast<int*>(s_red)[wave] = uns != 0ull ? 1 : 0;
+  }
   __syncthreads();
+  bool p1_fast = true;
+#pragma unroll
+  for (int w = 0; w < VPL; ++w) p1_fast = p1_fast && reinterpret_cast<const int*>(s_red)[w] == 0;
   DIRAL_WSTAMP(1);
 
   int myact[VPL];
@@ -391,6 +407,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       int bid[VPL];
 #pragma unroll
       for (int j = 0; j < VPL; ++j) { best[j] = 100000.0; bid[j] = -1; }   // network.py:385-386
+      auto search = [&](auto fast_tag) {
+      constexpr bool ABS = decltype(fast_tag)::value;     // |dx| without the per-pair exponent test (p1_fast)
 #pragma unroll
       for (int jt = 0; jt < VPL; ++jt) {
         unsigned long long m = mk[jt];
@@ -401,7 +419,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           int n_in = 0;
 #pragma unroll
           for (int j = 0; j < VPL; ++j) {
-            const double d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
+            double d;
+            if constexpr (ABS) {
+              const double dx = mypx[j] - xw;
+              d = __hiloint2double(__double2hiint(dx) & 0x7fffffff, __double2loint(dx));
+            } else {
+              d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
+            }
             const bool inr = d < p.Rc;
             const bool bt = inr && (d < best[j]);
             best[j] = bt ? d : best[j];
@@ -417,6 +441,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           if (EXTRA && !CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
         }
       }
+      };
+      if (p1_fast) search(std::true_type{});
+      else search(std::false_type{});
       unsigned int mw = 0u;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {

@@ -1259,56 +1259,6 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         assert e5.last_kernel() == KERNEL_GENERAL
 
 
-@pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 9, 1500.0), (64, 16, 9000.0)])
-def test_xpos_ring_agrees_with_the_plane_through_every_consumer(N, A, L, monkeypatch):
-    """The N <= 64 kernel keeps the xpos of young entries in a per-subject ring and the per-entry plane only
-    for older ones (csrc/step_fast64.hpp).  Everything else that reads the plane - export_state, a stand-alone
-    obtain_state with foreign arguments (diral_env_observe), a step of the general kernel, import_state - must
-    see it completed first, and the ring must be rebuilt when another kernel moved the tables.  A ring env and
-    a DIRAL_NO_RING env (plane only, the round-2 kernel) take the same rollout with those calls mixed in; the
-    third topology is sparse enough for lags beyond the ring (keyed fallback, plane hand-over at lag 7)."""
-    from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RING
-    cfg = bench_config(N, A, L, mobility_vary=True, communication_range=250.0 if L < 5000 else 140.0)
-    B = 6
-    ring = make_env(cfg, B, dtype=torch.float64)
-    monkeypatch.setenv("DIRAL_NO_RING", "1")
-    plane = make_env(cfg, B, dtype=torch.float64)
-    monkeypatch.delenv("DIRAL_NO_RING")
-    for e in (ring, plane):
-        e.reset_topology(seed=41)
-    rng = np.random.default_rng(N + A)
-
-    def same_tables(t):
-        a, b = ring.export_state(), plane.export_state()
-        for k in ("seq", "age", "x", "pos_x", "vel"):
-            assert torch.equal(a[k], b[k]), (k, t)
-
-    for t in range(90):
-        acts = torch.as_tensor(rng.integers(0, A, size=(B, N)).astype(np.int32), device="cuda:0")
-        general = t in (17, 18, 40) or 60 <= t < 64                  # the general kernel takes over for some slots
-        for e in (ring, plane):
-            e.force_general_kernel(general)
-        (o1, r1, _), (o2, r2, _) = ring.step(acts, t), plane.step(acts, t)
-        assert torch.equal(o1, o2) and torch.equal(r1, r2), t
-        assert ring.last_kernel() == (KERNEL_GENERAL if general else KERNEL_FAST64 | KERNEL_RING)
-        assert plane.last_kernel() == (KERNEL_GENERAL if general else KERNEL_FAST64)
-        if t % 7 == 3:
-            same_tables(t)                                           # export: the plane completed from the ring
-        if t % 11 == 5:                                              # foreign arguments: a diral_env_observe launch
-            fake = torch.full((B, N), 0.25, dtype=torch.float64, device="cuda:0")
-            s1 = ring.obtain_state(None, acts, fake).clone()
-            s2 = plane.obtain_state(None, acts, fake).clone()
-            assert torch.equal(s1, s2), t
-        if t == 30 or t == 71:                                       # checkpoint round trip through import_state
-            st = ring.export_state()
-            ring.import_state(st["pos_x"], st["pos_y"], st["vel"], seq=st["seq"], age=st["age"], x=st["x"])
-        if t % 25 == 24:
-            for e in (ring, plane):
-                e.update_velocity(seed=t)
-    same_tables(90)
-    ring.check(); plane.check()
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,A,L", [(64, 32, 2000.0), (40, 16, 6000.0), (128, 64, 4000.0), (200, 40, 12000.0)])
 def test_realnes_entry_records_round_trip_and_feed_the_step(N, A, L):
@@ -1385,17 +1335,21 @@ def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
                    expect_kernel=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE)
 
 
-@pytest.mark.parametrize("N,A,L,Rc", [(128, 64, 4000.0, 250.0), (256, 64, 4000.0, 250.0), (200, 24, 30000.0, 140.0),
+@pytest.mark.parametrize("N,A,L,Rc", [(64, 32, 2000.0, 250.0), (40, 9, 1500.0, 250.0), (64, 16, 9000.0, 140.0), (33, 5, 6000.0, 100.0),
+                                      (128, 64, 4000.0, 250.0), (256, 64, 4000.0, 250.0), (200, 24, 30000.0, 140.0),
                                       (96, 12, 20000.0, 120.0)])
-def test_wide_xpos_ring_agrees_with_the_oracle_through_every_consumer(N, A, L, Rc):
-    """The N > 64 kernels keep the xpos of young entries in the per-subject ring as well (csrc/step_wide.hpp);
-    there is no plane-only build of them to compare with, so the comparator is the oracle: a rollout with
-    general-kernel steps, stand-alone obtain_state calls with foreign arguments (diral_env_observe), export /
-    import round trips and velocity updates mixed in must match it slot by slot (state, reward, channel
-    observation) and plane by plane at every export.  The last two topologies are sparse enough for entries
-    beyond the ring (byte-rank / 32-bit passes, plane hand-over at lag 7)."""
+def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consumer(N, A, L, Rc):
+    """The specialised kernels do not keep the reference-shaped planes current: N <= 64 stores the table as
+    thermometer codes + ages + own sequence numbers, and both families keep the xpos of young entries in the
+    per-subject ring (csrc/step_fast64.hpp, step_wide.hpp); the planes `tkey` / `tx` only answer for entries older
+    than 7 stamps.  Everything else - export_state, a stand-alone obtain_state with foreign arguments
+    (diral_env_observe), a step of the general kernel, import_state - must see the planes completed first, and the
+    packed state must be rebuilt when another kernel moved the tables.  The comparator is the oracle: a rollout with
+    all of those mixed in must match it slot by slot (state, reward, channel observation) and plane by plane at
+    every export.  The sparse topologies (Rc < 200) hold entries beyond the codes / the ring (keyed quads,
+    byte-rank / 32-bit passes, hand-over at lag 7)."""
     from oracle.oracle import Oracle, SQ_IEEE
-    from diral_amd.config import KERNEL_GENERAL, KERNEL_RING, KERNEL_WIDE
+    from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RING, KERNEL_WIDE
     cfg = bench_config(N, A, L, mobility_vary=True, communication_range=Rc)
     B = 4
     rng = np.random.default_rng(N * 7 + A)
@@ -1419,7 +1373,7 @@ def test_wide_xpos_ring_agrees_with_the_oracle_through_every_consumer(N, A, L, R
         general = t in (13, 14, 37) or 55 <= t < 58                  # the general kernel takes over for some slots
         env.force_general_kernel(general)
         obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, acts, t)
-        assert (env.last_kernel() & (15 | KERNEL_RING)) == (KERNEL_GENERAL if general else KERNEL_WIDE | KERNEL_RING)
+        assert (env.last_kernel() & (15 | KERNEL_RING)) == (KERNEL_GENERAL if general else _fam(N) | KERNEL_RING)
         o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, t)
         o_state = orc.obtain_state(acts, o_chobs, o_rew)
         assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
