@@ -21,6 +21,12 @@
 
 #include "../../include/diral_env.h"
 
+// rare paths (IEEE sqrt, fmod, exp, reward weights) are kept out of line: the fused kernels were
+// instruction-fetch bound when these were inlined (profiles/README.md)
+#ifndef DIRAL_OUTLINE
+#define DIRAL_OUTLINE __attribute__((noinline))
+#endif
+
 namespace diral {
 
 constexpr int kModeObserve = 3;  // internal: obtain_state only

@@ -210,7 +210,7 @@ __device__ inline double fast_dist(double x1, double y1, double x2, double y2) {
 // Reward of a colliding resource (test_env.py:163-199) incl.
 // Network.calculate_reward_weights (network.py:273-300); wave-uniform, positions
 // broadcast from lanes.  Out of line: runs ~once per colliding resource.
-__device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
+__device__ DIRAL_OUTLINE double fast_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
                                                                   unsigned long long mk, int c, double mypx,
                                                                   double mypy) {
   int wgt = 0;
@@ -226,7 +226,7 @@ __device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32
       while (mb) {
         const int b = __builtin_ctzll(mb);
         mb &= mb - 1;
-        s = s + dist2d(xa, ya, readlane_f64(mypx, b), readlane_f64(mypy, b));
+        s = s + dist2d_leaf(xa, ya, readlane_f64(mypx, b), readlane_f64(mypy, b));
         ++cnt;
       }
     }
@@ -239,7 +239,7 @@ __device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32
         if (x < x_min) { x_min = x; umin = u; }
         if (x > x_max) { x_max = x; umax = u; }
       }
-      wgt = (m == dist2d(readlane_f64(mypx, umin), readlane_f64(mypy, umin), readlane_f64(mypx, umax),
+      wgt = (m == dist2d_leaf(readlane_f64(mypx, umin), readlane_f64(mypy, umin), readlane_f64(mypx, umax),
                          readlane_f64(mypy, umax)));
     } else {
       wgt = (m > Rc);
@@ -254,7 +254,7 @@ __device__ __attribute__((noinline)) double fast_collision_reward(int rd, uint32
 
 // my_step_ch reward of one transmitter (test_env.py:411-429) from its reception ratio
 // R = received / in_range (1 for a sole transmitter).  Out of line: exp().
-__device__ __attribute__((noinline)) double fast_ch_reward(int rd, bool collided, double R) {
+__device__ DIRAL_OUTLINE double fast_ch_reward(int rd, bool collided, double R) {
   if (collided) {
     if (rd == 3) return 1.0 - exp(1.0 - R);
     if (rd == 4) return -1.0 * exp(1.0 - R);
@@ -310,6 +310,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   const bool live = lane < N;
   constexpr int NV = 64;                       // padded viewer stride (host guarantees p.NV == 64)
   DIRAL_FSTAMP(0);
+#ifdef DIRAL_TIMING
+  if (lane == 0 && p.dbg) {     // where this wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, behind the stamps
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.dbg[(size_t)gridDim.x * 32 + (size_t)b * 4 + wave] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   // ---- P0: per-vehicle state straight into registers (every wave, lane = vehicle)
   // (unconditional, index-clamped loads pinned ahead of the table loads: vmcnt

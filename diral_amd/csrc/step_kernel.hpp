@@ -65,7 +65,7 @@ struct Geo {
 // binary64 (no over/underflow for 2^-500 <= |dx| <= 2^500), so the sqrt is skipped.
 // rare general paths are kept out of line so the hot code stays compact
 // (the fused kernels were instruction-fetch bound when these were inlined)
-__device__ __attribute__((noinline)) double dist_general(double dx, double dy) {
+__device__ DIRAL_OUTLINE double dist_general(double dx, double dy) {
   return __builtin_sqrt(dx * dx + dy * dy);
 }
 __device__ inline double dist2d(double x1, double y1, double x2, double y2) {
@@ -76,9 +76,19 @@ __device__ inline double dist2d(double x1, double y1, double x2, double y2) {
   return dist_general(dx, dy);
 }
 
+// dist2d for the out-of-line reward functions: the IEEE sqrt is inlined so that they stay LEAF functions - a nested
+// call makes the callee save its return address through a callee-saved VGPR in scratch memory, and a kernel that
+// may reach such a callee carries a private segment (16 B / lane) for every wave it launches
+__device__ inline double dist2d_leaf(double x1, double y1, double x2, double y2) {
+  const double dx = x2 - x1, dy = y2 - y1;
+  const double ax = __builtin_fabs(dx);
+  if (dy == 0.0 && (ax == 0.0 || (ax >= 0x1p-500 && ax <= 0x1p500))) return ax;
+  return __builtin_sqrt(dx * dx + dy * dy);
+}
+
 // Python float `%` for the position wrap (network.py:203): fast exact path when
 // 0 <= s <= 2L (Sterbenz), generic fmod + sign fix-up otherwise.
-__device__ __attribute__((noinline)) double py_mod_general(double s, double L) {
+__device__ DIRAL_OUTLINE double py_mod_general(double s, double L) {
   double m = fmod(s, L);
   if (m != 0.0) { if ((L < 0) != (m < 0)) m += L; } else { m = copysign(0.0, L); }
   return m;

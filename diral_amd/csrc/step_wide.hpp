@@ -210,7 +210,7 @@ __device__ inline void unpack_src(unsigned int mw, unsigned int (&a)[VPL]) {
 // Reward of a colliding resource (test_env.py:163-199) for N > 64, positions in
 // LDS, all y == 0.  Out of line: runs ~once per colliding resource.
 template <int VPL>
-__device__ __attribute__((noinline)) double wide_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
+__device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, double L, double Rc, int N,
                                                                   const unsigned long long* mkp, int c,
                                                                   const double* s_px) {
   int wgt = 0;
@@ -227,7 +227,7 @@ __device__ __attribute__((noinline)) double wide_collision_reward(int rd, uint32
           while (mb) {
             const int b = jb * 64 + __builtin_ctzll(mb);
             mb &= mb - 1;
-            s = s + dist2d(s_px[a], 0.0, s_px[b], 0.0);
+            s = s + dist2d_leaf(s_px[a], 0.0, s_px[b], 0.0);
             ++cnt;
           }
         }
@@ -242,7 +242,7 @@ __device__ __attribute__((noinline)) double wide_collision_reward(int rd, uint32
         if (x < x_min) { x_min = x; umin = u; }
         if (x > x_max) { x_max = x; umax = u; }
       }
-      wgt = (m == dist2d(s_px[umin], 0.0, s_px[umax], 0.0));
+      wgt = (m == dist2d_leaf(s_px[umin], 0.0, s_px[umax], 0.0));
     } else {
       wgt = (m > Rc);
     }

@@ -56,3 +56,36 @@ span = t[:, :, 7].max() - t[:, :, 0].min()
 print("  kernel span %d ticks" % span)
 start = t[:, 0, 0] - t[:, 0, 0].min()
 print("  WG start time percentiles (ticks):", [int(np.percentile(start, q)) for q in (0, 25, 50, 75, 100)])
+# occupancy timeline per XCD (the s_memtime counters of different XCDs are not aligned): HW_ID / XCC_ID of every wave
+# sit behind the stamps (c2 / DIRAL_TIMING build only)
+if WL == "c2":
+    full = np.zeros((B * 4096,), np.uint64)
+    assert fn(env._h, full.ctypes.data_as(ctypes.c_void_p), 512) == 0
+    ids = full[B * 32:B * 32 + B * 4].reshape(B, 4)
+    hw = (ids & np.uint64(0xffffffff)).astype(np.int64)
+    xcc = (ids >> np.uint64(32)).astype(np.int64) & 15
+    cu = (hw >> 8) & 15
+    se = (hw >> 13) & 7
+    sh = (hw >> 12) & 1
+    print("  XCC ids %s  SE ids %s  SH ids %s  CU ids %s" % (sorted(set(xcc[:, 0].tolist())), sorted(set(se[:, 0].tolist())),
+                                                             sorted(set(sh[:, 0].tolist())), sorted(set(cu[:, 0].tolist()))))
+    ws = t[:, :, 0].min(axis=1)
+    we = t[:, :, 7].max(axis=1)
+    grp = xcc[:, 0] * 8 + se[:, 0]                 # s_memtime is per (XCC, shader engine)
+    for x in sorted(set(grp.tolist()))[:3]:
+        idx = np.nonzero(grp == x)[0]
+        t0 = ws[idx].min()
+        s_ = (ws[idx] - t0).astype(np.float64)
+        e_ = (we[idx] - t0).astype(np.float64)
+        sp = e_.max()
+        bins = np.linspace(0, sp, 25)
+        alive = [int(((s_ < hi) & (e_ > lo)).sum()) for lo, hi in zip(bins[:-1], bins[1:])]
+        ncu = len(set(zip(se[idx, 0].tolist(), sh[idx, 0].tolist(), cu[idx, 0].tolist())))
+        print("  XCC*8+SE %d: %d WGs on %d CUs (WG ids mod 8: %s); span %d ticks; alive per 1/24 of the span: %s" % (
+            x, len(idx), ncu, sorted(set((idx % 8).tolist())), sp, alive))
+        print("     WG start percentiles %s\n     end percentiles %s" % (
+            [int(np.percentile(s_, q)) for q in (0, 10, 25, 50, 75, 90, 100)], [int(np.percentile(e_, q)) for q in (0, 10, 25, 50, 75, 90, 100)]))
+        per_cu = {}
+        for i in idx:
+            per_cu.setdefault((int(se[i, 0]), int(sh[i, 0]), int(cu[i, 0])), []).append(i)
+        print("     WGs per CU: min %d max %d" % (min(len(v) for v in per_cu.values()), max(len(v) for v in per_cu.values())))
