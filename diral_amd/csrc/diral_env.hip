@@ -264,7 +264,7 @@ hipError_t launch_observe_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   o.actions = p.actions; o.chobs_in = p.chobs_in; o.rew_in = p.rew_in;
   o.pos_x = p.pos_x; o.pos_y = p.pos_y; o.vel = p.vel; o.tkey = p.tkey; o.tx = p.tx;
   o.ring = use_ring ? e->ring : nullptr;
-  const bool packed = use_ring && e->tcode != nullptr;           // N <= 64: codes, ages, own sequence numbers
+  const bool packed = use_ring && e->tcode != nullptr;           // codes, ages, own sequence numbers
   o.tcode = packed ? e->tcode : nullptr; o.tage = packed ? e->tage : nullptr; o.tseq = packed ? e->tseq : nullptr;
   o.edges = p.edges; o.inv_tab = e->inv_tab; o.err = p.err; o.state_out = p.state_out;
   const RichParams r = rich_for(e, p);
@@ -354,7 +354,7 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   q.off_posdist = p.off_posdist; q.off_hist = p.off_hist;
   q.pos_x = p.pos_x; q.pos_y = p.pos_y; q.tkey = p.tkey; q.tx = p.tx; q.edges1 = e->edges1; q.state_out = p.state_out;
   q.do_full = 0; q.do_type1 = 0; q.ring = nullptr;
-  if (type1 && e->tcode) {                                      // N <= 64: the packed table -> planes first
+  if (type1 && e->tcode) {                                      // the packed table -> planes first
     const hipError_t st = ensure_plane(e, s);
     if (st != hipSuccess) return st;
   }
@@ -522,16 +522,17 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
-    if (e->vpl == 1) {                                          // the packed table of step_fast64
+    if (e->vpl != 2) {                                          // the packed table of step_fast64 and of step_wide at N > 128
+      // (+ 512 words of slack: step_wide.hpp loads a padded viewer slot past the end of a row without clamping)
       const size_t nq = (size_t)e->B * (e->NR / 4);
-      CREATE_TRY(alloc((void**)&e->tcode, nq * e->NV * 4));
-      CREATE_TRY(alloc((void**)&e->tage, nq * e->NV * 4));
-      CREATE_TRY(alloc((void**)&e->tseq, (size_t)e->B * e->NR * 4));
-      CREATE_TRY(alloc((void**)&e->told, nq * 4));
-      CREATE_TRY(hipMemset(e->tcode, 0, nq * e->NV * 4));
-      CREATE_TRY(hipMemset(e->tage, 0, nq * e->NV * 4));
-      CREATE_TRY(hipMemset(e->tseq, 0, (size_t)e->B * e->NR * 4));
-      CREATE_TRY(hipMemset(e->told, 0, nq * 4));
+      CREATE_TRY(alloc((void**)&e->tcode, (nq * e->NV + 512) * 4));
+      CREATE_TRY(alloc((void**)&e->tage, (nq * e->NV + 512) * 4));
+      CREATE_TRY(alloc((void**)&e->tseq, ((size_t)e->B * e->NR + 64) * 4));
+      CREATE_TRY(alloc((void**)&e->told, (nq + 16) * 4));
+      CREATE_TRY(hipMemset(e->tcode, 0, (nq * e->NV + 512) * 4));
+      CREATE_TRY(hipMemset(e->tage, 0, (nq * e->NV + 512) * 4));
+      CREATE_TRY(hipMemset(e->tseq, 0, ((size_t)e->B * e->NR + 64) * 4));
+      CREATE_TRY(hipMemset(e->told, 0, (nq + 16) * 4));
     }
     e->ring_valid = true;                                       // all tables zero: never heard, age 0, xpos 0
   }

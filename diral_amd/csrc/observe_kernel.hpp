@@ -144,23 +144,25 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
       }
     };
     if (p.tcode) {
-      // the packed table (N <= 64): one code word + one age word per row-quad and viewer = four entries
+      // the packed table: one code word + one age word per row-quad and viewer = four entries
       const size_t bQ = (size_t)b * (p.NR >> 2);
       const int nq = (N + 3) >> 2;
       for (int u = lane; u < N; u += 64) {
         const double mx = s_px[u], my = s_py[u];
         unsigned int mycnt = 0u;
         unsigned int* const hrow = s_hist + u * KP;
+#pragma unroll 1
+        for (int qb = wave; qb < nq; qb += RW * 4) {
         unsigned int cv[4], av[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int q = wave + RW * i;
+          const int q = qb + RW * i;
           cv[i] = p.tcode[(bQ + (q < nq ? q : 0)) * NV + u];
           av[i] = p.tage[(bQ + (q < nq ? q : 0)) * NV + u];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int q = wave + RW * i;
+          const int q = qb + RW * i;
           if (q >= nq) break;                                          // wave-uniform
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
             }
             entry(u, k, mx, my, age, heard, xg, hrow, mycnt);
           }
+        }
         }
         if (mycnt) atomicAdd(&s_cnt[u], mycnt);
       }

@@ -564,7 +564,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
   const bool lds_base_is_zero = __builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u;
   const double inv_w = p.inv_w;
-  const global_ptr<double> ringp = uniform_ptr(((LateFastArgs)late_kernarg_base())->ring, 0);
+  const LateFastArgs lpp = (LateFastArgs)late_kernarg_base();      // the packed planes: late-bound kernel arguments
+  const global_ptr<double> ringp = uniform_ptr(lpp->ring, 0);
+  unsigned int* const g_tcode = lpp->tcode;
+  unsigned int* const g_tage = lpp->tage;
+  unsigned int* const g_tseq = lpp->tseq;
+  unsigned int* const g_told = lpp->told;
 
   // resources with at least one transmitter, as a wave-uniform bit word (A <= 64)
   unsigned long long actw;
@@ -589,14 +594,17 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (unchanged lanes rewrite their value): a lane-masked store leaves partially written
   // 32-byte sectors, which HBM turns into read-modify-write - measured 1.4x the traffic.
   // xmode 1 (xpos ring): only the lanes with `upd` set store (an entry at lag 7 or a copy of an older one: rare);
-  // xmode 2: every lane stores.
+  // xmode 2: every lane stores.  xmode 3: a coded entry of the packed table - both planes only at the hand-over.
   auto emit = [&](int k, bool kvalid, int j, bool upd, unsigned int wn, double xg, global_ptr<unsigned int> tkrow,
                   global_ptr<double> txrow, auto xmode_tag) {
     constexpr int XMODE = decltype(xmode_tag)::value;
     const int u = lane + 64 * j;
     const bool lv = FULL || ((u < N) && kvalid);
     const bool slot_upd = XMODE == 0 ? (__ballot(upd || u == k) != 0ull) : (XMODE == 2 || upd);
-    if (lv) {
+    if constexpr (XMODE == 3) {
+      // coded entry (packed table): nothing goes to the planes, except at the hand-over (`upd`: the entry is now 7 behind)
+      if (lv && upd) { tkrow[(unsigned int)u] = wn; txrow[(unsigned int)u] = xg; }
+    } else if (lv) {
       tkrow[(unsigned int)u] = wn;
       if (slot_upd) txrow[(unsigned int)u] = xg;
     }
@@ -633,6 +641,663 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   bool ovf = false;
   unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, acc_load = 0, acc_merge = 0, acc_fin = 0, t_p3 = 0;
   DIRAL_WCLOCK(t_p3);
+  // N <= 256 (VPL == 4, BASELINE configs[2]): the PACKED table - codes, ages, own sequence numbers (below).
+  // N <= 128 (VPL == 2, configs[4]): the (seq, age) plane `tkey` as in round 2.  At that density 2 % of the entries
+  // lag more than 7 stamps (profiles/lag_distribution.py) - most passes of 8 x 128 entries hold one - which the
+  // 8-level codes cannot carry: the passes keep re-deriving the lags from the words every slot and fall back to byte
+  // ranks in place (measured: the packed form, with its detour through the planes for such passes, C5 + 13 %).
+  if constexpr (VPL == 4) {
+  unsigned int passbits = 0u;                      // bit pch: a quad of pass pch was flagged when the slot began
+#pragma unroll 1
+  for (int pch = 0; pch < CPW / PC; ++pch) {
+    const int kbase = wave * CPW + pch * PC;
+    if (kbase >= p.NR) break;
+    if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
+    // The table is stored the way the merge wants it (round 3, as in step_fast64.hpp): per row-quad and viewer one word
+    // of four thermometer codes of the entries' lags (0 = never heard, or older than 7: then `tkey` holds its
+    // sequence number) and one word of four ages; `tseq` holds the subjects' own sequence numbers, `told` flags the
+    // quads with an entry beyond the codes.  A pass of PC columns = NW quads:
+    //  * clean quads: the stamp (vehicle.py:56-70) is a shift of the code words + a packed age increment, the merge
+    //    ORs the words, and what goes back to HBM are the merged code words and the age words - the planes `tkey` /
+    //    `tx` are neither read nor written, except where an entry reaches lag 7 (hand-over: sequence number to
+    //    `tkey`, xpos to `tx`, quad flagged);
+    //  * a flagged quad: the pass goes through the planes - its entries are written to `tkey` as (seq, age) words
+    //    (unstamped), the byte-rank / 32-bit pass of round 2 runs on them unchanged, and the packed words are
+    //    rebuilt from the words it leaves.  Rare, and kept apart so that the coded pass owns its registers.
+    const size_t qrow = (size_t)b * (p.NR >> 2) + (kbase >> 2);
+    const global_ptr<unsigned int> tcrow = uniform_ptr(g_tcode, qrow * NV);
+    const global_ptr<unsigned int> tarow = uniform_ptr(g_tage, qrow * NV);
+    const global_ptr<unsigned int> tsrow = uniform_ptr(g_tseq, bR + kbase);
+    bool clean;
+    {
+      const global_ptr<const unsigned int> tof = uniform_ptr<const unsigned int>(g_told, qrow);
+      unsigned int anyold = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) anyold |= tof[w];
+      clean = __builtin_amdgcn_readfirstlane((int)anyold) == 0;
+    }
+    passbits |= (clean ? 0u : 1u) << pch;
+    if (!clean) continue;                        // (flagged passes: the second loop below)
+    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 codes each; ages, same packing
+    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
+    DIRAL_WCLOCK(tc0);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        kp[w * VPL + j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
+        agew[w * VPL + j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
+      }
+    {
+      const unsigned int ts = tsrow[ul < (unsigned int)PC ? ul : 0u];
+      tkov = ul < (unsigned int)PC ? ts + 1u : 0u;
+      if (ul < (unsigned int)PC) tsrow[ul] = tkov;
+      ovf = ovf || (tkov >= (1u << 24) - 1u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Vehicle.periodic_update (vehicle.py:56-70): every lag + 1 (a shift), every age + 1 (saturating, packed), the
+    // own entry: lag 0 / age 0.  Padded viewer slots (u >= N) read whatever lies behind the row: masked to 0.
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const bool uval = FULL || (lane + 64 * j < N);
+        const unsigned int c0 = uval ? kp[w * VPL + j] : 0u, a = uval ? agew[w * VPL + j] : 0u;
+        kp[w * VPL + j] = (c0 << 1) & 0xfefefefeu;
+        const unsigned int hi = a & 0x80808080u, lo = (a & 0x7f7f7f7fu) + 0x01010101u, sat = lo & hi;
+        agew[w * VPL + j] = (lo ^ hi) | sat | (sat - (sat >> 7));
+      }
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const int k = kbase + c;
+      const bool own = (FULL || k < N) && (lane == (k & 63));
+      const unsigned int ob = own ? (0xffu << (8 * (c & 3))) : 0u;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
+          kp[(c >> 2) * VPL + j] |= ob;
+          agew[(c >> 2) * VPL + j] &= ~ob;
+        }
+      }
+    }
+    DIRAL_WCLOCK(tc1);
+    {
+      constexpr bool thermo = true;
+      unsigned int kp0[NK];                      // the codes before the merge
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
+      // -- Vehicle.received_update for every (resource, rx), resources ascending:
+      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
+      if constexpr (!VEC) {
+        // plane layout sw[word][viewer]: one 4-byte gather per word and slot
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+        wave_lds_order();
+        auto merge_loop = [&](auto wtag, auto ttag) {
+          constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
+          constexpr bool THERMO = decltype(ttag)::value;
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, 2u>(mw, sa);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+#pragma unroll
+              for (int w = 0; w < NW; ++w)
+                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(SCR * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
+                                      : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
+            }
+            // a transmitter's words are not written during its own resource, so all
+            // gathers of a step may precede all its writes
+            wave_lds_order();
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
+            lds_store4_lane_linear(sw_lds, kp);     // (ds_write_addtid_b32: no address VGPR, half the LDS store cycles) sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
+            wave_lds_order();
+          }
+        };
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+      } else {
+        // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
+        // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
+        // wider pass halves the number of chains a wave walks per column.
+        typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
+        uvec* const sv = reinterpret_cast<uvec*>(sw);
+        auto put = [&]() {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            uvec t;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
+            sv[lane + 64 * j] = t;
+          }
+        };
+        put();
+        wave_lds_order();
+        auto merge_loop = [&](auto wtag, auto ttag) {
+          constexpr int W = decltype(wtag)::value;
+          constexpr bool THERMO = decltype(ttag)::value;
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
+#pragma unroll
+              for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
+            }
+            wave_lds_order();
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
+            put();
+            wave_lds_order();
+          }
+        };
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+      }
+      DIRAL_WCLOCK(tc2);
+
+      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
+      //    extraction).  The code -> xpos table of the column: the subject's 8 latest stamps from its ring row
+      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass); EVERY coded entry reads its
+      //    xpos by its final code, a never-heard one (code 0) its ghost xpos from the plane.
+      double rg = 0.0;
+      {
+        const unsigned int rc = ul >> 3, rl = ul & 7u;
+        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
+        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
+      }
+      // ages of updated entries cleared with a byte mask of the code bytes that changed; the two words go back
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        const unsigned int x = kp[q] ^ kp0[q];
+        const unsigned int nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+        agew[q] &= ~(nz | (nz - (nz >> 7)));
+      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          if (FULL || lane + 64 * j < N) {
+            tcrow[(unsigned int)(w * NV) + ul + 64u * j] = kp[w * VPL + j];
+            tarow[(unsigned int)(w * NV) + ul + 64u * j] = agew[w * VPL + j];
+          }
+        }
+      bool handw[NW];                              // a lane handed an entry of the quad over (now 7 behind)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) handw[w] = false;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll FIN_UNROLL
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * w + cc;
+        const int k = kbase + c;
+        const bool kvalid = FULL || k < N;
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        const double pxk = s_px[kvalid ? k : 0];
+        if ((ul >> 3) == (unsigned int)c) {
+          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
+          const unsigned int l = ul & 7u;
+          xt[(0xffu << l) & 0xffu] = (l == 0u) ? pxk : rg;
+          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int rf = pick(kp, j, w, cc);
+          double xg = xt[rf];
+          if (rf == 0u) xg = txrow[ul + 64u * j];                       // never heard: the ghost xpos lives in the plane
+          // sequence number back from the code (lag = 8 - popcount)
+          const unsigned int seqf = rf ? tk_own - 8u + (unsigned int)__popc(rf) : 0u;
+          const unsigned int wn = (seqf << 8) | pick(agew, j, w, cc);
+          const bool at7 = rf == 0x80u;                                 // from the next slot on beyond the codes: hand over
+          emit(k, kvalid, j, at7, wn, xg, tkrow, txrow, std::integral_constant<int, 3>{});
+          handw[w] = handw[w] || (at7 && (FULL || (lane + 64 * j < N && kvalid)));
+        }
+        wave_lds_order();
+      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        if (__ballot(handw[w]) != 0ull && lane == 0) g_told[qrow + w] = 1u;
+      }
+    }
+#ifdef DIRAL_TIMING
+    DIRAL_WCLOCK(tc3);
+    acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
+#endif
+  }
+  // ---- flagged passes (a quad with an entry beyond the codes): through the planes, in a loop of their own so that
+  //      the coded pass above carries none of this path's registers
+#pragma unroll 1
+  for (int pch = 0; pch < CPW / PC; ++pch) {
+    const int kbase = wave * CPW + pch * PC;
+    if (kbase >= p.NR) break;
+    if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
+    const size_t qrow = (size_t)b * (p.NR >> 2) + (kbase >> 2);
+    const global_ptr<unsigned int> tcrow = uniform_ptr(g_tcode, qrow * NV);
+    const global_ptr<unsigned int> tarow = uniform_ptr(g_tage, qrow * NV);
+    const global_ptr<unsigned int> tsrow = uniform_ptr(g_tseq, bR + kbase);
+    {
+      // (the flags as the previous slot left them: the coded loop above only ever SETS flags of clean quads it
+      // handed an entry over in - those passes ran there and must not run again)
+      if (((passbits >> pch) & 1u) == 0u) continue;
+#ifdef DIRAL_WIDE_NO_FLAGGED
+      continue;   // (compile-time probe: the coded loop's own register needs)
+#endif
+    }
+    // ---- flagged pass: through the planes ------------------------------------------------------------------
+    {
+      // the pass's entries as (seq, age) words, unstamped: coded ones from the subject's own number and the lag,
+      // code-0 ones keep the sequence number `tkey` holds (0: never heard); ages from the age words
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        unsigned int cwj[VPL], awj[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          cwj[j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
+          awj[j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
+        }
+#pragma unroll 1
+        for (int cc = 0; cc < 4; ++cc) {
+          const int k = kbase + 4 * w + cc;
+          if (!(FULL || k < N)) continue;
+          const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+          const unsigned int ts_old = tsrow[4 * w + cc];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            if (FULL || u < N) {
+              const unsigned int r = (cwj[j] >> (8 * cc)) & 255u, a = (awj[j] >> (8 * cc)) & 255u;
+              const unsigned int seq = r ? ts_old - 8u + (unsigned int)__popc(r) : (tkrow[(unsigned int)u] >> 8);
+              tkrow[(unsigned int)u] = (seq << 8) | a;
+            }
+          }
+        }
+      }
+      wave_lds_order();
+    }
+    // One packed pass, ONE body for both packed representations (two copies of it cost 12 more spilled
+    // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
+    // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are
+    // simply repeated with the other pair of constants.  Only the merge loop exists per representation.
+    bool thermo = false;                         // (a flagged pass: the codes do not reach - byte ranks, then 32-bit keys)
+    bool packed_ok;
+    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 lag bytes (then codes / ranks) each; ages, same packing
+    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
+    for (;;) {
+    const unsigned int lag_clamp = thermo ? 12u : 255u, lag_limit = thermo ? 8u : 255u;
+    DIRAL_WCLOCK(tc0);
+    // -- load + Vehicle.periodic_update (vehicle.py:56-70), lags behind the subject's
+    //    own fresh sequence number
+#pragma unroll
+    for (int q = 0; q < NK; ++q) { kp[q] = 0u; agew[q] = 0u; }
+    tkov = 0u;
+    bool bad = false;
+    // (16 table words in flight at a time: LC columns x VPL slots)
+    constexpr int LC = DIRAL_WIDE_INFLIGHT / VPL;
+#pragma unroll
+    for (int c0 = 0; c0 < PC; c0 += LC) {
+    unsigned int wraw[LC * VPL];
+#pragma unroll
+    for (int c = 0; c < LC; ++c) {
+      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c0 + c) * NV);   // rows are padded to 16: in bounds
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = c0; c < c0 + LC; ++c) {
+      const int k = kbase + c;
+      const bool kval = FULL || k < N;
+      unsigned int seq[VPL], age[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;
+        const unsigned int w = (FULL || (kval && u < N)) ? wraw[(c - c0) * VPL + j] : 0u;
+        seq[j] = w >> 8;
+        const unsigned int a0 = w & 255u;
+        age[j] = a0 + (a0 < 255u ? 1u : 0u);
+        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
+          const bool own = kval && (lane == (k & 63));
+          seq[j] += own ? 1u : 0u;
+          age[j] = own ? 0u : age[j];
+          ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
+        }
+      }
+      unsigned int t = 0u;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)seq[j], k & 63);
+        t = ((k >> 6) == j) ? cand : t;
+      }
+      tkov = (lane == c) ? t : tkov;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        // codes: lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); ranks: 0..254, or 255 =
+        // never heard; anything else is not exact in that representation
+        const unsigned int lagc = min(t - seq[j], lag_clamp);
+        // ('||' / '&&' compile to exec-mask control flow per entry, the bitwise form to straight-line code: the
+        // latter is 8 % faster on the plain N <= 128 kernel, 4 % slower on its RICH instantiation and 25 % SLOWER at
+        // N <= 256 - register allocation - so each gets the form that measured best)
+        if constexpr (VPL == 2 && !RICH) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
+        else bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
+        kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
+        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    }
+    // (pinned packed words: left alone, the compiler sinks the packing below the exit test and keeps all
+    // PC x VPL lags alive across it)
+    if constexpr (VPL == 2) {
+#pragma unroll
+      for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
+    }
+    packed_ok = (__ballot(bad) == 0ull);
+    DIRAL_WCLOCK(tc1);
+    if (packed_ok || !thermo) break;
+    thermo = false;
+    }
+    if (packed_ok) {
+      // lag bytes -> thermometer codes, or byte ranks 255 - lag (the complement; 255 -> 0: never heard)
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kp[q] = thermo ? thermo_codes(kp[q]) : ~kp[q];
+      const unsigned int seq_base = thermo ? 8u : 255u;
+      unsigned int kp0[NK];                      // the ranks before the merge
+#pragma unroll
+      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
+      // -- Vehicle.received_update for every (resource, rx), resources ascending:
+      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
+      if constexpr (!VEC) {
+        // plane layout sw[word][viewer]: one 4-byte gather per word and slot
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
+        wave_lds_order();
+        auto merge_loop = [&](auto wtag, auto ttag) {
+          constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
+          constexpr bool THERMO = decltype(ttag)::value;
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, 2u>(mw, sa);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+#pragma unroll
+              for (int w = 0; w < NW; ++w)
+                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(SCR * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
+                                      : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
+            }
+            // a transmitter's words are not written during its own resource, so all
+            // gathers of a step may precede all its writes
+            wave_lds_order();
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
+            lds_store4_lane_linear(sw_lds, kp);     // (ds_write_addtid_b32: no address VGPR, half the LDS store cycles) sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
+            wave_lds_order();
+          }
+        };
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
+        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
+      } else {
+        // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
+        // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
+        // wider pass halves the number of chains a wave walks per column.
+        typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
+        uvec* const sv = reinterpret_cast<uvec*>(sw);
+        auto put = [&]() {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            uvec t;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
+            sv[lane + 64 * j] = t;
+          }
+        };
+        put();
+        wave_lds_order();
+        auto merge_loop = [&](auto wtag, auto ttag) {
+          constexpr int W = decltype(wtag)::value;
+          constexpr bool THERMO = decltype(ttag)::value;
+          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
+          unsigned long long rem = actw;
+          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
+          while (rem) {
+            rem &= rem - 1;
+            const unsigned int mw = m_next;
+            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+            unsigned int v[NK], sa[VPL];
+            unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
+#pragma unroll
+              for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
+            }
+            wave_lds_order();
+            if constexpr (THERMO) {
+#pragma unroll
+              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
+            } else {
+              max_u8_words<NK>(kp, v);
+            }
+            put();
+            wave_lds_order();
+          }
+        };
+        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
+        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
+        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
+        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
+      }
+      DIRAL_WCLOCK(tc2);
+
+      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
+      //    extraction).  The rank -> xpos table of the column: the subject's 8 latest stamps from its ring row
+      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass), the few older entries
+      //    scatter their xpos from the plane; then EVERY entry reads its xpos by its final rank.
+      double rg = 0.0;
+      {
+        const unsigned int rc = ul >> 3, rl = ul & 7u;
+        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
+        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
+      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll FIN_UNROLL
+      for (int cc = 0; cc < 4; ++cc) {
+        const int c = 4 * w + cc;
+        const int k = kbase + c;
+        const bool kvalid = FULL || k < N;
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
+        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+        const double pxk = s_px[kvalid ? k : 0];
+        if ((ul >> 3) == (unsigned int)c) {
+          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
+          const unsigned int l = ul & 7u;
+          xt[thermo ? ((0xffu << l) & 0xffu) : 255u - l] = (l == 0u) ? pxk : rg;
+          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
+        }
+        unsigned int rank0[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          rank0[j] = pick(kp0, j, w, cc);
+          // older than the ring reaches (codes: only the never-heard entries): the plane holds its xpos
+          const bool old = thermo ? rank0[j] == 0u : rank0[j] <= 247u;
+          if (old && (FULL || (u < N && kvalid))) xt[rank0[j]] = txrow[ul + 64u * j];
+        }
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int rf = pick(kp, j, w, cc);
+          const double xg = xt[rf];
+          const bool upd = rf != rank0[j];
+          // sequence number back from the rank / from the code (lag = 8 - popcount)
+          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
+          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, w, cc));
+          // the plane must hold the xpos of every entry the ring may not reach next slot: an entry that is now 7
+          // behind, or a fresh copy of an older one
+          const bool at7 = thermo ? rf == 0x80u : rf == 248u;
+          const bool far = thermo ? rf == 0x80u : (rf != 0u && rf <= 248u);
+          emit(k, kvalid, j, far && (upd || at7), wn, xg, tkrow, txrow, std::integral_constant<int, 1>{});
+        }
+        wave_lds_order();
+      }
+    } else {
+      // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
+      //    very stale tables: an entry with lag >= 255 and seq != 0)
+      DIRAL_WCLOCK(tc2);
+      double* const sx = xt;
+#pragma unroll 1
+      for (int c = 0; c < PC; ++c) {
+        const int k = kbase + c;
+        const bool kvalid = k < N;
+        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
+        unsigned int ws[VPL], key[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          const bool lv = (u < N);
+          unsigned int w = tkrow[lv ? u : 0];
+          w = (lv && kvalid) ? w : 0u;
+          const bool own = lv && (u == k);
+          const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
+          const unsigned int a0 = w & 255u;
+          ws[j] = (seq << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
+          key[j] = (ws[j] & ~255u) | (unsigned int)u;
+          sw[u] = key[j];
+        }
+        wave_lds_order();
+        unsigned long long rem = actw;
+        while (rem) {
+          const int i = __builtin_ctzll(rem);
+          rem &= rem - 1;
+          const unsigned int mw = (unsigned int)s_mtab[i * MT + lane];
+          unsigned int v[VPL];
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) v[j] = sw[(mw >> (8 * j)) & 255u];
+          wave_lds_order();
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) { key[j] = max(key[j], v[j]); sw[lane + 64 * j] = key[j]; }
+          wave_lds_order();
+        }
+        const double pxk = s_px[kvalid ? k : 0];
+        double xo[VPL];
+        unsigned int tk_own = 0u;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(ws[j] >> 8), k & 63);
+          tk_own = ((k >> 6) == j) ? cand : tk_own;
+        }
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const int u = lane + 64 * j;
+          xo[j] = txrow[u < N ? u : 0];
+          // a young entry's xpos is in the subject's ring row, not (necessarily) in the plane
+          if (tk_own - (ws[j] >> 8) <= 7u) xo[j] = ringp[(size_t)(bR + (kvalid ? k : 0)) * 8 + ((ws[j] >> 8) & 7u)];
+          xo[j] = (u == k) ? pxk : xo[j];
+        }
+        if (lane == 0 && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;   // this slot's stamp (after the row was read)
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
+        wave_lds_order();
+        double xs[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) xs[j] = sx[key[j] & 255u];
+        wave_lds_order();
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
+          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow,
+               std::integral_constant<int, 2>{});   // with the ring: the plane complete for this column
+        }
+        wave_lds_order();
+      }
+    }
+    {
+      // the packed words again, from the (seq, age) words the pass left in `tkey`; the fresh sequence numbers;
+      // the flags of the next slot: an entry 7 or more behind keeps its quad on this path
+      if (ul < (unsigned int)PC) tsrow[ul] = tkov;
+      ovf = ovf || (ul < (unsigned int)PC && tkov >= (1u << 24) - 1u);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        unsigned int ncw[VPL], naw[VPL];
+        bool keep = false;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) { ncw[j] = 0u; naw[j] = 0u; }
+#pragma unroll 1
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = 4 * w + cc;
+          const int k = kbase + c;
+          if (!(FULL || k < N)) continue;
+          const global_ptr<const unsigned int> tkrow = uniform_ptr<const unsigned int>(p.tkey, (bR + k) * NV);
+          const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const int u = lane + 64 * j;
+            if (FULL || u < N) {
+              const unsigned int wk = tkrow[(unsigned int)u];
+              const unsigned int seqf = wk >> 8, lagf = tk_own - seqf;
+              ncw[j] |= ((seqf != 0u && lagf <= 7u) ? ((0xffu << lagf) & 0xffu) : 0u) << (8 * cc);
+              naw[j] |= (wk & 255u) << (8 * cc);
+              keep = keep || (seqf != 0u && lagf >= 7u);
+            }
+          }
+        }
+        const bool anyk = __ballot(keep) != 0ull;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          if (FULL || lane + 64 * j < N) {
+            tcrow[(unsigned int)(w * NV) + ul + 64u * j] = ncw[j];
+            tarow[(unsigned int)(w * NV) + ul + 64u * j] = naw[j];
+          }
+        }
+        if (lane == 0) g_told[qrow + w] = anyk ? 1u : 0u;
+      }
+    }
+      }
+  } else {
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
@@ -956,6 +1621,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     DIRAL_WCLOCK(tc3);
     acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
 #endif
+  }
   }
   if (ovf) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
 #ifdef DIRAL_TIMING
