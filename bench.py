@@ -203,15 +203,21 @@ def roofline_object(res, pmc):
     (diral_amd/roofline.py layout_bytes_per_env_slot: every 4-byte table key read and written once, the
     subjects' xpos rings, per-vehicle arrays, the outputs) over the kernel time measured in this run, over
     the 8 TB/s HBM peak - a fraction of the HBM roofline, <= 1 by construction.  `counter_frac`: the same
-    with the HBM bytes the PMC counters saw (committed passes).  The kernels are VALU-bound: `valu_busy`
-    is busy VALU cycles over elapsed CU cycles, both counted in the committed PMC passes.
+    with the HBM bytes the PMC counters saw (committed passes).  `bound` names the busiest pipe: `valu_busy` /
+    `lds_busy` are busy cycles over (shader clock x kernel duration), the clock from GRBM_GUI_ACTIVE of the same
+    session; `cu_busy` is the share of the kernel's duration a CU holds at least one wave (the 2.29-round tail of
+    4096 workgroups on 256 x 7 slots shows here).
     SURVEY 8d's canonical byte model (16-byte table entry) is reported as `model_*`: a throughput in the
     model's units, not an HBM utilisation (this layout does not move two thirds of those bytes)."""
     k_s = res["kernel_ms"] * 1e-3
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
-    pmc_ms = pmc.get("kernel_ms_profiled") if pmc else None
+    pmc_ms = (pmc.get("kernel_ms_traffic_passes") or pmc.get("kernel_ms_profiled")) if pmc else None
+    counter_frac = (traffic / ((pmc_ms or res["kernel_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None
+    # what limits: the busiest of the three pipes the committed counters cover (VALU, LDS, HBM)
+    pipes = {"valu": (pmc or {}).get("valu_busy") or 0.0, "lds": (pmc or {}).get("lds_busy") or 0.0,
+             "hbm": counter_frac or res["layout_rate_GBps"] / HBM_PEAK_GBPS}
     out = {
-        "bound": "valu" if (pmc and pmc.get("valu_busy", 0) >= 0.7) else "hbm",
+        "bound": max(pipes, key=pipes.get),
         "achieved": res["layout_rate_GBps"],
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
@@ -222,9 +228,10 @@ def roofline_object(res, pmc):
         "kernel": res["kernel"],
         "kernel_ms": res["kernel_ms"],
         "traffic": traffic,
-        "counter_frac": (traffic / ((pmc_ms or res["kernel_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+        "counter_frac": counter_frac,
         "valu_busy": pmc.get("valu_busy") if pmc else None,
         "lds_busy": pmc.get("lds_busy") if pmc else None,
+        "cu_busy": pmc.get("cu_busy") if pmc else None,
         "clock_GHz": pmc.get("clock_GHz") if pmc else None,
         "pmc_source": pmc.get("source") if pmc else None,
         "pmc_note": "traffic / valu_busy / clock_GHz come from the committed rocprofv3 --pmc passes of this command "

@@ -11,10 +11,11 @@ outputs:
 C2 (N=64, A=32, S=52): 155136 B/env-slot = 2424 B/agent-step.  This is the figure
 `roofline.achieved` is built from (the task's definition).
 
-The packed layout of this build moves fewer bytes: per table entry only the 4-byte key
-(sequence number, age) - the xpos of an entry that lags its subject by at most 7 stamps comes
+The layout of this build moves fewer bytes: per table entry one byte of thermometer code (the
+entry's lag behind its subject) and one byte of age (N <= 64 and N > 128; a 4-byte (seq, age)
+word for 64 < N <= 128) - the xpos of an entry that lags its subject by at most 7 stamps comes
 from an 8-deep per-subject ring (csrc/step_fast64.hpp, step_wide.hpp), and in
-steady state that is every entry; the per-entry xpos plane is touched only for older entries.
+steady state that is every entry; the per-entry planes are touched only for older entries.
 `layout_bytes_per_env_slot` is that figure (the rocprofv3 FETCH_SIZE / WRITE_SIZE counters show
 it plus the register-spill scratch of the kernel, profiles/README.md).  bench.py reports both;
 the layout figure over the kernel time is the real HBM rate.
@@ -26,9 +27,18 @@ def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
     return 2 * 16 * n * n + n * (4 + 16 + 8 + 8) + 4 * n * a + 4 * n + 4 * n * s
 
 
+def packed_table(n: int) -> bool:
+    """Which kernels store the table as packed codes + ages (2 B per entry): step_fast64 (N <= 64) and
+    step_wide at N > 128; N in (64, 128] keeps the 4-byte (seq, age) word (csrc/step_wide.hpp)."""
+    return n <= 64 or n > 128
+
+
 def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4) -> int:
-    """What csrc/step_fast64.hpp / step_wide.hpp move per env-slot in steady state: every table key read
-    and written once, the subjects' ring rows read and one stamp each written, the per-vehicle arrays, reward
-    and state, and the channel observation only when it is requested."""
-    table = 2 * 4 * n * n + 64 * n + 8 * n
+    """What csrc/step_fast64.hpp / step_wide.hpp HAVE to move per env-slot in steady state - the compulsory
+    bytes of this build's table layout: every table entry's stored form read and written once (packed: one
+    code byte + one age byte; else the 4-byte (seq, age) word), the subjects' ring rows read and one stamp each
+    written, the subjects' own sequence numbers (packed form), the per-vehicle arrays, reward and state, and
+    the channel observation only when it is requested."""
+    entry = 2 if packed_table(n) else 4
+    table = 2 * entry * n * n + 64 * n + 8 * n + (8 * n if packed_table(n) else 0)
     return table + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)
