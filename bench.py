@@ -390,6 +390,35 @@ def secondary_modes(device, envs=4096, slots=200, warm=100):
     return out
 
 
+def streamed_c2(device, groups, steps=600, warm=100):
+    """The c2 batch stepped as `groups` sub-batches on as many HIP streams (diral_amd/streamed.py): slot t + 1 of a
+    sub-batch only waits for slot t of the SAME sub-batch, so the tail of one launch overlaps with the head of the next.
+    Every env takes `steps` slots; state + reward + channel observation; wall time per slot of ALL envs.  A side
+    measurement: the headline stays the single launch whose outputs are complete, in stream order, after every step."""
+    from diral_amd.streamed import StreamedVecEnv
+    N, A, L, B, _ = WORKLOADS["c2"]
+    cfg = bench_config(N, A, L)
+    env = StreamedVecEnv(cfg, batch=B, groups=groups, device=device, out_dtype=torch.float32)
+    env.reset_topology(seed=GLOBAL_SEED)
+    acts = [env.sample(seed=1000 + i) for i in range(32)]
+    torch.cuda.synchronize(device)          # the pre-generated actions are complete: no per-slot hand-shake needed
+    for t in range(warm):
+        env.step(acts[t % 32], t, sync=False, actions_ready=True)
+    env.wait()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for t in range(warm, warm + steps):
+        env.step(acts[t % 32], t, sync=False, actions_ready=True)
+    env.wait()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    out = {"workload": "c2: %d-UE/%d-res, batch=%d as %d sub-batches on %d streams (no per-slot join)" % (N, A, B, groups, groups),
+           "agent_steps_per_s": B * N * steps / dt, "ms_per_step": dt / steps * 1e3}
+    env.close()
+    return out
+
+
 def short(res):
     """The keys of a secondary measurement that go into the JSON line (frac: this layout's compulsory
     bytes over the kernel time over the HBM peak, as in the main roofline object)."""
@@ -547,6 +576,9 @@ def main() -> int:
                 also["c2_sticky_0.9"] = short(r2)
                 also["c2_sticky_0.9"]["emit_chobs"] = emit
                 also["rollout_sps"] = rollout_sps(device)
+                torch.cuda.empty_cache()
+                also["c2_streams2"] = streamed_c2(device, 2)
+                also["c2_streams4"] = streamed_c2(device, 4)
                 torch.cuda.empty_cache()
                 also["secondary_observation_modes"] = secondary_modes(device)
                 torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ interface.  See DESIGN.md.
 from .config import (ConfigError, EnvConfig, StateConfig, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH,
                      bench_config, c2_config)
 
-__all__ = ["EnvConfig", "StateConfig", "ConfigError", "VecV2VEnv", "TestEnv", "bench_config", "c2_config",
+__all__ = ["EnvConfig", "StateConfig", "ConfigError", "VecV2VEnv", "StreamedVecEnv", "TestEnv", "bench_config", "c2_config",
            "STEP_MY_STEP", "STEP_MY_STEP_CH", "STEP_DESIGN"]
 
 
@@ -18,6 +18,9 @@ def __getattr__(name):
     if name == "VecV2VEnv":
         from .vec_env import VecV2VEnv
         return VecV2VEnv
+    if name == "StreamedVecEnv":
+        from .streamed import StreamedVecEnv
+        return StreamedVecEnv
     if name == "TestEnv":
         from .compat import TestEnv
         return TestEnv

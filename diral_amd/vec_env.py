@@ -79,7 +79,8 @@ class VecV2VEnv:
     def __init__(self, cfg: Union[EnvConfig, Mapping[str, Any]], batch: int = 1,
                  device: Union[str, int, torch.device] = "cuda:0",
                  out_dtype: torch.dtype = torch.float32, step_mode: Union[str, int] = "my_step",
-                 env_offset: int = 0, speculate_state: bool = True, io_ring: int = 1):
+                 env_offset: int = 0, speculate_state: bool = True, io_ring: int = 1,
+                 out_buffers: Optional[Mapping[str, Optional[torch.Tensor]]] = None):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_dict(cfg)
         cfg.validate()
@@ -117,11 +118,27 @@ class VecV2VEnv:
         if int(io_ring) < 1:
             raise ValueError("io_ring must be >= 1")
         self.io_ring = int(io_ring)
-        with torch.cuda.device(self.device):
-            self._ring = [dict(obs=torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device),
-                               rew=torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device),
-                               done=torch.zeros((self.B,), dtype=torch.uint8, device=self.device), chobs=None)
-                          for _ in range(self.io_ring)]
+        if out_buffers is not None:
+            # caller-owned output tensors (e.g. this handle's slice of a batch stepped as several sub-batches,
+            # diral_amd/streamed.py): contiguous, right shape / dtype / device, io_ring == 1
+            if self.io_ring != 1:
+                raise ValueError("out_buffers needs io_ring == 1")
+            want = dict(obs=((self.B, self.N, self.S), out_dtype), rew=((self.B, self.N), out_dtype),
+                        done=((self.B,), torch.uint8), chobs=((self.B, self.N, self.A), out_dtype))
+            for k, (shape, dt) in want.items():
+                tns = out_buffers.get(k)
+                if tns is None and k == "chobs":
+                    continue
+                if tns is None or tuple(tns.shape) != shape or tns.dtype != dt or tns.device != self.device or not tns.is_contiguous():
+                    raise ValueError("out_buffers[%r] must be a contiguous %s %s tensor on %s" % (k, shape, dt, self.device))
+            self._ring = [dict(obs=out_buffers["obs"], rew=out_buffers["rew"], done=out_buffers["done"],
+                               chobs=out_buffers.get("chobs"))]
+        else:
+            with torch.cuda.device(self.device):
+                self._ring = [dict(obs=torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device),
+                                   rew=torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device),
+                                   done=torch.zeros((self.B,), dtype=torch.uint8, device=self.device), chobs=None)
+                              for _ in range(self.io_ring)]
         self._ri = 0
         self._obs, self._rew, self._done = self._ring[0]["obs"], self._ring[0]["rew"], self._ring[0]["done"]
         self._chobs: Optional[torch.Tensor] = None
@@ -250,7 +267,7 @@ class VecV2VEnv:
         return out
 
     def _step(self, mode: int, actions: torch.Tensor, t: int, episode: float = 0.0, eps: float = 1.0,
-              want_chobs: bool = False, want_obs: bool = True):
+              want_chobs: bool = False, want_obs: bool = True, stream: Optional[ctypes.c_void_p] = None):
         if self.io_ring > 1:
             self._ri = (self._ri + 1) % self.io_ring
         slot = self._ring[self._ri]
@@ -262,7 +279,7 @@ class VecV2VEnv:
                                      _ptr(self._obs) if (want_obs and self.S > 0) else None,
                                      _ptr(self._rew), _ptr(self._done),
                                      _ptr(self._chobs) if want_chobs else None,
-                                     self._dt, float(episode), float(eps), self._stream())
+                                     self._dt, float(episode), float(eps), self._stream() if stream is None else stream)
         self._ok(st, "diral_env_step")
         return self._obs, self._rew, self._done
 

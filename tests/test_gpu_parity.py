@@ -1496,3 +1496,37 @@ def test_observe_kernel_f32_is_the_cast_of_f64_and_leaves_the_env_alone(N, A, y)
         assert torch.equal(before[k], after[k]), k
     assert torch.equal(m0, e64.metrics())
     e64.check(); e32.check()
+
+
+@pytest.mark.parametrize("N,A,G,B", [(64, 32, 4, 64), (64, 32, 3, 50), (128, 64, 2, 12), (256, 64, 2, 6)])
+def test_streamed_sub_batches_equal_one_handle(N, A, G, B):
+    """StreamedVecEnv (diral_amd/streamed.py): the batch stepped as G sub-batches on G streams - with and without a
+    per-slot wait on the caller's stream - against ONE handle holding all B envs: same device-drawn topology (global
+    env index), same states, rewards, channel observations, tables and metrics, bit for bit."""
+    from diral_amd.streamed import StreamedVecEnv
+    cfg = bench_config(N, A, 30.0 * N + 100, mobility_vary=True)
+    one = make_env(cfg, B, dtype=torch.float32)
+    one.reset_topology(seed=77)
+    for sync in (True, False):
+        one.reset_topology(seed=77)
+        many = StreamedVecEnv(cfg, batch=B, groups=G, out_dtype=torch.float32)
+        many.reset_topology(seed=77)
+        acts = [one.sample(seed=100 + i) for i in range(30)]
+        outs = []
+        for t in range(30):
+            o1, r1, d1 = one._step(STEP_MY_STEP, acts[t], t, want_chobs=True)
+            o2, r2, d2 = many.step(acts[t], t, sync=sync)
+            if sync:
+                assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(one._chobs, many.chobs), t
+            if t % 10 == 9:
+                one.update_velocity(seed=t)
+                many.update_velocity(seed=t)
+        many.wait()
+        assert torch.equal(o1, many.obs) and torch.equal(r1, many.rew) and torch.equal(one._chobs, many.chobs)
+        a, b = one.export_state(), many.export_state()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(one.metrics(clear=True)[:, [0, 2, 3]], many.metrics()[:, [0, 2, 3]])
+        many.check()
+        many.close()
+    one.check()
