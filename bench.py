@@ -363,6 +363,34 @@ def rollout_sps(device, envs=4096, slots=400, warm=80):
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
+def rollout_sps_graph(device, envs=4096, K=50, replays=8):
+    """The same closed loop (env step -> reward shaping -> SPS policy) as `rollout_sps`, K slots captured into ONE
+    hipGraph and replayed (diral_amd/rollout.py: slot number, policy draws and actions live in device memory)."""
+    from diral_amd import c2_config
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    cfg = c2_config()
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
+    env.reset_topology(seed=GLOBAL_SEED)
+    pol = SpsPolicy(env.B, env.N, env.A, device=device, seed=0)
+    ro = GraphRollout(env, pol, K=K)
+    ro.run(2)
+    torch.cuda.synchronize(device)
+    env.metrics(clear=True)
+    t0 = time.perf_counter()
+    ro.run(replays)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    m = env.metrics().sum(0)
+    slots = K * replays
+    out = {"what": "c2 env + driver reward shaping + SPS policy, %d envs: %d slots captured into one hipGraph, %d replays" % (envs, K, replays),
+           "agent_steps_per_s": envs * env.N * slots / dt, "ms_per_slot": dt / slots * 1e3,
+           "collision_fraction": float(m[3] / (m[2] + m[3]))}
+    ro.close()
+    return out
+
+
 def secondary_modes(device, envs=4096, slots=200, warm=100):
     """the secondary observation modes of obtain_state at the c2 shapes - the
     step on the specialised kernels plus the observation launch of csrc/posdist_kernel.hpp - per slot,
@@ -576,6 +604,8 @@ def main() -> int:
                 also["c2_sticky_0.9"] = short(r2)
                 also["c2_sticky_0.9"]["emit_chobs"] = emit
                 also["rollout_sps"] = rollout_sps(device)
+                torch.cuda.empty_cache()
+                also["rollout_sps_graph"] = rollout_sps_graph(device)
                 torch.cuda.empty_cache()
                 also["c2_streams2"] = streamed_c2(device, 2)
                 also["c2_streams4"] = streamed_c2(device, 4)

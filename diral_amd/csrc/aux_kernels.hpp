@@ -259,6 +259,9 @@ __global__ void info_age_kernel(int N, long long t, const int32_t* la, int32_t* 
   for (int j = threadIdx.x; j < 100; j += blockDim.x) out[(size_t)b * 100 + j] = bins[j];
 }
 
+// the slot clock of a captured rollout (diral_env_set_clock): one thread
+__global__ void clock_add_kernel(long long* clock, long long inc) { *clock += inc; }
+
 // SemiPersistentScheduling.__init__ (algorithms/v2x_sps.py:8-22)
 __global__ void sps_init_kernel(int agents, int window, uint64_t seed, int32_t* prev_action, int32_t* counter) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,7 +429,9 @@ template <int NC, typename T, bool CHOBS>
 __global__ void sps_step_wave_kernel(int agents, int A, const T* src, const int32_t* actions_in, int32_t* prev_action,
                                      int32_t* counter, double threshold, double inc_db, double keep_prob,
                                      const int32_t* draw_counter, const double* draw_keep, const int32_t* draw_choice,
-                                     uint64_t seed, int32_t* actions_out) {
+                                     uint64_t seed0, const long long* clock, int32_t* actions_out) {
+  // (`clock`: a device counter added to the seed - the draws of a captured graph move on with its replays)
+  const uint64_t seed = seed0 + (clock ? (uint64_t)*clock : 0ull);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool live = i < agents;

@@ -45,6 +45,7 @@ struct StepParams {
   double pf_penalty;
   double L, H, Rc, Rb, hist_inv_width;   // K / (Rb - (-Rb)): bin-index estimate only
   long long t;
+  const long long* t_dev;   // slot clock (diral_env_set_clock) or null: slot number = t + *t_dev
   double episode, eps;
   int out_f64;
   int episode_interval;

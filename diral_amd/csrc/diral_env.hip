@@ -305,13 +305,13 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
     f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
-    f.done_now = ((p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226
+    f.done_now = (!p.t_dev && (p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226 (with a slot clock: on the device)
     f.prr = ((p.flags & DIRAL_F_TRACK_PRR) && p.mode == DIRAL_STEP_MY_STEP) ? 1 : 0;
     f.notab = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) ? 0 : 1;     // no piggybacked tables: test_env.py:138-139, 231-238
     f.nomove = (p.flags & DIRAL_F_MOBILITY) ? 0 : 1;             // static (design) topology: network.py:302-305
     f.trace = f.nomove ? nullptr : p.trace;
     f.chobs_mode = (p.chobs_out ? 1 : 0) | ((p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ? 2 : 0);
-    f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t;
+    f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t; f.t_dev = p.t_dev;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
     f.metrics = p.metrics; f.err = p.err; f.edges = p.edges; f.inv_tab = e->inv_tab;
     f.ring = use_ring ? e->ring : nullptr;
@@ -880,7 +880,7 @@ int diral_sps_step(int agents, int num_channels, const double* selection_window,
 #define DIRAL_SPS_WAVE(NC)                                                                                           \
   hipLaunchKernelGGL((sps_step_wave_kernel<NC, double, false>), g, t, 0, st, agents, num_channels, selection_window, \
                      (const int32_t*)nullptr, prev_action, counter, rssi_threshold, inc_db, keep_prob, draw_counter, \
-                     draw_keep, draw_choice, seed, actions_out)
+                     draw_keep, draw_choice, seed, (const long long*)nullptr, actions_out)
   if (num_channels <= 64) DIRAL_SPS_WAVE(1);
   else if (num_channels <= 128) DIRAL_SPS_WAVE(2);
   else if (num_channels <= kSpsWaveMaxA) DIRAL_SPS_WAVE(4);
@@ -935,10 +935,11 @@ int diral_sps_window_from_chobs(int agents, int num_channels, const void* chobs,
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 
-int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
-                         int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
-                         double keep_prob, const int32_t* draw_counter, const double* draw_keep,
-                         const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream) {
+static int sps_step_chobs_impl(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
+                               int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
+                               double keep_prob, const int32_t* draw_counter, const double* draw_keep,
+                               const int32_t* draw_choice, uint64_t seed, const long long* clock, int32_t* actions_out,
+                               void* stream) {
   if (agents < 1 || num_channels < 1 || !chobs || !actions || !prev_action || !counter || !actions_out)
     return DIRAL_ERR_BAD_ARG;
   if (chobs_dtype != DIRAL_F32 && chobs_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
@@ -950,7 +951,7 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
 #define DIRAL_SPS_WAVE(NC, T)                                                                                          \
   hipLaunchKernelGGL((sps_step_wave_kernel<NC, T, true>), g, t, 0, st, agents, num_channels, static_cast<const T*>(chobs), \
                      actions, prev_action, counter, rssi_threshold, inc_db, keep_prob, draw_counter, draw_keep,        \
-                     draw_choice, seed, actions_out)
+                     draw_choice, seed, clock, actions_out)
 #define DIRAL_SPS_WAVE_T(T)                          \
   do {                                               \
     if (num_channels <= 64) DIRAL_SPS_WAVE(1, T);    \
@@ -962,6 +963,36 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
 #undef DIRAL_SPS_WAVE_T
 #undef DIRAL_SPS_WAVE
   return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
+int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
+                         int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
+                         double keep_prob, const int32_t* draw_counter, const double* draw_keep,
+                         const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream) {
+  return sps_step_chobs_impl(agents, num_channels, chobs, chobs_dtype, actions, prev_action, counter, rssi_threshold, inc_db,
+                             keep_prob, draw_counter, draw_keep, draw_choice, seed, nullptr, actions_out, stream);
+}
+
+int diral_sps_step_chobs_clocked(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
+                                 int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
+                                 double keep_prob, uint64_t seed, const int64_t* clock, int32_t* actions_out, void* stream) {
+  if (!clock) return DIRAL_ERR_BAD_ARG;
+  return sps_step_chobs_impl(agents, num_channels, chobs, chobs_dtype, actions, prev_action, counter, rssi_threshold, inc_db,
+                             keep_prob, nullptr, nullptr, nullptr, seed, (const long long*)clock, actions_out, stream);
+}
+
+int diral_clock_add(int64_t* clock, int64_t inc, void* stream) {
+  if (!clock) return DIRAL_ERR_BAD_ARG;
+  PtrDeviceGuard guard(clock);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  hipLaunchKernelGGL(clock_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)clock, (long long)inc);
+  return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+}
+
+int diral_env_set_clock(DiralEnv* e, const int64_t* t_dev) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  e->base.t_dev = (const long long*)t_dev;
+  return DIRAL_OK;
 }
 
 int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32_t* counter, uint64_t seed,

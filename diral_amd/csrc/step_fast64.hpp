@@ -67,6 +67,8 @@ struct FastParams {
                                  // (my_step_ch, my_step_design, State.type 1).  Host-folded: P1 touches no RichParams field
   double L, Rc, Rb, inv_w;
   long long t;
+  const long long* t_dev;        // slot clock (diral_env_set_clock) or null: the slot number is t + *t_dev, read on the device -
+                                 // a captured hipGraph of K steps replays with a clock that moves on
   const int32_t* actions;
   double* pos_x;
   const double* pos_y;
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   }
   double mynpx = live ? py_mod_pos(mypx + myvel + p.L, p.L) : 0.0;             // network.py:203
   if (EXTRA && p.trace && live) {                                              // replay branch, network.py:194-199
-    long long tt = p.t % p.trace_len;
+    long long tt = (p.t + (p.t_dev ? *p.t_dev : 0ll)) % p.trace_len;
     if (tt < 0) tt += p.trace_len;
     const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
     mynpx = p.trace[(base + (size_t)tt) * N + lane];
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         s_stage[lane * SA + i] = (out_t)ob;
       }
     }
-    if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)p.t;           // test_env.py:436
+    if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)(p.t + (p.t_dev ? *p.t_dev : 0ll));   // test_env.py:436
     if (CH || (EXTRA && p.prr)) {
       if (c > 1) {
         // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
@@ -540,7 +542,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       mt[DIRAL_M_TX_COLLIDED] += (double)vc;
       if (CH || (EXTRA && p.prr)) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
       uint8_t* const done_out = lp->done_out;
-      if (done_out) done_out[b] = (uint8_t)lp->done_now;
+      if (done_out) {
+        int dn = lp->done_now;                                    // folded on the host ...
+        const long long* const td = lp->t_dev;                     // ... unless the slot number lives on the device
+        if (td) dn = ((unsigned int)(lp->t + *td) % (unsigned int)lp->episode_interval) == (unsigned int)lp->episode_interval - 1u;
+        done_out[b] = (uint8_t)dn;
+      }
     }
     if (live) p.pos_x[bN + lane] = mynpx;
   }

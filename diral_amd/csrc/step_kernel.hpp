@@ -260,7 +260,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
       nx = x;
       if (do_step && mobile) {
         if (!FAST && p.trace) {                                    // replay branch, network.py:194-199
-          long long tt = p.t % p.trace_len;
+          long long tt = (p.t + (p.t_dev ? *p.t_dev : 0ll)) % p.trace_len;
           if (tt < 0) tt += p.trace_len;
           const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
           nx = p.trace[(base + (size_t)tt) * N + u];
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
           if (p.state_out && p.off_chobs >= 0)
             store_out(p.state_out, (bN + u) * p.S + p.off_chobs + i, ob, out_f64);
           if (track_la && mode == DIRAL_STEP_MY_STEP_CH && got)
-            p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;                         // test_env.py:436
+            p.la[(bN + bid[j]) * N + u] = (int32_t)(p.t + (p.t_dev ? *p.t_dev : 0ll));   // test_env.py:436
         }
       }
       if (!FAST && want_prr && c > 1) {
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(Geo<VPL>::THREADS, (VPL == 1 ? DIRAL_MINWAVES : 4))
   if (do_step) {
     for (int u = tid; u < N; u += G::THREADS) p.pos_x[bN + u] = s_npx[u];
     if (tid == 0) {
-      if (p.done_out) p.done_out[b] = (uint8_t)((p.t % p.episode_interval) == p.episode_interval - 1);
+      if (p.done_out) p.done_out[b] = (uint8_t)(((p.t + (p.t_dev ? *p.t_dev : 0ll)) % p.episode_interval) == p.episode_interval - 1);
       double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
       for (int w = 0; w < VPL; ++w) {
         sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3];

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     }
     double nx = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;     // network.py:203
     if (EXTRA && p.trace && lv) {                            // replay branch, network.py:194-199
-      long long tt = p.t % p.trace_len;
+      long long tt = (p.t + (p.t_dev ? *p.t_dev : 0ll)) % p.trace_len;
       if (tt < 0) tt += p.trace_len;
       const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
       nx = p.trace[(base + (size_t)tt) * N + u];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         const int u = lane + 64 * j;
         const bool got = (myact[j] != i) && (bid[j] >= 0) && (u < N);
         mw |= (unsigned int)(got ? bid[j] : u) << (8 * j);
-        if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)p.t;       // test_env.py:436
+        if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)(p.t + (p.t_dev ? *p.t_dev : 0ll));   // test_env.py:436
       }
       s_mtab[i * MT + lane] = (mword_t)mw;
       if (CH || (EXTRA && p.prr)) {
@@ -1652,7 +1652,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   void* const state_out = lp->state_out;
   if (tid == 0) {
     uint8_t* const done_out = lp->done_out;
-    if (done_out) done_out[b] = (uint8_t)lp->done_now;
+    if (done_out) {
+      int dn = lp->done_now;                                      // (slot clock: see step_fast64.hpp)
+      const long long* const td = lp->t_dev;
+      if (td) dn = ((unsigned int)(lp->t + *td) % (unsigned int)lp->episode_interval) == (unsigned int)lp->episode_interval - 1u;
+      done_out[b] = (uint8_t)dn;
+    }
     double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
     for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
     double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;

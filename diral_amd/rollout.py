@@ -1,0 +1,131 @@
+"""A K-slot rollout captured into ONE hipGraph (launch-overhead-free closed loop).
+
+The reference's slot loop is env step -> reward shaping -> policy, once per slot (main_test.py:119-236); on the
+device that is three launches per slot driven from Python (`examples/rollout_sps.py`: ~100 us per slot at 4096 envs
+against ~90 us of kernels).  `GraphRollout` records K slots of
+
+    obs, rew = env.my_step*(actions, t)            (state + reward + channel observation, one launch)
+    shaped   = diral_driver_shape(rew, actions)    (main_test.py:171-206)
+    actions  = SpsPolicy(obs, actions)             (algorithms/v2x_sps.py, decision from the channel observation)
+
+into one graph and replays it.  Everything a replay must see move on lives in device memory: the slot number
+(`diral_env_set_clock`: `done`, arrival stamps, trace replay), the seed offset of the policy's draws
+(`diral_sps_step_chobs_clocked`), the actions (two buffers the slots alternate between), and the clock itself,
+advanced by K by the graph's last node.  A replay of the graph equals K eager slots bit for bit
+(tests/test_gpu_parity.py::test_graph_rollout_equals_eager).
+
+Scope: the per-slot outputs live in the env's output ring (`io_ring` sets; K must be a multiple of it), i.e. a
+replay leaves the LAST `io_ring` slots' state / reward behind - a policy-evaluation rollout (metrics accumulate on
+the device), not a replay-buffer filler.  Episode ends that change the env from the host (`update_velocity` with
+mobility_vary, the epsilon schedule behind the fingerprint columns) are not part of the graph: such configs raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from .config import STEP_MY_STEP, STEP_MY_STEP_CH
+from .sps import SpsPolicy
+from .vec_env import DiralError, VecV2VEnv
+
+
+class SlotClock:
+    """An int64 slot counter in HBM shared by the env and the policy of a captured rollout."""
+
+    def __init__(self, device, start: int = 0):
+        self.t = torch.full((1,), int(start), dtype=torch.int64, device=device)
+
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def value(self) -> int:
+        return int(self.t.item())
+
+
+def shape_rewards(env: VecV2VEnv, reward: torch.Tensor, actions: torch.Tensor, out: torch.Tensor, sum_r: torch.Tensor,
+                  coll: torch.Tensor, global_reward_avg: bool) -> None:
+    """main_test.py:171-206 without the information-age terms: `diral_driver_shape`, one launch, caller-owned outputs."""
+    B, N = reward.shape
+    st = env.lib.diral_driver_shape(B, N, env.A, reward.data_ptr(), 1 if reward.dtype == torch.float64 else 0,
+                                    actions.data_ptr(), None, None, None, None, 1 if global_reward_avg else 0, 0, 0.0,
+                                    out.data_ptr(), sum_r.data_ptr(), coll.data_ptr(), None, None, env._stream())
+    if st != 0:
+        raise DiralError(st, "diral_driver_shape")
+
+
+class GraphRollout:
+    def __init__(self, env: VecV2VEnv, policy: SpsPolicy, K: int, global_reward_avg: bool = True, enable_channel: bool = False,
+                 clock: Optional[SlotClock] = None, capture: bool = True):
+        cfg = env.cfg
+        if cfg.mobility_vary or cfg.enable_fingerprint:
+            raise ValueError("GraphRollout: configs whose episode ends act on the env from the host (mobility_vary, "
+                             "enable_fingerprint) are not captured")
+        if K < 1 or K % env.io_ring or K % 2:
+            raise ValueError("K must be a positive multiple of 2 and of the env's io_ring (%d)" % env.io_ring)
+        self.env, self.pol, self.K = env, policy, int(K)
+        self.global_reward_avg = bool(global_reward_avg)
+        self.mode = STEP_MY_STEP_CH if enable_channel else STEP_MY_STEP
+        dev = env.device
+        self.clock = clock or SlotClock(dev)
+        B, N = env.B, env.N
+        self.actions = [policy.prev_action.clone(), torch.empty_like(policy.prev_action)]
+        dt = env.out_dtype
+        self.shaped = [torch.empty((B, N), dtype=dt, device=dev) for _ in range(2)]
+        self.sum_r = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
+        self.coll = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
+        env._ok(env.lib.diral_env_set_clock(env._h, ctypes.c_void_p(self.clock.ptr())), "diral_env_set_clock")
+        self.graph = None
+        self._slots_run = 0
+        if capture:
+            # a first eager pass: output buffers exist, the ring <-> plane state is settled (a conversion launch must
+            # not be captured: DIRAL_ERR_CAPTURE), lazy initialisations are done
+            self._run_slots(eager=True)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            self._stream = torch.cuda.Stream(device=dev)
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._stream):
+                with torch.cuda.graph(self.graph, stream=self._stream):
+                    self._run_slots(eager=False)
+            torch.cuda.current_stream(dev).wait_stream(self._stream)
+
+    def _one_slot(self, k: int) -> None:
+        env, pol = self.env, self.pol
+        a, a_next = self.actions[k & 1], self.actions[(k + 1) & 1]
+        env._step(self.mode, a, k, want_chobs=True)                      # slot number = clock + k, on the device
+        i = k & 1
+        shape_rewards(env, env._rew, a, self.shaped[i], self.sum_r[i], self.coll[i], self.global_reward_avg)
+        pol.step_from_chobs_clocked(env._chobs, a, self.clock, k, out=a_next)
+
+    def _run_slots(self, eager: bool) -> None:
+        for k in range(self.K):
+            self._one_slot(k)
+        st = self.env.lib.diral_clock_add(ctypes.c_void_p(self.clock.ptr()), self.K, self.env._stream())
+        if st != 0:
+            raise DiralError(st, "diral_clock_add")
+        if eager:
+            self._slots_run += self.K
+
+    def run(self, replays: int = 1) -> None:
+        """`replays` x K slots (enqueued on the current stream; no host sync)."""
+        for _ in range(replays):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._run_slots(eager=True)
+                continue
+            self._slots_run += self.K
+
+    @property
+    def slots(self) -> int:
+        return self._slots_run
+
+    def last(self):
+        """(state, shaped reward, actions that produced them) of the last slot run."""
+        i = (self.K - 1) & 1
+        return self.env._obs, self.shaped[i], self.actions[i]
+
+    def close(self) -> None:
+        self.env._ok(self.env.lib.diral_env_set_clock(self.env._h, None), "diral_env_set_clock")

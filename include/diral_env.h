@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 2
+#define DIRAL_ABI_VERSION 3
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -369,6 +369,22 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
                          double rssi_threshold, double inc_db, double keep_prob,
                          const int32_t* draw_counter, const double* draw_keep,
                          const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream);
+
+/* ---- slot clock: rollouts captured into a hipGraph ---------------------------------------------
+ * A captured sequence of K slots (env step, reward shaping, policy) bakes every by-value argument into its
+ * kernel nodes; what has to move on from replay to replay - the slot number behind `done`, arrival stamps and
+ * trace replay; the seed of the policy's draws - is read from a DEVICE counter instead.
+ *   diral_env_set_clock(env, t_dev): from now on diral_env_step's `t` is an OFFSET: the slot number is
+ *     *t_dev + t, read by the kernel (t_dev NULL: back to the by-value slot number).  int64 in HBM, owned by
+ *     the caller, alive as long as it is set.
+ *   diral_clock_add(clock, inc, stream): *clock += inc as a one-thread launch (the last node of the graph).
+ *   diral_sps_step_chobs_clocked: diral_sps_step_chobs with device draws seeded by seed + *clock. */
+int diral_env_set_clock(DiralEnv* env, const int64_t* t_dev);
+int diral_clock_add(int64_t* clock, int64_t inc, void* stream);
+int diral_sps_step_chobs_clocked(int agents, int num_channels, const void* chobs, int chobs_dtype,
+                                 const int32_t* actions, int32_t* prev_action, int32_t* counter,
+                                 double rssi_threshold, double inc_db, double keep_prob, uint64_t seed,
+                                 const int64_t* clock, int32_t* actions_out, void* stream);
 
 /* Replaces SemiPersistentScheduling.__init__ (v2x_sps.py:8-22): prev_action =
  * randint(0, selection_window) (inclusive, as in the reference), counter =

@@ -1530,3 +1530,41 @@ def test_streamed_sub_batches_equal_one_handle(N, A, G, B):
         many.check()
         many.close()
     one.check()
+
+
+@pytest.mark.parametrize("N,A,B,ch", [(64, 32, 64, False), (64, 32, 16, True), (128, 64, 8, False), (256, 64, 4, False)])
+def test_graph_rollout_equals_eager(N, A, B, ch):
+    """diral_amd/rollout.py: K slots of [env step -> reward shaping -> SPS policy] captured into one hipGraph and replayed
+    20 times against the same 210 slots run eagerly: slot number (done flag, arrival stamps), policy draws and actions come
+    from device memory, so the replays move on exactly like the eager loop - env state, tables, policy state, metrics and the
+    last outputs equal bit for bit."""
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2, track_arrival=ch)
+    runs = []
+    for capture in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32, io_ring=2)
+        env.reset_topology(seed=5)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=3)
+        ro = GraphRollout(env, pol, K=10, enable_channel=ch, capture=capture)
+        ro.run(20 if capture else 21)
+        torch.cuda.synchronize()
+        assert ro.slots == 210 and ro.clock.value() == 210
+        runs.append((env, pol, ro))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    for x, y in zip(r1.last(), r2.last()):
+        assert torch.equal(x, y)
+    assert torch.equal(e1._done, e2._done) and torch.equal(e1._chobs, e2._chobs)
+    m1, m2 = e1.metrics(), e2.metrics()
+    assert torch.equal(m1[:, [0, 2, 3]], m2[:, [0, 2, 3]]) and torch.allclose(m1, m2, rtol=1e-12, atol=1e-9)
+    assert float(m1[:, 0].min()) == 210.0
+    if ch:
+        assert torch.equal(e1.info_age(209), e2.info_age(209))
+    for e, _, r in runs:
+        e.check()
+        r.close()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, "diral_amd/_lib.py and include/diral_env.h disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.diral_env_abi_version() == 2
+    assert lib.diral_env_abi_version() == 3
 
 
 def test_cfg_struct_layout_matches_header():
