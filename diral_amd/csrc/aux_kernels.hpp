@@ -506,6 +506,67 @@ __device__ T np_pairwise_sum(const T* a, int n) {
 //   reward'     = reward + ia_penalty (:190-192); counter / threshold penalty (:194-203);
 //                 + sum_r / N (global_reward_avg, :205-206)
 constexpr int kShapeEnvsPerBlock = 64;
+
+// The common case - no information-age terms, 8 <= N <= 64 - one WAVE per env: lane = vehicle, the rewards arrive with
+// one coalesced load, np.sum's order (eight running accumulators over blocks of eight, a pairwise tree, a sequential
+// tail: numpy/_core/src/umath/loops_utils.h pairwise_sum) is walked with lane shuffles, and every lane rewrites its own
+// reward.  (The thread-per-env kernel below reads 64 strided rows per wave and sums them one element at a time:
+// 12 us at 4096 envs against 3 us here.)
+template <typename T>
+__device__ inline T shfl_t(T v, int src) {
+  if constexpr (sizeof(T) == 8) {
+    const double d = (double)v;
+    return (T)__hiloint2double(__shfl(__double2hiint(d), src), __shfl(__double2loint(d), src));
+  } else {
+    return __shfl(v, src);
+  }
+}
+constexpr int kShapeWaveBlock = 256;
+template <typename T>
+__global__ __launch_bounds__(kShapeWaveBlock) void driver_shape_wave_kernel(int envs, int N, int A, const T* reward_in,
+                                                                           const int32_t* actions, int32_t* pen_counter,
+                                                                           int32_t* prev_actions, int flags, int pen_threshold,
+                                                                           double pen_value, T* reward_out, T* sum_r_out,
+                                                                           T* collision_out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kShapeWaveBlock / 64) + (threadIdx.x >> 6);
+  if (b >= envs) return;                                            // (wave-uniform)
+  const bool global_avg = flags & 1, pen_enable = flags & 4;
+  const size_t g = (size_t)b * N + lane;
+  const bool live = lane < N;
+  const T a = live ? reward_in[g] : (T)0;
+  // r[j] = a[j] + a[8 + j] + a[16 + j] + ... (in that order) for j = 0..7, over the whole blocks of eight
+  const int nb = N >> 3;
+  T r = a;
+  for (int i = 1; i < nb; ++i) {
+    const T v = shfl_t(a, (lane & 7) + 8 * i);
+    r = r + v;
+  }
+  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a shuffle-down tree over lanes 0..7
+  T t = r + shfl_t(r, lane + 1);
+  t = t + shfl_t(t, lane + 2);
+  t = t + shfl_t(t, lane + 4);
+  T sr = shfl_t(t, 0);
+  for (int i = nb * 8; i < N; ++i) sr = sr + shfl_t(a, i);          // the sequential tail
+  if (lane == 0) {
+    if (sum_r_out) sum_r_out[b] = sr;
+    if (collision_out) collision_out[b] = (T)A - sr;
+  }
+  if (live) {
+    T rr = a;
+    if (pen_enable) {
+      const int ac = actions[g];
+      const bool stuck = (rr < (T)1) && (ac == prev_actions[g]);
+      const int c = stuck ? pen_counter[g] + 1 : 0;
+      pen_counter[g] = c;
+      if (c > pen_threshold) rr = (T)pen_value;
+      prev_actions[g] = ac;
+    }
+    if (global_avg) rr = rr + sr / (T)N;
+    reward_out[g] = rr;
+  }
+}
+
 template <typename T>
 __global__ void driver_shape_kernel(int envs, int N, int A, const T* reward_in, const int32_t* actions,
                                     const int32_t* ia, long long* sum_ia_prev, int32_t* pen_counter,

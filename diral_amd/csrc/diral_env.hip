@@ -903,6 +903,21 @@ int diral_driver_shape(int envs, int num_users, int num_channels, const void* re
   if ((flags & 2) && (!ia || !sum_ia_prev)) return DIRAL_ERR_BAD_ARG;
   PtrDeviceGuard guard(reward_in);
   if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  if (!ia && !(flags & 2) && num_users >= 8 && num_users <= 64) {
+    // no information-age terms, one wave per env (aux_kernels.hpp)
+    const dim3 gw(blocks((size_t)envs, kShapeWaveBlock / 64)), tw(kShapeWaveBlock);
+    if (dtype == DIRAL_F64)
+      hipLaunchKernelGGL(driver_shape_wave_kernel<double>, gw, tw, 0, (hipStream_t)stream, envs, num_users, num_channels,
+                         static_cast<const double*>(reward_in), actions, pen_counter, prev_actions, flags, ia_penalty_threshold,
+                         ia_penalty_value, static_cast<double*>(reward_out), static_cast<double*>(sum_r_out),
+                         static_cast<double*>(collision_out));
+    else
+      hipLaunchKernelGGL(driver_shape_wave_kernel<float>, gw, tw, 0, (hipStream_t)stream, envs, num_users, num_channels,
+                         static_cast<const float*>(reward_in), actions, pen_counter, prev_actions, flags, ia_penalty_threshold,
+                         ia_penalty_value, static_cast<float*>(reward_out), static_cast<float*>(sum_r_out),
+                         static_cast<float*>(collision_out));
+    return hipGetLastError() == hipSuccess ? DIRAL_OK : DIRAL_ERR_HIP;
+  }
   const dim3 g(blocks((size_t)envs, kShapeEnvsPerBlock)), t(256);
   if (dtype == DIRAL_F64)
     hipLaunchKernelGGL(driver_shape_kernel<double>, g, t, 0, (hipStream_t)stream, envs, num_users, num_channels,

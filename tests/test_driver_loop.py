@@ -137,6 +137,38 @@ def test_device_reward_shaping_equals_the_torch_statement(N, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,dtype,pen", [(8, torch.float64, True), (9, torch.float32, False), (15, torch.float64, True),
+                                         (16, torch.float32, True), (40, torch.float64, False), (63, torch.float32, True),
+                                         (64, torch.float32, False), (64, torch.float64, True), (7, torch.float64, True)])
+def test_device_reward_shaping_wave_kernel_equals_the_torch_statement(N, dtype, pen):
+    """`diral_driver_shape` without information-age terms takes the one-wave-per-env kernel at 8 <= N <= 64
+    (np.sum's pairwise order walked with lane shuffles): against the torch statement, bit for bit."""
+    from diral_amd.config import bench_config
+    from diral_amd.vec_env import VecV2VEnv
+    A = 6
+    cfg = bench_config(N, A, 30.0 * N + 50, reward_design=3, communication_range=120.0)
+    B = 37
+    envs = [VecV2VEnv(cfg, batch=B, out_dtype=dtype) for _ in range(2)]
+    loops = [DriverLoop(e, global_reward_avg=True, ia_penalty_enable=pen, ia_penalty_threshold=2, ia_penalty_value=-10,
+                        device_shaping=ds) for e, ds in zip(envs, (True, False))]
+    for e in envs:
+        e.reset_topology(seed=31)
+    rng = np.random.default_rng(N)
+    acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+    for lp in loops:
+        lp.bootstrap(torch.as_tensor(acts, device="cuda:0"))
+    for t in range(30):
+        new = rng.integers(0, A, size=(B, N))
+        acts = np.where(rng.random((B, N)) < 0.7, acts, new).astype(np.int32)
+        a = torch.as_tensor(acts, device="cuda:0")
+        o_dev, o_ref = loops[0].slot(a, t), loops[1].slot(a, t)
+        for k in ("reward", "raw_reward", "sum_r", "collision", "next_state"):
+            assert torch.equal(o_dev[k].to(o_ref[k].dtype), o_ref[k]), (k, t)
+    if pen:
+        assert torch.equal(loops[0]._pen_counter.long(), loops[1]._pen_counter.long())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
 def test_io_ring_keeps_the_previous_slot_intact_without_copies(fused):
     """VecV2VEnv(io_ring=2): the step calls alternate between two output-buffer sets, DriverLoop
