@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
+from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_PACKED, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
                               bench_config)
 from diral_amd.metrics import gather_metrics  # noqa: E402
 from diral_amd.roofline import (HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot,  # noqa: E402
@@ -175,8 +175,8 @@ def kernel_name(code: int, N: int, out_dtype: str) -> str:
     if fam == KERNEL_FAST64:
         return "diral::step_fast64_kernel<true,%s,%s,%s,%s>" % (b(o64), b(ch), b(extra), b(rich))
     if fam == KERNEL_WIDE:
-        return "diral::step_wide_kernel<%d,%s,%s,%s,%s,%s>" % (2 if N <= 128 else 4, b(o64), b(N in (128, 256)), b(ch),
-                                                             b(extra), b(rich))
+        return "diral::step_wide_kernel<%d,%s,%s,%s,%s,%s,%s>" % (2 if N <= 128 else 4, b(o64), b(N in (128, 256)), b(ch),
+                                                                b(extra), b(rich), b(code & KERNEL_PACKED))
     return "diral::step_kernel<%d,%s>" % (1 if N <= 64 else 2 if N <= 128 else 4, b(out_dtype == "f32" and not ch))
 
 

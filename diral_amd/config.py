@@ -55,6 +55,7 @@ KERNEL_RICH = 16
 KERNEL_EXTRA = 32
 KERNEL_CH = 64
 KERNEL_RING = 128
+KERNEL_PACKED = 256
 
 MAX_USERS = 256
 MAX_CHANNELS = 256

@@ -127,6 +127,25 @@ Offsets state_offsets(const DiralCfg* c) {
 
 int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
 
+// The table form of a handle (fixed at create): packed thermometer codes + ages + own sequence numbers, or the (seq, age)
+// plane `tkey` of round 2.  N <= 64: always packed (step_fast64 has no other form).  64 < N <= 128: the plane (step_wide
+// <2>).  128 < N <= 256: packed where the vehicles are dense enough for tables to stay fresh - on average at least
+// kPackedMinNeighbours vehicles within communication range (N * 2 Rc / L; BASELINE configs[2]: 32) -, else the plane: on a
+// sparse highway most entries lag their subject by more than the 7 stamps the codes carry, and every pass of the packed
+// form would detour through the planes (measured + 60 % at 2.4 neighbours, + 58 % at 10.7).  DIRAL_TABLE_FORM = packed |
+// plane in the environment overrides the choice for N > 128 (tests run both forms on both kinds of topology).
+constexpr double kPackedMinNeighbours = 20.0;
+bool use_packed_table(const DiralEnv* e) {
+  if (e->vpl == 1) return true;
+  if (e->vpl == 2) return false;
+  if (const char* f = std::getenv("DIRAL_TABLE_FORM")) {
+    if (std::strcmp(f, "packed") == 0) return true;
+    if (std::strcmp(f, "plane") == 0) return false;
+  }
+  const double neigh = e->N * 2.0 * e->cfg.communication_range / e->cfg.highway_length;
+  return neigh >= kPackedMinNeighbours;
+}
+
 // Every entry point that touches the device runs with the handle's device current and
 // restores the caller's (torch's) current device afterwards.
 struct DeviceGuard {
@@ -329,7 +348,9 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
     k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr || f.prr != 0 || f.notab != 0 || f.nomove != 0;   // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
+    k.packed = use_wide && vpl == 4 && e->tcode != nullptr;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
+                     ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
     return launch_fast64(f, r, k, p.B, s);
@@ -522,7 +543,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
-    if (e->vpl != 2) {                                          // the packed table of step_fast64 and of step_wide at N > 128
+    if (use_packed_table(e)) {                                  // the packed table of step_fast64 and of step_wide at N > 128
       // (+ 512 words of slack: step_wide.hpp loads a padded viewer slot past the end of a row without clamping)
       const size_t nq = (size_t)e->B * (e->NR / 4);
       CREATE_TRY(alloc((void**)&e->tcode, (nq * e->NV + 512) * 4));

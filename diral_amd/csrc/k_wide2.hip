@@ -9,14 +9,14 @@ struct LaunchWide {
   const FastParams& f; const RichParams& r; dim3 g; uint32_t lds; hipStream_t s;
   template <bool O, bool F, bool C, bool X, bool R>
   void operator()(std::integer_sequence<bool, O, F, C, X, R>) const {
-    hipLaunchKernelGGL((step_wide_kernel<V, O, F, C, X, R>), g, dim3(64 * wide_waves(V)), lds, s, f, r);
+    hipLaunchKernelGGL((step_wide_kernel<V, O, F, C, X, R, false>), g, dim3(64 * wide_waves(V)), lds, s, f, r);
   }
 };
 struct AttrWide {
   int lds; hipError_t* st;
   template <bool O, bool F, bool C, bool X, bool R>
   void operator()(std::integer_sequence<bool, O, F, C, X, R>) const {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<V, O, F, C, X, R>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<V, O, F, C, X, R, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) *st = e;
   }

@@ -658,8 +658,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (h1) ringp[64 + lane] = px1;
     }
   }
-  {
-    // the coded merge (the words of a bad quad are merged along - meaningless, never read)
+  if (badq != 15u) {
+    // the coded merge (the words of a bad quad are merged along - meaningless, never read; none at all when every
+    // quad of the wave is keyed: a sparse topology)
     unsigned long long rem = actw;
     int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
 #pragma unroll 1

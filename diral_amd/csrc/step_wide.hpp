@@ -287,8 +287,14 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
 // CH: my_step_ch (PRR reward, test_env.py:351-443) instead of my_step, as in step_fast64.hpp
 // EXTRA: run-time switches for my_step_design and the arrival stamps, as in step_fast64.hpp
 // RICH: the output tail of rich_out.hpp (channel observation output, cheap State flags)
-template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH>
+// PACKED: the table form (the host decides per handle, csrc/diral_env.hip `use_packed_table`): codes + ages + own sequence
+// numbers, or the round-2 (seq, age) plane `tkey` whose passes re-derive the lags every slot and fall back to byte
+// ranks in place.  Dense topologies (BASELINE configs[2]) are 16 % faster packed; where most entries lag their subject
+// by more than 7 stamps (sparse topologies, and configs[4] at N <= 128) every pass of the packed form would detour
+// through the planes - those handles keep the plane form.
+template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH, bool PACKED>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p, const RichParams r) {
+  static_assert(!PACKED || VPL == 4, "the packed pass exists for N > 128");
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
   constexpr int PC = VPL == 2 ? DIRAL_WIDE_PC2 : DIRAL_WIDE_PC4;   // subject columns per pass
@@ -641,12 +647,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   bool ovf = false;
   unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, acc_load = 0, acc_merge = 0, acc_fin = 0, t_p3 = 0;
   DIRAL_WCLOCK(t_p3);
-  // N <= 256 (VPL == 4, BASELINE configs[2]): the PACKED table - codes, ages, own sequence numbers (below).
-  // N <= 128 (VPL == 2, configs[4]): the (seq, age) plane `tkey` as in round 2.  At that density 2 % of the entries
-  // lag more than 7 stamps (profiles/lag_distribution.py) - most passes of 8 x 128 entries hold one - which the
-  // 8-level codes cannot carry: the passes keep re-deriving the lags from the words every slot and fall back to byte
-  // ranks in place (measured: the packed form, with its detour through the planes for such passes, C5 + 13 %).
-  if constexpr (VPL == 4) {
+  // PACKED (128 < N <= 256 on a dense topology, BASELINE configs[2]): codes, ages, own sequence numbers (below).
+  // Otherwise the (seq, age) plane `tkey` as in round 2: at configs[4]'s density (N <= 128) 2 % of the entries lag more
+  // than 7 stamps (profiles/lag_distribution.py) - most passes of 8 x 128 entries hold one -, on sparse topologies most
+  // entries do; the 8-level codes cannot carry them, and the packed form's detour through the planes for such passes
+  // costs more than it saves (C5 + 13 %, a sparse 256-vehicle highway + 60 %).
+  if constexpr (PACKED) {
   unsigned int passbits = 0u;                      // bit pch: a quad of pass pch was flagged when the slot began
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {

@@ -193,7 +193,9 @@ enum {
   DIRAL_KERNEL_RICH    = 16,  /* channel-obs output / cheap State flags (csrc/rich_out.hpp) */
   DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
   DIRAL_KERNEL_CH      = 64,  /* my_step_ch */
-  DIRAL_KERNEL_RING    = 128  /* step_fast64 with the xpos ring (the per-entry xpos plane only for old entries) */
+  DIRAL_KERNEL_RING    = 128, /* the xpos ring (the per-entry xpos plane only for old entries) */
+  DIRAL_KERNEL_PACKED  = 256  /* the packed table form: thermometer codes + ages + own sequence numbers (N <= 64 always;
+                                 128 < N <= 256 on dense topologies), else the (seq, age) plane */
 };
 int diral_env_last_kernel(const DiralEnv* env);
 

@@ -86,7 +86,7 @@ def test_histogram_bin_edges_sweep_on_the_hip_path(K, rb, N, path):
         env.force_general_kernel(path == "general")
         obs, rew, _ = env.step(acts, 0)
         torch.cuda.synchronize()
-        assert (env.last_kernel() & ~KERNEL_RING) == want_kernel and bool(env.last_kernel() & KERNEL_RING) == (path != "general")
+        assert (env.last_kernel() & ~(KERNEL_RING | 256)) == want_kernel and bool(env.last_kernel() & KERNEL_RING) == (path != "general")   # (256: KERNEL_PACKED)
         assert np.array_equal(env.export_state()["pos_x"].cpu().numpy(), np.zeros((B, N)))   # post-move x == 0
         got = obs.cpu().numpy()
         assert np.array_equal(got, o_state if dt == torch.float64 else o_state.astype(np.float32)), (K, rb, N, path)
@@ -203,7 +203,7 @@ def test_c4_shard_sized_run_properties_and_sampled_oracle():
         if t % 7 == 0 or t == T - 1:
             assert np.array_equal(obs[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_state.astype(np.float32)), t
             assert np.array_equal(rew[torch.as_tensor(pick, device=obs.device)].cpu().numpy(), o_rew.astype(np.float32)), t
-    assert env.last_kernel() == KERNEL_FAST64 | KERNEL_RING
+    assert env.last_kernel() == KERNEL_FAST64 | KERNEL_RING | 256           # (256: KERNEL_PACKED, the packed table form)
     # properties on all 32768 envs of the last slot
     onehot = obs[:, :, :A]
     assert torch.equal(onehot.argmax(-1).to(torch.int32), a) and torch.all(onehot.sum(-1) == 1)

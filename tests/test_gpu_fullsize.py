@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from diral_amd.config import KERNEL_FAST64, KERNEL_RICH, KERNEL_RING, KERNEL_WIDE, STEP_MY_STEP, bench_config
+from diral_amd.config import (KERNEL_FAST64, KERNEL_PACKED, KERNEL_RICH, KERNEL_RING, KERNEL_WIDE, STEP_MY_STEP,
+                              bench_config)
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +33,8 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None):
         a_t = torch.randint(0, A, (B, N), device="cuda:0", dtype=torch.int32, generator=g)
         obs, rew, done = env._step(STEP_MY_STEP, a_t, t, want_chobs=True)     # what bench.py's timed step calls
         chobs = env._chobs
-        assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_RING, env.last_kernel()
+        # (the packed table form: N <= 64, and N > 128 on a dense topology; N = 128 keeps the (seq, age) plane)
+        assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_RING | (0 if N == 128 else KERNEL_PACKED), env.last_kernel()
         al = a_t.long()
         # (1) one-hot section == actions
         assert torch.equal(obs[..., :A].argmax(-1), al) and torch.all(obs[..., :A].sum(-1) == 1)

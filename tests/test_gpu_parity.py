@@ -1197,7 +1197,10 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     env.reset_topology(seed=3)
     a = env.sample(seed=1)
     env.step(a, 0)
-    ring = KERNEL_RING                                                  # the xpos ring rides on every specialised launch
+    from diral_amd.config import KERNEL_PACKED
+    # the xpos ring rides on every specialised launch; the packed table form at N <= 64 and, on these dense topologies,
+    # at N > 128
+    ring = KERNEL_RING | (KERNEL_PACKED if (N <= 64 or N > 128) else 0)
     assert env.last_kernel() == fam | ring                              # plain
     chobs, rew = env.my_step(a, 1)
     assert env.last_kernel() == fam | KERNEL_RICH | ring
@@ -1229,7 +1232,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         e2 = make_env(c2, B, dtype=torch.float64)
         e2.reset_topology(seed=4)
         e2.step(e2.sample(seed=2), 0)
-        assert (e2.last_kernel() & ~KERNEL_RING) == want, (state, extra, e2.last_kernel())
+        assert (e2.last_kernel() & ~ring) == want, (state, extra, e2.last_kernel())
         e2.check()
     # a State block without piggybacked tables (test_env.py:138-139, 231-238: the table-less step), a static
     # topology (network.py:302-305) - run-time switches of the EXTRA instantiations - and a stand-alone
@@ -1243,7 +1246,7 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
         e3.reset_topology(seed=5)
         a3 = e3.sample(seed=2)
         e3.step(a3, 0)
-        assert (e3.last_kernel() & ~KERNEL_RING) == want, (state, extra, e3.last_kernel())
+        assert (e3.last_kernel() & ~ring) == want, (state, extra, e3.last_kernel())
         e3.obtain_state(None, e3.sample(seed=3), None)
         assert (e3.last_kernel() & 15) == KERNEL_OBSERVE, (state, extra, e3.last_kernel())
         e3.check()
@@ -1335,10 +1338,12 @@ def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
                    expect_kernel=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE)
 
 
-@pytest.mark.parametrize("N,A,L,Rc", [(64, 32, 2000.0, 250.0), (40, 9, 1500.0, 250.0), (64, 16, 9000.0, 140.0), (33, 5, 6000.0, 100.0),
-                                      (128, 64, 4000.0, 250.0), (256, 64, 4000.0, 250.0), (200, 24, 30000.0, 140.0),
-                                      (96, 12, 20000.0, 120.0)])
-def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consumer(N, A, L, Rc):
+@pytest.mark.parametrize("N,A,L,Rc,form", [(64, 32, 2000.0, 250.0, None), (40, 9, 1500.0, 250.0, None), (64, 16, 9000.0, 140.0, None),
+                                           (33, 5, 6000.0, 100.0, None), (128, 64, 4000.0, 250.0, None), (96, 12, 20000.0, 120.0, None),
+                                           (256, 64, 4000.0, 250.0, None), (256, 64, 4000.0, 250.0, "plane"),
+                                           (200, 24, 30000.0, 140.0, None), (200, 24, 30000.0, 140.0, "packed"),
+                                           (256, 16, 12000.0, 250.0, "packed")])
+def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consumer(N, A, L, Rc, form, monkeypatch):
     """The specialised kernels do not keep the reference-shaped planes current: N <= 64 stores the table as
     thermometer codes + ages + own sequence numbers, and both families keep the xpos of young entries in the
     per-subject ring (csrc/step_fast64.hpp, step_wide.hpp); the planes `tkey` / `tx` only answer for entries older
@@ -1349,8 +1354,13 @@ def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consume
     every export.  The sparse topologies (Rc < 200) hold entries beyond the codes / the ring (keyed quads,
     byte-rank / 32-bit passes, hand-over at lag 7)."""
     from oracle.oracle import Oracle, SQ_IEEE
-    from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_RING, KERNEL_WIDE
+    from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_PACKED, KERNEL_RING, KERNEL_WIDE
     cfg = bench_config(N, A, L, mobility_vary=True, communication_range=Rc)
+    # the table form of a 128 < N <= 256 handle follows the density (N * 2 Rc / L >= 20 neighbours: packed); `form`
+    # forces the other one (DIRAL_TABLE_FORM, read at create): both forms on both kinds of topology
+    if form:
+        monkeypatch.setenv("DIRAL_TABLE_FORM", form)
+    want_packed = N <= 64 or (N > 128 and (form == "packed" or (form is None and N * 2 * Rc / L >= 20)))
     B = 4
     rng = np.random.default_rng(N * 7 + A)
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
@@ -1374,6 +1384,7 @@ def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consume
         env.force_general_kernel(general)
         obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, acts, t)
         assert (env.last_kernel() & (15 | KERNEL_RING)) == (KERNEL_GENERAL if general else _fam(N) | KERNEL_RING)
+        assert general or bool(env.last_kernel() & KERNEL_PACKED) == want_packed, env.last_kernel()
         o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, t)
         o_state = orc.obtain_state(acts, o_chobs, o_rew)
         assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
