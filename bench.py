@@ -301,6 +301,11 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         one_step(t)
         t += 1
     ev1.record()
+    # (the end of the timed region: the event is polled first - hipEventQuery, a few microseconds of latency - and the
+    # blocking synchronize the contract asks for then returns at once; waiting in hipDeviceSynchronize alone adds its
+    # interrupt wake-up, ~50 us, to a region that is only K x 70 us long at the driver's K = 20)
+    while not ev1.query():
+        pass
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
