@@ -223,8 +223,9 @@ def roofline_object(res, pmc):
         "unit": "GB/s",
         "frac": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
         "bytes_per_launch": res["layout_bytes_per_launch"],
-        "bytes_note": "compulsory HBM bytes of this build's table layout per launch (4-byte key per entry read + written, "
-                      "per-subject xpos rings, per-vehicle arrays, outputs): diral_amd/roofline.py",
+        "bytes_note": "compulsory HBM bytes of this build's table layout per launch (per entry one code byte + one age byte read "
+                      "+ written - a 4-byte (seq, age) word for 64 < N <= 128 -, per-subject xpos rings and sequence numbers, "
+                      "per-vehicle arrays, outputs): diral_amd/roofline.py",
         "kernel": res["kernel"],
         "kernel_ms": res["kernel_ms"],
         "traffic": traffic,
@@ -239,7 +240,7 @@ def roofline_object(res, pmc):
         "model_bytes_per_launch": res["algorithmic_bytes_per_launch"],
         "model_throughput_TBps": res["algorithmic_bytes_per_launch"] / k_s / 1e12,
         "model_note": "SURVEY 8d's canonical byte model (16-byte table entry read + written) over the kernel time: a throughput "
-                      "in the MODEL's units - this layout moves a 4-byte key per entry, so the figure can exceed the 8 TB/s "
+                      "in the MODEL's units - this layout moves 2 bytes per entry, so the figure can exceed the 8 TB/s "
                       "peak without the HBM being near it; not a roofline fraction",
     }
     return out

@@ -374,11 +374,8 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   q.posdist_type = p.posdist_type; q.age_limit = p.age_limit; q.out_f64 = p.out_f64;
   q.off_posdist = p.off_posdist; q.off_hist = p.off_hist;
   q.pos_x = p.pos_x; q.pos_y = p.pos_y; q.tkey = p.tkey; q.tx = p.tx; q.edges1 = e->edges1; q.state_out = p.state_out;
-  q.do_full = 0; q.do_type1 = 0; q.ring = nullptr;
-  if (type1 && e->tcode) {                                      // the packed table -> planes first
-    const hipError_t st = ensure_plane(e, s);
-    if (st != hipSuccess) return st;
-  }
+  q.do_full = 0; q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
+  q.flat_y = e->flat_y ? 1 : 0;
   const bool full_flat = full && e->flat_y;                     // one ranking of the env's x serves every viewer
   const bool type1_n64 = type1 && p.NV == 64;                   // lane = viewer, sort in registers
   const bool type1_lanes = type1 && !type1_n64;                 // 2 / 4 lanes per viewer (N <= 128 / 256)
@@ -390,17 +387,19 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   if (type1_n64) {
     q.do_type1 = 1;
     q.ring = (e->ring && !e->plane_valid) ? e->ring : nullptr;  // young entries straight from the ring: no materialise pass
+    if (q.ring && e->tcode) { q.tcode = e->tcode; q.tage = e->tage; q.tseq = e->tseq; }   // ... and the words from the packed table
     hipLaunchKernelGGL(posdist_type1_n64_kernel, dim3(p.B), dim3(64), posdist_type1_lds_bytes(p.K), s, q);
-    q.do_type1 = 0; q.ring = nullptr;
+    q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   if (type1_lanes) {
     const int lpv = p.N <= 128 ? 2 : 4, vw = 64 / lpv, nvb = (p.N + vw - 1) / vw;
     q.do_type1 = 1;
     q.ring = (e->ring && !e->plane_valid) ? e->ring : nullptr;
+    if (q.ring && e->tcode) { q.tcode = e->tcode; q.tage = e->tage; q.tseq = e->tseq; }
     const uint32_t lds = posdist_type1_lanes_lds_bytes(p.K, lpv);
     if (lpv == 2) hipLaunchKernelGGL(posdist_type1_lanes_kernel<2>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
     else hipLaunchKernelGGL(posdist_type1_lanes_kernel<4>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
-    q.do_type1 = 0; q.ring = nullptr;
+    q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   q.do_full = (full && !full_flat) ? 1 : 0;
   q.do_type1 = 0;

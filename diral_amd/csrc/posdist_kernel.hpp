@@ -44,7 +44,26 @@ struct PosdistParams {
   void* state_out;
   int do_full, do_type1;    // which of the two modes THIS launch serves
   const double* ring;       // xpos ring (aux_kernels.hpp) when the plane is incomplete, else null
+  // the packed table (step_fast64.hpp; step_wide.hpp at N > 128) when it is the current form, else null: the type-1
+  // kernels then build every (seq, age) word from the code byte, the age byte and the subject's own sequence number
+  // (`tkey` only answers for code-0 entries) instead of waiting for an unpack launch
+  const uint32_t* tcode;
+  const uint32_t* tage;
+  const uint32_t* tseq;
+  int flat_y;               // every pos_y == 0: whether a code-0 entry was ever heard (its ypos) cannot matter
 };
+
+// viewer u's table word (seq << 8) | age about subject k of env b, from the packed words
+__device__ inline uint32_t pd_packed_word(const PosdistParams& p, int b, int k, int u) {
+  const size_t qi = ((size_t)b * (p.NR >> 2) + (k >> 2)) * p.NV + u;
+  const uint32_t sh = 8u * (uint32_t)(k & 3);
+  const uint32_t r = (p.tcode[qi] >> sh) & 255u, a = (p.tage[qi] >> sh) & 255u;
+  const size_t row = (size_t)b * p.NR + k;
+  // (code 0 = never heard, or older than the codes reach: its xpos comes from the plane either way, and the sequence
+  // number only decides the entry's ypos - 0 or the subject's lane - which is 0 on the one-lane highway)
+  const uint32_t seq = r ? p.tseq[row] - 8u + (uint32_t)__popc(r) : (p.flat_y ? 0u : (p.tkey[row * p.NV + u] >> 8));
+  return (seq << 8) | a;
+}
 
 constexpr int kPdWaves = 4;
 
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
   double v[64];
   double dmax = 0.0;
   int nvalid = 0;
+  const uint32_t ts_lane = p.tseq ? p.tseq[(size_t)b * p.NR + (lane < p.NR ? lane : 0)] : 0u;
   const uint32_t* const trow = p.tkey + (size_t)b * p.NR * 64 + lane;     // NV == 64 for N <= 64
   const double* const xrow = p.tx + (size_t)b * p.NR * 64 + lane;
   const double* const rrow = p.ring ? p.ring + (size_t)b * p.NR * 8 : nullptr;
@@ -265,6 +285,28 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
     uint32_t tw[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) tw[c] = trow[(k0 + c) * 64];
+    if (p.tcode) {
+      // the packed table: four code words + four age words serve the batch's 16 rows; the subjects' own sequence
+      // numbers sit in `ts_lane` (lane k: subject k)
+      uint32_t cq[4], aq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int qi = (k0 >> 2) + q;
+        const size_t at = ((size_t)b * (p.NR >> 2) + (qi < (p.NR >> 2) ? qi : 0)) * 64 + lane;
+        cq[q] = p.tcode[at];
+        aq[q] = p.tage[at];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const uint32_t sh = 8u * (uint32_t)(c & 3);
+        const uint32_t r = (cq[c >> 2] >> sh) & 255u, a = (aq[c >> 2] >> sh) & 255u;
+        const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)ts_lane, k0 + c);
+        // (code 0: never heard, or older than the codes reach - the plane holds its xpos either way, and its sequence
+        // number only decides the ypos, 0 on the one-lane highway)
+        const uint32_t seq = r ? tk - 8u + (uint32_t)__popc(r) : (p.flat_y ? 0u : (tw[c] >> 8));
+        tw[c] = (seq << 8) | a;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int k = k0 + c;
@@ -411,13 +453,34 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
     uint32_t tw[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) tw[c] = trow[(size_t)(k0 + c) * NV];
+    if (p.tcode) {
+      // the packed table: four code words + four age words serve the batch's 16 rows (see posdist_type1_n64_kernel)
+      uint32_t cq[4], aq[4];
+      const int tq = t < NV ? t : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int qi = ((sub * 64 + k0) >> 2) + q;
+        const size_t at = ((size_t)b * (p.NR >> 2) + (qi < (p.NR >> 2) ? qi : 0)) * NV + tq;
+        cq[q] = p.tcode[at];
+        aq[q] = p.tage[at];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int kg = sub * 64 + k0 + c;
+        const uint32_t sh = 8u * (uint32_t)(c & 3);
+        const uint32_t r = (cq[c >> 2] >> sh) & 255u, a = (aq[c >> 2] >> sh) & 255u;
+        const uint32_t tk = p.tseq[(size_t)b * p.NR + (kg < p.NR ? kg : 0)];
+        const uint32_t seq = r ? tk - 8u + (uint32_t)__popc(r) : (p.flat_y ? 0u : (tw[c] >> 8));
+        tw[c] = (seq << 8) | a;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const int k = k0 + c;
       const uint32_t seq = tw[c] >> 8;
       const double* src = xrow + (size_t)k * NV;
       if (rrow) {                                                          // uniform: the plane holds only entries 7+ stamps old
-        const uint32_t tk = drow[(size_t)k * NV + k] >> 8;
+        const uint32_t tk = p.tseq ? p.tseq[row0 + (sub * 64 + k < p.NR ? k : 0)] : drow[(size_t)k * NV + k] >> 8;
         if (sub * 64 + k < N && tk - seq <= 7u) src = rrow + k * 8 + (seq & 7u);
       }
       v[k] = *src;
