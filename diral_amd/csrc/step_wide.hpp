@@ -313,7 +313,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   typedef typename std::conditional<VPL == 4, uint32_t, uint16_t>::type mword_t;
 
   extern __shared__ __align__(16) unsigned char smem[];
-  const WideLds lay = wide_lds_layout(VPL, p.A, p.K);
+  // The first eight words of the argument block (N ... age_limit), each through a scalar load of its OWN: read as `p.N`
+  // etc. the compiler fetches them with one s_load_dwordx8 and - once the hot loops have pushed the tuple out of the
+  // SGPR file - reloads all eight lanes (v_readlane, a VALU instruction each) at every use of any one of them:
+  // 43 x 8 reloads in the N <= 128 kernel, 16 per table column in its finalize loop for the age limit alone.
+  auto late_i32 = [](size_t off) -> int {
+    return *(const __attribute__((address_space(4))) int*)(late_kernarg_base() + off);
+  };
+  const int N = late_i32(offsetof(FastParams, N)), A = late_i32(offsetof(FastParams, A)), K = late_i32(offsetof(FastParams, K));
+  const int NV = late_i32(offsetof(FastParams, NV)), NRows = late_i32(offsetof(FastParams, NR));
+  const int age_limit = late_i32(offsetof(FastParams, age_limit));
+  const int reward_design = late_i32(offsetof(FastParams, reward_design));
+  const uint32_t pflags = (uint32_t)late_i32(offsetof(FastParams, flags));
+  auto late_f64 = [](size_t off) -> double {
+    return *(const __attribute__((address_space(4))) double*)(late_kernarg_base() + off);
+  };
+  const double pL = late_f64(offsetof(FastParams, L)), pRc = late_f64(offsetof(FastParams, Rc)), pRb = late_f64(offsetof(FastParams, Rb));
+  const WideLds lay = wide_lds_layout(VPL, A, K);
   double* s_px = reinterpret_cast<double*>(smem + lay.px);
   double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
@@ -338,10 +354,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int N = p.N, A = p.A, K = p.K, NV = p.NV;
   const int KP = wide_hist_stride(K);          // histogram row stride (words, two bins each)
   const size_t bN = (size_t)b * N;
-  const size_t bR = (size_t)b * p.NR;
+  const size_t bR = (size_t)b * NRows;
   DIRAL_WSTAMP(0);
 
   // ---- P0: per-vehicle state and the post-move position into LDS --------------
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       const unsigned int xh = (unsigned int)__double2hiint(x) & 0x7fffffffu;
       x_unsafe = !(xh >= 0x24000000u || (xh | (unsigned int)__double2loint(x)) == 0u);
     }
-    double nx = lv ? py_mod_pos(x + v + p.L, p.L) : 0.0;     // network.py:203
+    double nx = lv ? py_mod_pos(x + v + pL, pL) : 0.0;     // network.py:203
     if (EXTRA && p.trace && lv) {                            // replay branch, network.py:194-199
       long long tt = (p.t + (p.t_dev ? *p.t_dev : 0ll)) % p.trace_len;
       if (tt < 0) tt += p.trace_len;
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             } else {
               d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
             }
-            const bool inr = d < p.Rc;
+            const bool inr = d < pRc;
             const bool bt = inr && (d < best[j]);
             best[j] = bt ? d : best[j];
             bid[j] = bt ? w : bid[j];
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
             if ((CH || (EXTRA && p.prr)) && c > 1)              // in_range[tx] (test_env.py:395-397)
               n_in += __popcll(__ballot((FULL || lane + 64 * j < N) && (myact[j] != i) && inr));
             if (EXTRA && !CH && p.design && c > 1)              // my_step_design: tx of this resource within 2 Rc
-              n_in += __popcll(__ballot((myact[j] == i) && (lane + 64 * j != w) && (d < 2.0 * p.Rc)));
+              n_in += __popcll(__ballot((myact[j] == i) && (lane + 64 * j != w) && (d < 2.0 * pRc)));
           }
           if ((CH || (EXTRA && p.prr)) && c > 1 && lane == 0) *inr_of(w) = n_in;
           if (EXTRA && !CH && p.design && c > 1 && lane == 0) *rtx_of(w) = (n_in == 0) ? 1.0 : -(double)(n_in + 1);   // network.py:122-157
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
       if (!CH && c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
         double rw;
-        if (p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
+        if (reward_design == 2 && !(pflags & DIRAL_F_TOY_WEIGHTS)) {
           if (c == 2) {
             // the two transmitters, ascending (network.py:291-295 weight of a pair)
             int ab[2], n = 0;
@@ -493,12 +508,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
               while (m) { ab[n < 2 ? n : 1] = j * 64 + __builtin_ctzll(m); ++n; m &= m - 1; }
             }
             const double dab = fast_dist<true>(s_px[ab[0]], 0.0, s_px[ab[1]], 0.0);
-            rw = 2.0 * (double)(dab > p.Rc) - (double)c;       // (0 + d) / 1 == d exactly
+            rw = 2.0 * (double)(dab > pRc) - (double)c;       // (0 + d) / 1 == d exactly
           } else {
             rw = 0.0 - (double)c;
           }
         } else {
-          rw = wide_collision_reward<VPL>(p.reward_design, p.flags, p.L, p.Rc, N, s_mask + i * VPL, c, s_px);
+          rw = wide_collision_reward<VPL>(reward_design, pflags, pL, pRc, N, s_mask + i * VPL, c, s_px);
         }
         if (lane == 0) s_rv[i] = rw;
       }
@@ -521,8 +536,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       for (int j = 0; j < VPL; ++j) c += __popcll(s_mask[a * VPL + j]);
       if (CH) {
         const double R = (c > 1) ? *rtx_of(u) : 1.0;                          // test_env.py:411-429
-        const bool plain = (p.reward_design == 2);
-        rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
+        const bool plain = (reward_design == 2);
+        rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
       } else if (c > 1) { rw = (EXTRA && p.design) ? *rtx_of(u) : s_rv[a]; coll = 1; } else { rw = 1.0; sole = 1; }      // test_env.py:211-222, 297-301
       if (!CH && EXTRA && p.prr) prr = (c > 1) ? *rtx_of(u) : 1.0;            // DIRAL_F_TRACK_PRR: the metric only
@@ -569,7 +584,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   const unsigned int sw_lds = __builtin_amdgcn_readfirstlane(lds_addr(sw));
   // (the dynamic LDS segment starts at address 0 when the kernel has no static LDS - checked, not assumed)
   const bool lds_base_is_zero = __builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u;
-  const double inv_w = p.inv_w;
+  const double inv_w = late_f64(offsetof(FastParams, inv_w));
   const LateFastArgs lpp = (LateFastArgs)late_kernarg_base();      // the packed planes: late-bound kernel arguments
   const global_ptr<double> ringp = uniform_ptr(lpp->ring, 0);
   unsigned int* const g_tcode = lpp->tcode;
@@ -622,9 +637,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       d = dist_general(s_npx[u] - xg, 0.0);
       v = (xg - s_npx[u] > 0.0) ? d : -d;
     }
-    const bool ok = lv && (u != k) && ((int)(wn & 255u) < p.age_limit) && (d < p.Rb);
+    const bool ok = lv && (u != k) && ((int)(wn & 255u) < age_limit) && (d < pRb);
     if (ok) {
-      int est = (int)((v + p.Rb) * inv_w);
+      int est = (int)((v + pRb) * inv_w);
       est = est > K - 1 ? K - 1 : est;
       const double e0 = s_edges[est], e1 = s_edges[est + 1];
       const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
-    if (kbase >= p.NR) break;
+    if (kbase >= NRows) break;
     if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
     // The table is stored the way the merge wants it (round 3, as in step_fast64.hpp): per row-quad and viewer one word
     // of four thermometer codes of the entries' lags (0 = never heard, or older than 7: then `tkey` holds its
@@ -670,7 +685,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     //  * a flagged quad: the pass goes through the planes - its entries are written to `tkey` as (seq, age) words
     //    (unstamped), the byte-rank / 32-bit pass of round 2 runs on them unchanged, and the packed words are
     //    rebuilt from the words it leaves.  Rare, and kept apart so that the coded pass owns its registers.
-    const size_t qrow = (size_t)b * (p.NR >> 2) + (kbase >> 2);
+    const size_t qrow = (size_t)b * (NRows >> 2) + (kbase >> 2);
     const global_ptr<unsigned int> tcrow = uniform_ptr(g_tcode, qrow * NV);
     const global_ptr<unsigned int> tarow = uniform_ptr(g_tage, qrow * NV);
     const global_ptr<unsigned int> tsrow = uniform_ptr(g_tseq, bR + kbase);
@@ -902,9 +917,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
-    if (kbase >= p.NR) break;
+    if (kbase >= NRows) break;
     if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
-    const size_t qrow = (size_t)b * (p.NR >> 2) + (kbase >> 2);
+    const size_t qrow = (size_t)b * (NRows >> 2) + (kbase >> 2);
     const global_ptr<unsigned int> tcrow = uniform_ptr(g_tcode, qrow * NV);
     const global_ptr<unsigned int> tarow = uniform_ptr(g_tage, qrow * NV);
     const global_ptr<unsigned int> tsrow = uniform_ptr(g_tseq, bR + kbase);
@@ -947,320 +962,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
       wave_lds_order();
     }
-    // One packed pass, ONE body for both packed representations (two copies of it cost 12 more spilled
-    // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
-    // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are
-    // simply repeated with the other pair of constants.  Only the merge loop exists per representation.
-    bool thermo = false;                         // (a flagged pass: the codes do not reach - byte ranks, then 32-bit keys)
-    bool packed_ok;
-    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 lag bytes (then codes / ranks) each; ages, same packing
-    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
-    for (;;) {
-    const unsigned int lag_clamp = thermo ? 12u : 255u, lag_limit = thermo ? 8u : 255u;
-    DIRAL_WCLOCK(tc0);
-    // -- load + Vehicle.periodic_update (vehicle.py:56-70), lags behind the subject's
-    //    own fresh sequence number
-#pragma unroll
-    for (int q = 0; q < NK; ++q) { kp[q] = 0u; agew[q] = 0u; }
-    tkov = 0u;
-    bool bad = false;
-    // (16 table words in flight at a time: LC columns x VPL slots)
-    constexpr int LC = DIRAL_WIDE_INFLIGHT / VPL;
-#pragma unroll
-    for (int c0 = 0; c0 < PC; c0 += LC) {
-    unsigned int wraw[LC * VPL];
-#pragma unroll
-    for (int c = 0; c < LC; ++c) {
-      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c0 + c) * NV);   // rows are padded to 16: in bounds
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = c0; c < c0 + LC; ++c) {
-      const int k = kbase + c;
-      const bool kval = FULL || k < N;
-      unsigned int seq[VPL], age[VPL];
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const int u = lane + 64 * j;
-        const unsigned int w = (FULL || (kval && u < N)) ? wraw[(c - c0) * VPL + j] : 0u;
-        seq[j] = w >> 8;
-        const unsigned int a0 = w & 255u;
-        age[j] = a0 + (a0 < 255u ? 1u : 0u);
-        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
-          const bool own = kval && (lane == (k & 63));
-          seq[j] += own ? 1u : 0u;
-          age[j] = own ? 0u : age[j];
-          ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
-        }
-      }
-      unsigned int t = 0u;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)seq[j], k & 63);
-        t = ((k >> 6) == j) ? cand : t;
-      }
-      tkov = (lane == c) ? t : tkov;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        // codes: lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); ranks: 0..254, or 255 =
-        // never heard; anything else is not exact in that representation
-        const unsigned int lagc = min(t - seq[j], lag_clamp);
-        // ('||' / '&&' compile to exec-mask control flow per entry, the bitwise form to straight-line code: the
-        // latter is 8 % faster on the plain N <= 128 kernel, 4 % slower on its RICH instantiation and 25 % SLOWER at
-        // N <= 256 - register allocation - so each gets the form that measured best)
-        if constexpr (VPL == 2 && !RICH) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
-        else bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
-        kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
-        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    }
-    // (pinned packed words: left alone, the compiler sinks the packing below the exit test and keeps all
-    // PC x VPL lags alive across it)
-    if constexpr (VPL == 2) {
-#pragma unroll
-      for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
-    }
-    packed_ok = (__ballot(bad) == 0ull);
-    DIRAL_WCLOCK(tc1);
-    if (packed_ok || !thermo) break;
-    thermo = false;
-    }
-    if (packed_ok) {
-      // lag bytes -> thermometer codes, or byte ranks 255 - lag (the complement; 255 -> 0: never heard)
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp[q] = thermo ? thermo_codes(kp[q]) : ~kp[q];
-      const unsigned int seq_base = thermo ? 8u : 255u;
-      unsigned int kp0[NK];                      // the ranks before the merge
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
-      // -- Vehicle.received_update for every (resource, rx), resources ascending:
-      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
-      if constexpr (!VEC) {
-        // plane layout sw[word][viewer]: one 4-byte gather per word and slot
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
-        wave_lds_order();
-        auto merge_loop = [&](auto wtag, auto ttag) {
-          constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
-          constexpr bool THERMO = decltype(ttag)::value;
-          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
-          unsigned long long rem = actw;
-          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-          while (rem) {
-            rem &= rem - 1;
-            const unsigned int mw = m_next;
-            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-            unsigned int v[NK], sa[VPL];
-            unpack_src<VPL, 2u>(mw, sa);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-#pragma unroll
-              for (int w = 0; w < NW; ++w)
-                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(SCR * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
-                                      : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
-            }
-            // a transmitter's words are not written during its own resource, so all
-            // gathers of a step may precede all its writes
-            wave_lds_order();
-            if constexpr (THERMO) {
-#pragma unroll
-              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
-            } else {
-              max_u8_words<NK>(kp, v);
-            }
-            lds_store4_lane_linear(sw_lds, kp);     // (ds_write_addtid_b32: no address VGPR, half the LDS store cycles) sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
-            wave_lds_order();
-          }
-        };
-        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
-        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
-        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
-        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
-      } else {
-        // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
-        // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
-        // wider pass halves the number of chains a wave walks per column.
-        typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
-        uvec* const sv = reinterpret_cast<uvec*>(sw);
-        auto put = [&]() {
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            uvec t;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
-            sv[lane + 64 * j] = t;
-          }
-        };
-        put();
-        wave_lds_order();
-        auto merge_loop = [&](auto wtag, auto ttag) {
-          constexpr int W = decltype(wtag)::value;
-          constexpr bool THERMO = decltype(ttag)::value;
-          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
-          unsigned long long rem = actw;
-          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-          while (rem) {
-            rem &= rem - 1;
-            const unsigned int mw = m_next;
-            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-            unsigned int v[NK], sa[VPL];
-            unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-              const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
-#pragma unroll
-              for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
-            }
-            wave_lds_order();
-            if constexpr (THERMO) {
-#pragma unroll
-              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
-            } else {
-              max_u8_words<NK>(kp, v);
-            }
-            put();
-            wave_lds_order();
-          }
-        };
-        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
-        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
-        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
-        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
-      }
-      DIRAL_WCLOCK(tc2);
-
-      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
-      //    extraction).  The rank -> xpos table of the column: the subject's 8 latest stamps from its ring row
-      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass), the few older entries
-      //    scatter their xpos from the plane; then EVERY entry reads its xpos by its final rank.
-      double rg = 0.0;
-      {
-        const unsigned int rc = ul >> 3, rl = ul & 7u;
-        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
-        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
-      }
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-#pragma unroll FIN_UNROLL
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * w + cc;
-        const int k = kbase + c;
-        const bool kvalid = FULL || k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        const double pxk = s_px[kvalid ? k : 0];
-        if ((ul >> 3) == (unsigned int)c) {
-          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
-          const unsigned int l = ul & 7u;
-          xt[thermo ? ((0xffu << l) & 0xffu) : 255u - l] = (l == 0u) ? pxk : rg;
-          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
-        }
-        unsigned int rank0[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          rank0[j] = pick(kp0, j, w, cc);
-          // older than the ring reaches (codes: only the never-heard entries): the plane holds its xpos
-          const bool old = thermo ? rank0[j] == 0u : rank0[j] <= 247u;
-          if (old && (FULL || (u < N && kvalid))) xt[rank0[j]] = txrow[ul + 64u * j];
-        }
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int rf = pick(kp, j, w, cc);
-          const double xg = xt[rf];
-          const bool upd = rf != rank0[j];
-          // sequence number back from the rank / from the code (lag = 8 - popcount)
-          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
-          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, w, cc));
-          // the plane must hold the xpos of every entry the ring may not reach next slot: an entry that is now 7
-          // behind, or a fresh copy of an older one
-          const bool at7 = thermo ? rf == 0x80u : rf == 248u;
-          const bool far = thermo ? rf == 0x80u : (rf != 0u && rf <= 248u);
-          emit(k, kvalid, j, far && (upd || at7), wn, xg, tkrow, txrow, std::integral_constant<int, 1>{});
-        }
-        wave_lds_order();
-      }
-    } else {
-      // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
-      //    very stale tables: an entry with lag >= 255 and seq != 0)
-      DIRAL_WCLOCK(tc2);
-      double* const sx = xt;
-#pragma unroll 1
-      for (int c = 0; c < PC; ++c) {
-        const int k = kbase + c;
-        const bool kvalid = k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        unsigned int ws[VPL], key[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          const bool lv = (u < N);
-          unsigned int w = tkrow[lv ? u : 0];
-          w = (lv && kvalid) ? w : 0u;
-          const bool own = lv && (u == k);
-          const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
-          const unsigned int a0 = w & 255u;
-          ws[j] = (seq << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
-          key[j] = (ws[j] & ~255u) | (unsigned int)u;
-          sw[u] = key[j];
-        }
-        wave_lds_order();
-        unsigned long long rem = actw;
-        while (rem) {
-          const int i = __builtin_ctzll(rem);
-          rem &= rem - 1;
-          const unsigned int mw = (unsigned int)s_mtab[i * MT + lane];
-          unsigned int v[VPL];
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) v[j] = sw[(mw >> (8 * j)) & 255u];
-          wave_lds_order();
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) { key[j] = max(key[j], v[j]); sw[lane + 64 * j] = key[j]; }
-          wave_lds_order();
-        }
-        const double pxk = s_px[kvalid ? k : 0];
-        double xo[VPL];
-        unsigned int tk_own = 0u;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(ws[j] >> 8), k & 63);
-          tk_own = ((k >> 6) == j) ? cand : tk_own;
-        }
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          xo[j] = txrow[u < N ? u : 0];
-          // a young entry's xpos is in the subject's ring row, not (necessarily) in the plane
-          if (tk_own - (ws[j] >> 8) <= 7u) xo[j] = ringp[(size_t)(bR + (kvalid ? k : 0)) * 8 + ((ws[j] >> 8) & 7u)];
-          xo[j] = (u == k) ? pxk : xo[j];
-        }
-        if (lane == 0 && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;   // this slot's stamp (after the row was read)
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
-        wave_lds_order();
-        double xs[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) xs[j] = sx[key[j] & 255u];
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
-          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow,
-               std::integral_constant<int, 2>{});   // with the ring: the plane complete for this column
-        }
-        wave_lds_order();
-      }
-    }
+#define DIRAL_PASS_THERMO_FIRST false             // (a flagged pass: the codes do not reach - byte ranks, then 32-bit keys)
+#include "step_wide_pass.inc"
+#undef DIRAL_PASS_THERMO_FIRST
     {
       // the packed words again, from the (seq, age) words the pass left in `tkey`; the fresh sequence numbers;
       // the flags of the next slot: an entry 7 or more behind keeps its quad on this path
@@ -1307,329 +1011,21 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
-    if (kbase >= p.NR) break;
+    if (kbase >= NRows) break;
     if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
-    // One packed pass, ONE body for both packed representations (two copies of it cost 12 more spilled
-    // registers): the table words are loaded and turned into clamped lag bytes - clamp 12 / limit 8 for the
-    // thermometer codes, 255 / 255 for the byte ranks - and if an entry does not fit the codes the loads are
-    // simply repeated with the other pair of constants.  Only the merge loop exists per representation.
-    bool thermo = true;
-    bool packed_ok;
-    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 lag bytes (then codes / ranks) each; ages, same packing
-    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
-    for (;;) {
-    const unsigned int lag_clamp = thermo ? 12u : 255u, lag_limit = thermo ? 8u : 255u;
-    DIRAL_WCLOCK(tc0);
-    // -- load + Vehicle.periodic_update (vehicle.py:56-70), lags behind the subject's
-    //    own fresh sequence number
-#pragma unroll
-    for (int q = 0; q < NK; ++q) { kp[q] = 0u; agew[q] = 0u; }
-    tkov = 0u;
-    bool bad = false;
-    // (16 table words in flight at a time: LC columns x VPL slots)
-    constexpr int LC = DIRAL_WIDE_INFLIGHT / VPL;
-#pragma unroll
-    for (int c0 = 0; c0 < PC; c0 += LC) {
-    unsigned int wraw[LC * VPL];
-#pragma unroll
-    for (int c = 0; c < LC; ++c) {
-      const global_ptr<const unsigned int> row = uniform_ptr<const unsigned int>(p.tkey, (bR + kbase + c0 + c) * NV);   // rows are padded to 16: in bounds
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) wraw[c * VPL + j] = row[ul + 64u * j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = c0; c < c0 + LC; ++c) {
-      const int k = kbase + c;
-      const bool kval = FULL || k < N;
-      unsigned int seq[VPL], age[VPL];
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const int u = lane + 64 * j;
-        const unsigned int w = (FULL || (kval && u < N)) ? wraw[(c - c0) * VPL + j] : 0u;
-        seq[j] = w >> 8;
-        const unsigned int a0 = w & 255u;
-        age[j] = a0 + (a0 < 255u ? 1u : 0u);
-        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
-          const bool own = kval && (lane == (k & 63));
-          seq[j] += own ? 1u : 0u;
-          age[j] = own ? 0u : age[j];
-          ovf = ovf || (own && seq[j] >= (1u << 24) - 1u);
-        }
-      }
-      unsigned int t = 0u;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)seq[j], k & 63);
-        t = ((k >> 6) == j) ? cand : t;
-      }
-      tkov = (lane == c) ? t : tkov;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        // codes: lag byte 0..7, or 12 = never heard (seq 0 and at least 12 slots behind); ranks: 0..254, or 255 =
-        // never heard; anything else is not exact in that representation
-        const unsigned int lagc = min(t - seq[j], lag_clamp);
-        // ('||' / '&&' compile to exec-mask control flow per entry, the bitwise form to straight-line code: the
-        // latter is 8 % faster on the plain N <= 128 kernel, 4 % slower on its RICH instantiation and 25 % SLOWER at
-        // N <= 256 - register allocation - so each gets the form that measured best)
-        if constexpr (VPL == 2 && !RICH) bad |= (lagc >= lag_limit) & ((lagc < lag_clamp) | (seq[j] != 0u));
-        else bad = bad || (lagc >= lag_limit && (lagc < lag_clamp || seq[j] != 0u));
-        kp[(c >> 2) * VPL + j] |= lagc << (8 * (c & 3));
-        agew[(c >> 2) * VPL + j] |= age[j] << (8 * (c & 3));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    }
-    // (pinned packed words: left alone, the compiler sinks the packing below the exit test and keeps all
-    // PC x VPL lags alive across it)
-    if constexpr (VPL == 2) {
-#pragma unroll
-      for (int q = 0; q < NK; ++q) asm volatile("" : "+v"(kp[q]));
-    }
-    packed_ok = (__ballot(bad) == 0ull);
-    DIRAL_WCLOCK(tc1);
-    if (packed_ok || !thermo) break;
-    thermo = false;
-    }
-    if (packed_ok) {
-      // lag bytes -> thermometer codes, or byte ranks 255 - lag (the complement; 255 -> 0: never heard)
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp[q] = thermo ? thermo_codes(kp[q]) : ~kp[q];
-      const unsigned int seq_base = thermo ? 8u : 255u;
-      unsigned int kp0[NK];                      // the ranks before the merge
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
-      // -- Vehicle.received_update for every (resource, rx), resources ascending:
-      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
-      if constexpr (!VEC) {
-        // plane layout sw[word][viewer]: one 4-byte gather per word and slot
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) sw[w * NPAD + lane + 64 * j] = kp[w * VPL + j];
-        wave_lds_order();
-        auto merge_loop = [&](auto wtag, auto ttag) {
-          constexpr int W = decltype(wtag)::value;       // wave index, or -1: base in a register
-          constexpr bool THERMO = decltype(ttag)::value;
-          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
-          unsigned long long rem = actw;
-          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-          while (rem) {
-            rem &= rem - 1;
-            const unsigned int mw = m_next;
-            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-            unsigned int v[NK], sa[VPL];
-            unpack_src<VPL, 2u>(mw, sa);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-#pragma unroll
-              for (int w = 0; w < NW; ++w)
-                v[w * VPL + j] = W >= 0 ? *lds_at<unsigned int>(SCR * (W >= 0 ? W : 0) + w * NPAD * 4 + sa[j])
-                                      : *reinterpret_cast<const unsigned int*>(swb + w * NPAD * 4 + sa[j]);
-            }
-            // a transmitter's words are not written during its own resource, so all
-            // gathers of a step may precede all its writes
-            wave_lds_order();
-            if constexpr (THERMO) {
-#pragma unroll
-              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
-            } else {
-              max_u8_words<NK>(kp, v);
-            }
-            lds_store4_lane_linear(sw_lds, kp);     // (ds_write_addtid_b32: no address VGPR, half the LDS store cycles) sw[w * NPAD + lane + 64 j] = kp[w * VPL + j]: word q at 256 q + 4 lane
-            wave_lds_order();
-          }
-        };
-        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
-        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
-        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
-        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
-      } else {
-        // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
-        // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
-        // wider pass halves the number of chains a wave walks per column.
-        typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
-        uvec* const sv = reinterpret_cast<uvec*>(sw);
-        auto put = [&]() {
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            uvec t;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
-            sv[lane + 64 * j] = t;
-          }
-        };
-        put();
-        wave_lds_order();
-        auto merge_loop = [&](auto wtag, auto ttag) {
-          constexpr int W = decltype(wtag)::value;
-          constexpr bool THERMO = decltype(ttag)::value;
-          const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
-          unsigned long long rem = actw;
-          unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-          while (rem) {
-            rem &= rem - 1;
-            const unsigned int mw = m_next;
-            if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-            unsigned int v[NK], sa[VPL];
-            unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-              const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
-#pragma unroll
-              for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
-            }
-            wave_lds_order();
-            if constexpr (THERMO) {
-#pragma unroll
-              for (int q = 0; q < NK; ++q) kp[q] |= v[q];
-            } else {
-              max_u8_words<NK>(kp, v);
-            }
-            put();
-            wave_lds_order();
-          }
-        };
-        auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
-        auto merge_ranks = [&](auto wtag) { merge_loop(wtag, std::false_type{}); };
-        if (thermo) DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
-        else DIRAL_WIDE_DISPATCH_WAVE(merge_ranks);
-      }
-      DIRAL_WCLOCK(tc2);
-
-      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
-      //    extraction).  The rank -> xpos table of the column: the subject's 8 latest stamps from its ring row
-      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass), the few older entries
-      //    scatter their xpos from the plane; then EVERY entry reads its xpos by its final rank.
-      double rg = 0.0;
-      {
-        const unsigned int rc = ul >> 3, rl = ul & 7u;
-        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
-        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
-      }
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-#pragma unroll FIN_UNROLL
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * w + cc;
-        const int k = kbase + c;
-        const bool kvalid = FULL || k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        const double pxk = s_px[kvalid ? k : 0];
-        if ((ul >> 3) == (unsigned int)c) {
-          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
-          const unsigned int l = ul & 7u;
-          xt[thermo ? ((0xffu << l) & 0xffu) : 255u - l] = (l == 0u) ? pxk : rg;
-          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
-        }
-        unsigned int rank0[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          rank0[j] = pick(kp0, j, w, cc);
-          // older than the ring reaches (codes: only the never-heard entries): the plane holds its xpos
-          const bool old = thermo ? rank0[j] == 0u : rank0[j] <= 247u;
-          if (old && (FULL || (u < N && kvalid))) xt[rank0[j]] = txrow[ul + 64u * j];
-        }
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int rf = pick(kp, j, w, cc);
-          const double xg = xt[rf];
-          const bool upd = rf != rank0[j];
-          // sequence number back from the rank / from the code (lag = 8 - popcount)
-          const unsigned int seqf = rf ? tk_own - seq_base + (thermo ? (unsigned int)__popc(rf) : rf) : 0u;
-          const unsigned int wn = (seqf << 8) | (upd ? 0u : pick(agew, j, w, cc));
-          // the plane must hold the xpos of every entry the ring may not reach next slot: an entry that is now 7
-          // behind, or a fresh copy of an older one
-          const bool at7 = thermo ? rf == 0x80u : rf == 248u;
-          const bool far = thermo ? rf == 0x80u : (rf != 0u && rf <= 248u);
-          emit(k, kvalid, j, far && (upd || at7), wn, xg, tkrow, txrow, std::integral_constant<int, 1>{});
-        }
-        wave_lds_order();
-      }
-    } else {
-      // -- 32-bit path, column by column: key = (seq << 8) | source viewer (imported or
-      //    very stale tables: an entry with lag >= 255 and seq != 0)
-      DIRAL_WCLOCK(tc2);
-      double* const sx = xt;
-#pragma unroll 1
-      for (int c = 0; c < PC; ++c) {
-        const int k = kbase + c;
-        const bool kvalid = k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        unsigned int ws[VPL], key[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          const bool lv = (u < N);
-          unsigned int w = tkrow[lv ? u : 0];
-          w = (lv && kvalid) ? w : 0u;
-          const bool own = lv && (u == k);
-          const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
-          const unsigned int a0 = w & 255u;
-          ws[j] = (seq << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
-          key[j] = (ws[j] & ~255u) | (unsigned int)u;
-          sw[u] = key[j];
-        }
-        wave_lds_order();
-        unsigned long long rem = actw;
-        while (rem) {
-          const int i = __builtin_ctzll(rem);
-          rem &= rem - 1;
-          const unsigned int mw = (unsigned int)s_mtab[i * MT + lane];
-          unsigned int v[VPL];
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) v[j] = sw[(mw >> (8 * j)) & 255u];
-          wave_lds_order();
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) { key[j] = max(key[j], v[j]); sw[lane + 64 * j] = key[j]; }
-          wave_lds_order();
-        }
-        const double pxk = s_px[kvalid ? k : 0];
-        double xo[VPL];
-        unsigned int tk_own = 0u;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int cand = (unsigned int)__builtin_amdgcn_readlane((int)(ws[j] >> 8), k & 63);
-          tk_own = ((k >> 6) == j) ? cand : tk_own;
-        }
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const int u = lane + 64 * j;
-          xo[j] = txrow[u < N ? u : 0];
-          // a young entry's xpos is in the subject's ring row, not (necessarily) in the plane
-          if (tk_own - (ws[j] >> 8) <= 7u) xo[j] = ringp[(size_t)(bR + (kvalid ? k : 0)) * 8 + ((ws[j] >> 8) & 7u)];
-          xo[j] = (u == k) ? pxk : xo[j];
-        }
-        if (lane == 0 && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;   // this slot's stamp (after the row was read)
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) sx[lane + 64 * j] = xo[j];
-        wave_lds_order();
-        double xs[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) xs[j] = sx[key[j] & 255u];
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const bool upd = ((key[j] ^ ws[j]) >> 8) != 0u;
-          emit(k, kvalid, j, upd, upd ? (key[j] & ~255u) : ws[j], upd ? xs[j] : xo[j], tkrow, txrow,
-               std::integral_constant<int, 2>{});   // with the ring: the plane complete for this column
-        }
-        wave_lds_order();
-      }
-    }
+#define DIRAL_PASS_THERMO_FIRST true
+#include "step_wide_pass.inc"
+#undef DIRAL_PASS_THERMO_FIRST
 #ifdef DIRAL_TIMING
     DIRAL_WCLOCK(tc3);
     acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
 #endif
   }
   }
-  if (ovf) atomicOr(((LateFastArgs)late_kernarg_base())->err, kErrSeq);
+  if (__ballot(ovf) != 0ull) {                     // (wave-uniform branch around the late-bound load)
+    uint32_t* const errp = ((LateFastArgs)late_kernarg_base())->err;
+    if (lane == 0) atomicOr(errp, kErrSeq);
+  }
 #ifdef DIRAL_TIMING
   if (lane == 0 && p.dbg) {      // synthetic stamps: accumulated load / merge / finalize time of all passes
     unsigned long long* d = p.dbg + ((size_t)b * WAVES + wave) * 8;
@@ -1731,7 +1127,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       // barriers ago; the host dispatches here only with rew_out set when the column exists):
       // 2 KB of LDS for it would cost the third workgroup per CU at N = 256
       rich_write_state<OUT64>(
-          rr, p.flags, N, A, K, p.L, state_out, bN, tid, THREADS, [&](int u) { return s_act[u]; }, chv,
+          rr, pflags, N, A, K, pL, state_out, bN, tid, THREADS, [&](int u) { return s_act[u]; }, chv,
           [&](int u, int bin) {
             const unsigned int n = s_cnt[u];
             const unsigned int h = (s_hist[u * KP + (bin >> 1)] >> (16 * (bin & 1))) & 0xffffu;
