@@ -745,7 +745,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         // sequence number back from the code: lag = 8 - popcount
         const unsigned int seqn = tk_own - 8u + (unsigned int)__popc(rf);
         double xg = ring_x(rv, c, seqn);
-        if (rf == 0u) xg = txp[off];                                // never heard: the ghost xpos lives in the plane
+        if (rf == 0u) {                                             // never heard: the ghost xpos lives in the plane
+          xg = txp[off];
+          // (the load is consumed INSIDE the branch: left to the compiler, its s_waitcnt vmcnt(0) lands behind the join
+          // and every column - taken or not - then waits for the table stores issued just before the loop)
+          asm volatile("" : "+v"(xg));
+        }
         if (rf == 0x80u) {                                          // lag 7: from the next slot on beyond the codes
           txp[off] = xg;
           tk[off] = (seqn << 8) | age;

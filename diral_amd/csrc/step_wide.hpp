@@ -892,7 +892,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         for (int j = 0; j < VPL; ++j) {
           const unsigned int rf = pick(kp, j, w, cc);
           double xg = xt[rf];
-          if (rf == 0u) xg = txrow[ul + 64u * j];                       // never heard: the ghost xpos lives in the plane
+          if (rf == 0u) {                                               // never heard: the ghost xpos lives in the plane
+            xg = txrow[ul + 64u * j];
+            asm volatile("" : "+v"(xg));                                  // (consumed inside the branch: see step_fast64.hpp)
+          }
           // sequence number back from the code (lag = 8 - popcount)
           const unsigned int seqf = rf ? tk_own - 8u + (unsigned int)__popc(rf) : 0u;
           const unsigned int wn = (seqf << 8) | pick(agew, j, w, cc);
