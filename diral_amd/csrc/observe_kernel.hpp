@@ -135,10 +135,12 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
         v = (xg - mx > 0.0) ? d : -d;
       }
       if (u != k && (int)age < p.age_limit && d < p.Rb) {
-        int est = (int)((v + p.Rb) * inv_w);
-        est = est > K - 1 ? K - 1 : est;
-        const double e0 = s_edges[est], e1 = s_edges[est + 1];
-        const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+        bool unsafe;
+        int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);    // (step_kernel.hpp: the edges are read only near an edge)
+        if (unsafe) {
+          const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
+          bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+        }
         atomicAdd(&hrow[bin], 1u);
         mycnt += 1u;
       }

@@ -700,10 +700,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (ok) {
       // |v| < Rb, so the estimate is in [0, K] and the edge correction needs no bounds
       // tests: edges[0] = -Rb <= v and v < Rb = edges[K] hold by construction
-      int est = (int)((v + p.Rb) * inv_w);
-      est = est > K - 1 ? K - 1 : est;
-      const double e0 = s_edges[est], e1 = s_edges[est + 1];
-      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      bool unsafe;
+      int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);      // (step_kernel.hpp: the edges are read only near an edge)
+      if (unsafe) {
+        const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
+        bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      }
       atomicAdd(&hrow[bin], 1u);
       mycnt += 1u;
     }

@@ -86,6 +86,22 @@ __device__ inline double dist2d_leaf(double x1, double y1, double x2, double y2)
   return __builtin_sqrt(dx * dx + dy * dy);
 }
 
+// Bin of a value of the type-2 histogram, np.histogram(v, K, range=(-Rb, Rb)) (network.py:500): NumPy estimates the bin from
+// (v - first) / (last - first) * K and corrects it by at most one step against the float edges.  The correction can
+// only act when v lies within rounding distance of an edge.  With t = (v + Rb) * inv_w: t, the edges (linspace) and the
+// comparisons are each within 2^-45 bin widths of their exact values (K <= 64), so if the fractional part of t lies in
+// [2^-20, 1 - 2^-20] the value is safely inside bin floor(t) and the edges need not be read - one LDS round trip and two
+// f64 compares less per table entry.  `unsafe` lanes (an exact hit of an edge: integer-valued positions) take the reads.
+// Requires -Rb <= v < Rb (so 0 <= t <= K; t == K rounds in from below: fractional part 0, unsafe, clamped).
+__device__ inline int hist_bin_estimate(double v, double Rb, double inv_w, int K, bool& unsafe) {
+  const double t = (v + Rb) * inv_w;
+  int est = (int)t;
+  est = est > K - 1 ? K - 1 : est;
+  const double fr = __builtin_amdgcn_fract(t);
+  unsafe = !(__builtin_fabs(fr - 0.5) <= 0.5 - 0x1p-20);
+  return est;
+}
+
 // Python float `%` for the position wrap (network.py:203): fast exact path when
 // 0 <= s <= 2L (Sterbenz), generic fmod + sign fix-up otherwise.
 __device__ DIRAL_OUTLINE double py_mod_general(double s, double L) {

@@ -639,10 +639,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     }
     const bool ok = lv && (u != k) && ((int)(wn & 255u) < age_limit) && (d < pRb);
     if (ok) {
-      int est = (int)((v + pRb) * inv_w);
-      est = est > K - 1 ? K - 1 : est;
-      const double e0 = s_edges[est], e1 = s_edges[est + 1];
-      const int bin = est + (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      bool unsafe;
+      int bin = hist_bin_estimate(v, pRb, inv_w, K, unsafe);        // (step_kernel.hpp: the edges are read only near an edge)
+      if (unsafe) {
+        const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
+        bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
+      }
       atomicAdd(&s_hist[u * KP + (bin >> 1)], 1u << (16 * (bin & 1)));
       if constexpr (REGCNT) mycnt[j] += 1u;
     }
