@@ -123,13 +123,8 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
                      unsigned int& mycnt) {
       double d, v;
       if constexpr (FLAT) {
-        v = xg - mx;                                                  // all y == 0: x1 - x2 IS d * sign, d = |v|
-        const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-        d = __hiloint2double((int)vh, __double2loint(v));
-        if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
-          d = dist_general(mx - xg, 0.0);
-          v = (xg - mx > 0.0) ? d : -d;
-        }
+        v = xg - mx;                                                  // all y == 0: x1 - x2 IS d * sign, d = |v| (a square
+        d = __builtin_fabs(v);                                        // that underflows: the edge branch, see step_fast64.hpp)
       } else {
         d = fast_dist<false>(xg, heard ? s_py[k] : 0.0, mx, my);      // ypos: the subject's lane once heard
         v = (xg - mx > 0.0) ? d : -d;
@@ -138,6 +133,12 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
         bool unsafe;
         int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);    // (step_kernel.hpp: the edges are read only near an edge)
         if (unsafe) {
+          if constexpr (FLAT) {
+            if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {   // |v| below 2^-500 (its square underflows) or 0
+              d = dist_general(mx - xg, 0.0);
+              v = (v > 0.0) ? d : -d;
+            }
+          }
           const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
           bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
         }

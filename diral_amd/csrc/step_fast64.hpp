@@ -683,14 +683,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   auto tally = [&](int k, bool heard, unsigned int age, double xg) {
     double d, v;
     if constexpr (FLAT) {
-      // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v|
+      // all y == 0: v = x1 - x2 IS d * sign exactly (fl(a-b) == -fl(b-a)), d = |v| - unless the square underflows
+      // (0 < |v| < 2^-500), and even then the keep test agrees (both far below Rb) and so does the bin estimate
+      // (v + Rb absorbs either): only the comparison with a bin edge at exactly 0 tells -tiny from the reference's
+      // -0.  The exponent test therefore sits in the rare edge branch below, not in front of every entry.
       v = xg - mynpx;
-      const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-      d = __hiloint2double((int)vh, __double2loint(v));
-      if (vh < 0x20b00000u) {                                       // |v| below 2^-500 (its square underflows) or 0
-        d = dist_general(mynpx - xg, 0.0);
-        v = (xg - mynpx > 0.0) ? d : -d;
-      }
+      d = __builtin_fabs(v);
     } else {
       const double pyk = readlane_f64(mypy, k);
       d = fast_dist<false>(xg, heard ? pyk : 0.0, mynpx, mypy);
@@ -703,6 +701,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       bool unsafe;
       int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);      // (step_kernel.hpp: the edges are read only near an edge)
       if (unsafe) {
+        if constexpr (FLAT) {
+          if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {   // |v| below 2^-500 (its square underflows) or 0
+            d = dist_general(mynpx - xg, 0.0);
+            v = (v > 0.0) ? d : -d;
+          }
+        }
         const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
         bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
       }

@@ -629,19 +629,18 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       tkrow[(unsigned int)u] = wn;
       if (slot_upd) txrow[(unsigned int)u] = xg;
     }
-    // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v|
+    // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v| - unless the square underflows, which only the comparison
+    // with a bin edge at exactly 0 can notice: that case is handled in the rare edge branch (see step_fast64.hpp)
     double v = xg - s_npx[u];
-    const unsigned int vh = (unsigned int)__double2hiint(v) & 0x7fffffffu;
-    double d = __hiloint2double((int)vh, __double2loint(v));
-    if (vh < 0x20b00000u) {                                         // |v| below 2^-500 (its square underflows) or 0
-      d = dist_general(s_npx[u] - xg, 0.0);
-      v = (xg - s_npx[u] > 0.0) ? d : -d;
-    }
-    const bool ok = lv && (u != k) && ((int)(wn & 255u) < age_limit) && (d < pRb);
+    const bool ok = lv && (u != k) && ((int)(wn & 255u) < age_limit) && (__builtin_fabs(v) < pRb);
     if (ok) {
       bool unsafe;
       int bin = hist_bin_estimate(v, pRb, inv_w, K, unsafe);        // (step_kernel.hpp: the edges are read only near an edge)
       if (unsafe) {
+        if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {     // |v| below 2^-500 (its square underflows) or 0
+          const double d = dist_general(s_npx[u] - xg, 0.0);
+          v = (v > 0.0) ? d : -d;
+        }
         const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
         bin += (v >= e1 ? 1 : 0) - (v < e0 ? 1 : 0);
       }
