@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kObserveThreads) void observe_kernel(const ObserveP
         bool unsafe;
         int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);    // (step_kernel.hpp: the edges are read only near an edge)
         if (unsafe) {
+          bin = hist_bin_clamp(bin, K);
           if constexpr (FLAT) {
             if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {   // |v| below 2^-500 (its square underflows) or 0
               d = dist_general(mx - xg, 0.0);

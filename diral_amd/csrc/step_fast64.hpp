@@ -177,6 +177,18 @@ __device__ inline void stream_store2(double* p, double2 v) {
   __builtin_nontemporal_store(vv, reinterpret_cast<d2*>(p));
 }
 
+// A wave-uniform row pointer pinned into an SGPR pair, typed as a GLOBAL
+// (address_space(1)) pointer: loads/stores take the scalar-base + 32-bit lane offset
+// form.  Without the pin the compiler hoists per-lane 64-bit addresses out of the column
+// loops (16 VGPRs); without the address space a pointer rebuilt from integers is generic
+// and every access becomes a FLAT instruction (which also counts on lgkmcnt).
+template <typename T>
+using global_ptr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
+  return (global_ptr<T>)uniform_u64((unsigned long long)(base + elem_off));
+}
+
 __device__ inline double readlane_f64(double v, int srclane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -701,6 +713,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       bool unsafe;
       int bin = hist_bin_estimate(v, p.Rb, inv_w, K, unsafe);      // (step_kernel.hpp: the edges are read only near an edge)
       if (unsafe) {
+        bin = hist_bin_clamp(bin, K);
         if constexpr (FLAT) {
           if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {   // |v| below 2^-500 (its square underflows) or 0
             d = dist_general(mynpx - xg, 0.0);
@@ -744,23 +757,29 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * q + cc;
         const int k = wave * 16 + c;
-        const int off = c * NV + lane;
         const unsigned int sh = 8u * (unsigned int)cc;
         const unsigned int rf = (cnq >> sh) & 255u, age = (agq >> sh) & 255u;
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        // sequence number back from the code: lag = 8 - popcount
-        const unsigned int seqn = tk_own - 8u + (unsigned int)__popc(rf);
+        // sequence number back from the code: lag = 8 - popcount (the subject's own number - 8 rides in the add
+        // operand of v_bcnt)
+        const unsigned int tk8 = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c) - 8u;
+        unsigned int seqn;
+        asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(seqn) : "v"(rf), "s"(tk8));   // popcount(rf) + tk8
         double xg = ring_x(rv, c, seqn);
-        if (rf == 0u) {                                             // never heard: the ghost xpos lives in the plane
-          xg = txp[off];
-          // (the load is consumed INSIDE the branch: left to the compiler, its s_waitcnt vmcnt(0) lands behind the join
-          // and every column - taken or not - then waits for the table stores issued just before the loop)
-          asm volatile("" : "+v"(xg));
-        }
-        if (rf == 0x80u) {                                          // lag 7: from the next slot on beyond the codes
-          txp[off] = xg;
-          tk[off] = (seqn << 8) | age;
-          hand = true;
+        if ((rf & 0x7fu) == 0u) {                                   // 0: never heard; 0x80: lag 7 - both rare, one test
+          // (the plane row through a scalar base + lane offset, formed here: per-lane 64-bit pointers stepping from
+          // column to column cost the common path two VALU instructions per column)
+          const global_ptr<double> txrow = uniform_ptr(p.tx, ((size_t)b * p.NR + k) * NV);
+          if (rf == 0u) {                                           // never heard: the ghost xpos lives in the plane
+            xg = txrow[(unsigned int)lane];
+            // (the load is consumed INSIDE the branch: left to the compiler, its s_waitcnt vmcnt(0) lands behind the join
+            // and every column - taken or not - then waits for the table stores issued just before the loop)
+            asm volatile("" : "+v"(xg));
+          } else {                                                  // lag 7: from the next slot on beyond the codes
+            const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, ((size_t)b * p.NR + k) * NV);
+            txrow[(unsigned int)lane] = xg;
+            tkrow[(unsigned int)lane] = (seqn << 8) | age;
+            hand = true;
+          }
         }
 #ifdef DIRAL_DEBUG_XG
         if (p.dbg) p.dbg[((size_t)b * 64 + k) * 64 + lane] = (unsigned long long)__double_as_longlong(xg);

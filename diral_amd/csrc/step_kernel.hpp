@@ -92,15 +92,16 @@ __device__ inline double dist2d_leaf(double x1, double y1, double x2, double y2)
 // comparisons are each within 2^-45 bin widths of their exact values (K <= 64), so if the fractional part of t lies in
 // [2^-20, 1 - 2^-20] the value is safely inside bin floor(t) and the edges need not be read - one LDS round trip and two
 // f64 compares less per table entry.  `unsafe` lanes (an exact hit of an edge: integer-valued positions) take the reads.
-// Requires -Rb <= v < Rb (so 0 <= t <= K; t == K rounds in from below: fractional part 0, unsafe, clamped).
+// Requires -Rb <= v < Rb (so 0 <= t <= K; t == K rounds in from below: fractional part 0, unsafe - the edge branch
+// clamps the estimate to K - 1 first).
 __device__ inline int hist_bin_estimate(double v, double Rb, double inv_w, int K, bool& unsafe) {
   const double t = (v + Rb) * inv_w;
-  int est = (int)t;
-  est = est > K - 1 ? K - 1 : est;
+  const int est = (int)t;                        // (t == K: fractional part 0 - the caller's edge branch clamps, hist_bin_clamp)
   const double fr = __builtin_amdgcn_fract(t);
   unsafe = !(__builtin_fabs(fr - 0.5) <= 0.5 - 0x1p-20);
   return est;
 }
+__device__ inline int hist_bin_clamp(int est, int K) { return est > K - 1 ? K - 1 : est; }
 
 // Python float `%` for the position wrap (network.py:203): fast exact path when
 // 0 <= s <= 2L (Sterbenz), generic fmod + sign fix-up otherwise.

@@ -254,18 +254,7 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
   return (c == 2 && wgt == 1) ? 0.0 : -1.0;
 }
 
-// A wave-uniform row pointer pinned into an SGPR pair, typed as a GLOBAL
-// (address_space(1)) pointer: loads/stores take the scalar-base + 32-bit lane offset
-// form.  Without the pin the compiler hoists per-lane 64-bit addresses out of the column
-// loops (16 VGPRs); without the address space a pointer rebuilt from integers is generic
-// and every access becomes a FLAT instruction (which also counts on lgkmcnt).
-template <typename T>
-using global_ptr = __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
-  return (global_ptr<T>)uniform_u64((unsigned long long)(base + elem_off));
-}
-
+// (uniform_ptr / global_ptr: step_fast64.hpp)
 #ifdef DIRAL_TIMING
 #define DIRAL_WSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DIRAL_WCLOCK(v) v = __builtin_amdgcn_s_memtime()
@@ -623,8 +612,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     const bool lv = FULL || ((u < N) && kvalid);
     const bool slot_upd = XMODE == 0 ? (__ballot(upd || u == k) != 0ull) : (XMODE == 2 || upd);
     if constexpr (XMODE == 3) {
-      // coded entry (packed table): nothing goes to the planes, except at the hand-over (`upd`: the entry is now 7 behind)
-      if (lv && upd) { tkrow[(unsigned int)u] = wn; txrow[(unsigned int)u] = xg; }
+      // coded entry (packed table): nothing goes to the planes (the hand-over at lag 7 is the caller's; `wn` is the age)
     } else if (lv) {
       tkrow[(unsigned int)u] = wn;
       if (slot_upd) txrow[(unsigned int)u] = xg;
@@ -637,6 +625,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       bool unsafe;
       int bin = hist_bin_estimate(v, pRb, inv_w, K, unsafe);        // (step_kernel.hpp: the edges are read only near an edge)
       if (unsafe) {
+        bin = hist_bin_clamp(bin, K);
         if (((unsigned int)__double2hiint(v) & 0x7fffffffu) < 0x20b00000u) {     // |v| below 2^-500 (its square underflows) or 0
           const double d = dist_general(s_npx[u] - xg, 0.0);
           v = (v > 0.0) ? d : -d;
@@ -893,16 +882,19 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         for (int j = 0; j < VPL; ++j) {
           const unsigned int rf = pick(kp, j, w, cc);
           double xg = xt[rf];
-          if (rf == 0u) {                                               // never heard: the ghost xpos lives in the plane
-            xg = txrow[ul + 64u * j];
-            asm volatile("" : "+v"(xg));                                  // (consumed inside the branch: see step_fast64.hpp)
+          const unsigned int age = pick(agew, j, w, cc);
+          if ((rf & 0x7fu) == 0u) {                                     // 0: never heard; 0x80: lag 7 - both rare, one test
+            if (rf == 0u) {                                             // never heard: the ghost xpos lives in the plane
+              xg = txrow[ul + 64u * j];
+              asm volatile("" : "+v"(xg));                                // (consumed inside the branch: see step_fast64.hpp)
+            } else if (FULL || (lane + 64 * j < N && kvalid)) {
+              // from the next slot on beyond the codes: hand over - sequence number (lag 7) and xpos go to the planes
+              tkrow[ul + 64u * j] = ((tk_own - 7u) << 8) | age;
+              txrow[ul + 64u * j] = xg;
+              handw[w] = true;
+            }
           }
-          // sequence number back from the code (lag = 8 - popcount)
-          const unsigned int seqf = rf ? tk_own - 8u + (unsigned int)__popc(rf) : 0u;
-          const unsigned int wn = (seqf << 8) | pick(agew, j, w, cc);
-          const bool at7 = rf == 0x80u;                                 // from the next slot on beyond the codes: hand over
-          emit(k, kvalid, j, at7, wn, xg, tkrow, txrow, std::integral_constant<int, 3>{});
-          handw[w] = handw[w] || (at7 && (FULL || (lane + 64 * j < N && kvalid)));
+          emit(k, kvalid, j, false, age, xg, tkrow, txrow, std::integral_constant<int, 3>{});
         }
         wave_lds_order();
       }
