@@ -296,6 +296,10 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         torch.cuda.synchronize(device)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    # (a torch event creates its HIP event at the first record - 20 us that belong to no step: both exist before the clock starts)
+    ev0.record()
+    ev1.record()
+    torch.cuda.synchronize(device)
     t_start = time.perf_counter()
     ev0.record()
     for _ in range(steps):
@@ -395,6 +399,58 @@ def rollout_sps_graph(device, envs=4096, K=50, replays=8):
            "collision_fraction": float(m[3] / (m[2] + m[3]))}
     ro.close()
     return out
+
+
+def c2_graph(device, envs=4096, K=20, replays=50):
+    """The headline step (c2: state + reward + channel observation, iid-uniform actions from a ring of K action tensors)
+    with K slots captured into ONE hipGraph (slot number on the device: diral_env_set_clock) and replayed: what is left of
+    the gap between `ms_per_step` and the kernel time when no launch goes through Python.  Outputs of a replay equal K
+    eager steps (tests/test_gpu_parity.py::test_graph_rollout_equals_eager covers the clocked step)."""
+    import ctypes
+    from diral_amd import c2_config
+    from diral_amd.config import STEP_MY_STEP
+    from diral_amd.rollout import SlotClock
+    cfg = c2_config()
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
+    env.reset_topology(seed=GLOBAL_SEED)
+    clock = SlotClock(device)
+    env._ok(env.lib.diral_env_set_clock(env._h, ctypes.c_void_p(clock.ptr())), "diral_env_set_clock")
+    acts = [env.sample(seed=100 + i) for i in range(K)]
+
+    def k_slots():
+        for k in range(K):
+            env._step(STEP_MY_STEP, acts[k], k, want_chobs=True)
+        st = env.lib.diral_clock_add(ctypes.c_void_p(clock.ptr()), K, env._stream())
+        assert st == 0, st
+
+    for _ in range(4):
+        k_slots()                               # past the ghost-entry phase; lazy conversions done before the capture
+    torch.cuda.synchronize(device)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            k_slots()
+    torch.cuda.current_stream(device).wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(replays):
+        graph.replay()
+    ev1.record()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    env._ok(env.lib.diral_env_set_clock(env._h, None), "diral_env_set_clock")
+    slots = K * replays
+    return {"what": "the bench step (c2, %d envs), %d slots per hipGraph (device slot clock, ring of %d action tensors), %d replays"
+                    % (envs, K, K, replays),
+            "ms_per_step": dt / slots * 1e3, "ms_per_step_events": ev0.elapsed_time(ev1) / slots,
+            "agent_steps_per_s": envs * env.N * slots / dt}
 
 
 def secondary_modes(device, envs=4096, slots=200, warm=100):
@@ -612,6 +668,7 @@ def main() -> int:
                 also["rollout_sps"] = rollout_sps(device)
                 torch.cuda.empty_cache()
                 also["rollout_sps_graph"] = rollout_sps_graph(device)
+                also["c2_graph"] = c2_graph(device)
                 torch.cuda.empty_cache()
                 also["c2_streams2"] = streamed_c2(device, 2)
                 also["c2_streams4"] = streamed_c2(device, 4)
