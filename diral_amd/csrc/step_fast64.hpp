@@ -418,16 +418,16 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       while (m) {
         const int w = __builtin_ctzll(m);
         m &= m - 1;
-        double d;
-        if constexpr (ABS) {
-          const double dx = mypx - readlane_f64(mypx, w);
-          d = __hiloint2double(__double2hiint(dx) & 0x7fffffff, __double2loint(dx));
+        double d, keep;                                     // `best` holds `keep`: the distance, or (ABS) the SIGNED difference -
+        if constexpr (ABS) {                                // its magnitude is taken by the compares' source modifiers and once
+          keep = mypx - readlane_f64(mypx, w);              // behind the loop instead of with an extra instruction per transmitter
+          d = __builtin_fabs(keep);
         } else {
-          d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
+          d = keep = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
         }
         const bool inr = d < p.Rc;
-        const bool bt = inr && (d < best);
-        best = bt ? d : best;
+        const bool bt = inr && (d < __builtin_fabs(best));
+        best = bt ? keep : best;
         bid = bt ? w : bid;
         if ((CH || (EXTRA && p.prr)) && c > 1) {                // in_range[tx] (test_env.py:395-397)
           const int n_in = __popcll(__ballot(live && (myact != i) && inr));
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     };
     if (FLAT && p1_fast) search(std::true_type{});
     else search(std::false_type{});
+    best = __builtin_fabs(best);
     const bool got = live && (myact != i) && (bid >= 0);
     s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
     if constexpr (RICH) {

@@ -423,22 +423,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       for (int jt = 0; jt < VPL; ++jt) {
         unsigned long long m = mk[jt];
         while (m) {
-          const int w = jt * 64 + __builtin_ctzll(m);
+          const int wl = __builtin_ctzll(m);
+          const int w = jt * 64 + wl;
           m &= m - 1;
-          const double xw = s_px[w];
+          const double xw = readlane_f64(mypx[jt], wl);        // (from the registers: an LDS read here is a round trip per transmitter)
           int n_in = 0;
 #pragma unroll
           for (int j = 0; j < VPL; ++j) {
-            double d;
-            if constexpr (ABS) {
-              const double dx = mypx[j] - xw;
-              d = __hiloint2double(__double2hiint(dx) & 0x7fffffff, __double2loint(dx));
+            double d, keep;                                   // (`best` holds the SIGNED difference on the fast path: its magnitude
+            if constexpr (ABS) {                              // comes from the compares' source modifiers, see step_fast64.hpp)
+              keep = mypx[j] - xw;
+              d = __builtin_fabs(keep);
             } else {
-              d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
+              d = keep = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
             }
             const bool inr = d < pRc;
-            const bool bt = inr && (d < best[j]);
-            best[j] = bt ? d : best[j];
+            const bool bt = inr && (d < __builtin_fabs(best[j]));
+            best[j] = bt ? keep : best[j];
             bid[j] = bt ? w : bid[j];
             if (EXTRA && p.la && (FULL || lane + 64 * j < N) && (myact[j] != i) && !inr)
               p.la[(bN + w) * N + lane + 64 * j] = -1;          // find_closest_tx side effect (network.py:394)
