@@ -15,6 +15,7 @@ cp gpurun_out/rollout_r03.txt profiles/r03/rollout_example.txt
 cp gpurun_out/side_paths_r03.txt profiles/r03/side_paths.txt
 cp gpurun_out/secondary_modes_r03.txt profiles/r03/secondary_modes.txt
 cp gpurun_out/two_streams_r03.txt profiles/r03/two_streams.txt
+for f in batch_sweep end_effects lag_distribution any_order; do cp gpurun_out/${f}_r03.txt profiles/r03/$f.txt; done
 find gpurun_out/prof_secondary -name "*kernel_stats.csv" -exec cp {} profiles/r03/secondary_modes_kernel_stats.csv \;
 find gpurun_out/prof_side -name "*kernel_stats.csv" -exec cp {} profiles/r03/side_paths_kernel_stats.csv \;
 bash profiles/resource_usage.sh profiles/r03/resource_usage.txt

@@ -27,6 +27,10 @@ python examples/rollout_sps.py --envs 4096 --slots 1000 --policy random 2>&1 | g
 python profiles/side_paths.py 2>&1 | grep -v amdgpu > gpurun_out/side_paths_r03.txt
 WORKLOADS=c2,c5,c3 python profiles/secondary_modes.py 2>&1 | grep -v amdgpu > gpurun_out/secondary_modes_r03.txt
 python profiles/two_streams.py 2>&1 | grep -v amdgpu > gpurun_out/two_streams_r03.txt
+bash profiles/batch_sweep.sh 64 256 1024 1792 2048 3584 4096 8192 32768 2>&1 | grep -v amdgpu > gpurun_out/batch_sweep_r03.txt
+python profiles/end_effects.py 2>&1 | grep -v amdgpu > gpurun_out/end_effects_r03.txt
+python profiles/lag_distribution.py 2>&1 | grep -v amdgpu > gpurun_out/lag_distribution_r03.txt
+(hipcc --offload-arch=gfx950 -O3 profiles/micro/any_order.hip -o /tmp/any_order 2>/dev/null && timeout 60 /tmp/any_order) > gpurun_out/any_order_r03.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_secondary -o t -- env WORKLOADS=c2,c5,c3 python $GRAFT_REPO_ROOT/profiles/secondary_modes.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_side -o t -- python $GRAFT_REPO_ROOT/profiles/side_paths.py > /dev/null 2>&1
