@@ -20,7 +20,9 @@ for w in c3 c5; do
   python bench.py --workload $w --lean --steps 100 --warmup 10 --emit-chobs 0 2>/dev/null | tail -1 > gpurun_out/bench_r03_${w}_nochobs.json
 done
 NCCL_DEBUG=INFO python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
-  bench.py --gpus 1 --steps 200 --warmup 20 --lean > gpurun_out/bench_r03_torchrun1.json 2> gpurun_out/bench_r03_torchrun1.log
+  bench.py --gpus 1 --steps 200 --warmup 20 --lean > gpurun_out/bench_r03_torchrun1.stdout 2> gpurun_out/bench_r03_torchrun1.log
+tail -1 gpurun_out/bench_r03_torchrun1.stdout > gpurun_out/bench_r03_torchrun1.json        # (NCCL_DEBUG=INFO prints to stdout)
+grep -v '^{' gpurun_out/bench_r03_torchrun1.stdout >> gpurun_out/bench_r03_torchrun1.log
 python bench.py --gpus 2 > gpurun_out/bench_r03_gpus2.txt 2>&1; echo "rc=$?" >> gpurun_out/bench_r03_gpus2.txt
 python examples/rollout_sps.py --envs 4096 --slots 1000 2>&1 | grep -v amdgpu | tail -2 > gpurun_out/rollout_r03.txt
 python examples/rollout_sps.py --envs 4096 --slots 1000 --policy random 2>&1 | grep -v amdgpu | tail -2 >> gpurun_out/rollout_r03.txt
