@@ -189,6 +189,28 @@ __device__ inline global_ptr<T> uniform_ptr(T* base, size_t elem_off) {
   return (global_ptr<T>)uniform_u64((unsigned long long)(base + elem_off));
 }
 
+// Sum of a double over the 64 lanes of a wave with DPP moves (row_shr 8 / 4 / 2 / 1, then row_bcast 15 and 31): VALU only -
+// `__shfl_down` compiles to ds_bpermute, an LDS round trip per level, and this sits on the critical path of the wave that
+// does P2.  The total lands in lane 63 and is returned wave-uniform.  (The order differs from the shuffle tree: callers whose
+// sums are compared bit for bit across kernels keep the tree.)
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum_f64(double v) {
+  v = dpp_add_f64<0x118, 0xf>(v);      // row_shr:8 (lanes without a source add 0)
+  v = dpp_add_f64<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_add_f64<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_add_f64<0x111, 0xf>(v);      // row_shr:1: lane 15 of every row holds the row's sum
+  v = dpp_add_f64<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_add_f64<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ inline double readlane_f64(double v, int srclane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -538,14 +560,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
       if constexpr (RICH) s_rew[lane] = rw;
     }
-    double vr = rw, vp = prr;
-    int vs = sole, vc = coll;
+    // metric partials: the two counts are ballots, the reward sum a DPP reduction (no LDS round trips on this wave's
+    // critical path); the PRR sum keeps the shuffle tree of the general kernel (compared bit for bit with it)
+    const double vr = wave_sum_f64(rw);
+    const int vs = __popcll(__ballot(sole != 0)), vc = __popcll(__ballot(coll != 0));
+    double vp = prr;
+    if (CH || EXTRA) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      vr += __shfl_down(vr, off);
-      if (CH || EXTRA) vp += __shfl_down(vp, off);
-      vs += __shfl_down(vs, off);
-      vc += __shfl_down(vc, off);
+      for (int off = 32; off > 0; off >>= 1) vp += __shfl_down(vp, off);
     }
     if (lane == 0) {
       double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;

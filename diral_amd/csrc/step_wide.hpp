@@ -554,14 +554,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       else static_cast<float*>(rew_out2)[bN + u] = (float)rw;
     }
     if (u < N) lp2->pos_x[bN + u] = s_npx[u];
-    double vr = rw, vp = prr;
-    int vs = sole, vc = coll;
+    // (counts by ballot, the reward sum by DPP moves, the PRR sum on the shuffle tree of the general kernel: step_fast64.hpp)
+    const double vr = wave_sum_f64(rw);
+    const int vs = __popcll(__ballot(sole != 0)), vc = __popcll(__ballot(coll != 0));
+    double vp = prr;
+    if (CH || EXTRA) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      vr += __shfl_down(vr, off);
-      if (CH || EXTRA) vp += __shfl_down(vp, off);
-      vs += __shfl_down(vs, off);
-      vc += __shfl_down(vc, off);
+      for (int off = 32; off > 0; off >>= 1) vp += __shfl_down(vp, off);
     }
     if (lane == 0) {
       s_red[wave * 4 + 0] = vr; s_red[wave * 4 + 1] = vp; s_red[wave * 4 + 2] = (double)vs; s_red[wave * 4 + 3] = (double)vc;
