@@ -571,11 +571,13 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
     if (lane == 0) {
       double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;
-      mt[DIRAL_M_SLOTS] += 1.0;
-      mt[DIRAL_M_SUM_REWARD] += vr;
-      mt[DIRAL_M_TX_SOLE] += (double)vs;
-      mt[DIRAL_M_TX_COLLIDED] += (double)vc;
-      if (CH || (EXTRA && p.prr)) { mt[DIRAL_M_PRR_SUM] += vp; mt[DIRAL_M_PRR_CNT] += (double)vs + (double)vc; }
+      // (hardware f64 atomic adds without a return value: `mt[i] += x` is a global load the wave waits for - a microsecond on
+      // the critical path of the workgroup; one workgroup per env and launch adds here, so the sum is the same)
+      unsafeAtomicAdd(&mt[DIRAL_M_SLOTS], 1.0);
+      unsafeAtomicAdd(&mt[DIRAL_M_SUM_REWARD], vr);
+      unsafeAtomicAdd(&mt[DIRAL_M_TX_SOLE], (double)vs);
+      unsafeAtomicAdd(&mt[DIRAL_M_TX_COLLIDED], (double)vc);
+      if (CH || (EXTRA && p.prr)) { unsafeAtomicAdd(&mt[DIRAL_M_PRR_SUM], vp); unsafeAtomicAdd(&mt[DIRAL_M_PRR_CNT], (double)vs + (double)vc); }
       uint8_t* const done_out = lp->done_out;
       if (done_out) {
         int dn = lp->done_now;                                    // folded on the host ...

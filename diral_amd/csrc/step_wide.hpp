@@ -1059,11 +1059,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
     for (int w = 0; w < VPL; ++w) { sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
     double* mt = lp->metrics + (size_t)b * DIRAL_M_COLUMNS;
-    mt[DIRAL_M_SLOTS] += 1.0;
-    mt[DIRAL_M_SUM_REWARD] += sr;
-    mt[DIRAL_M_TX_SOLE] += ss;
-    mt[DIRAL_M_TX_COLLIDED] += sc;
-    if (CH || (EXTRA && lp->prr)) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
+    unsafeAtomicAdd(&mt[DIRAL_M_SLOTS], 1.0);          // (no-return hardware atomics: no load to wait for, see step_fast64.hpp)
+    unsafeAtomicAdd(&mt[DIRAL_M_SUM_REWARD], sr);
+    unsafeAtomicAdd(&mt[DIRAL_M_TX_SOLE], ss);
+    unsafeAtomicAdd(&mt[DIRAL_M_TX_COLLIDED], sc);
+    if (CH || (EXTRA && lp->prr)) { unsafeAtomicAdd(&mt[DIRAL_M_PRR_SUM], sp); unsafeAtomicAdd(&mt[DIRAL_M_PRR_CNT], ss + sc); }
   }
   if constexpr (RICH) {
     const RichParams rr = load_rich_args(late);
