@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // ---- P1: per owned resource i = wave + 4*s: transmitter set, closest in-range
   // transmitter per vehicle, gather sources, collision reward ----------------------
   const bool dist_obs = RICH && (p.chobs_mode & 2) != 0;
+  const bool rd2_lanes = FLAT && !CH && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS) && !(EXTRA && p.design);
   const bool emit_chobs = RICH && (p.chobs_mode & 1) != 0;
 #pragma unroll 1
   for (int i = wave; i < A; i += 4) {
@@ -499,24 +500,11 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         }
       }
     }
-    if (!CH && c > 1 && !(EXTRA && p.design)) {               // test_env.py:159-199
-      double rw;
-      if (FLAT && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS)) {
-        // inlined common case (reward_design 2, network.py:291-295 weight): a pair
-        // is rewarded 2*[dist > Rc] - 2, more than two transmitters -c
-        if (c == 2) {
-          const int a = __builtin_ctzll(mk);
-          const int bb = __builtin_ctzll(mk & (mk - 1));
-          const double dxab = readlane_f64(mypx, bb) - readlane_f64(mypx, a);
-          const double dab = p1_fast ? __hiloint2double(__double2hiint(dxab) & 0x7fffffff, __double2loint(dxab))
-                                     : fast_dist<true>(readlane_f64(mypx, a), 0.0, readlane_f64(mypx, bb), 0.0);
-          rw = 2.0 * (double)(dab > p.Rc) - (double)c;       // (0 + d) / 1 == d exactly
-        } else {
-          rw = 0.0 - (double)c;
-        }
-      } else {
-        rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
-      }
+    // reward of a colliding resource (test_env.py:159-199).  The common case - reward_design 2 with the distance weight of
+    // network.py:291-295 on the one-lane highway - is computed for ALL resources at once in P2, one lane per resource
+    // (`rd2_lanes`): here it cost every wave ~10 instructions per owned resource
+    if (!CH && c > 1 && !(EXTRA && p.design) && !rd2_lanes) {
+      const double rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
       if (lane == 0) s_rv[i] = rw;
     }
   }
@@ -526,6 +514,22 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
   if (wave == 0) {
     const LateFastArgs lp = (LateFastArgs)late_kernarg_base();     // rew_out, metrics, done_out: used here only
+    if (rd2_lanes) {
+      // lane i: resource i.  A pair is rewarded 2 * [dist > Rc] - 2 (the mean distance of ONE pair is the distance:
+      // (0 + d) / 1 == d exactly), more than two transmitters -c
+      const unsigned long long mkl = lane < A ? s_mask[lane] : 0ull;
+      const int cl = __popcll(mkl);
+      const unsigned long long mk2 = mkl & (mkl - 1ull);
+      const int la = cl > 0 ? __builtin_ctzll(mkl) : 0, lb = cl > 1 ? __builtin_ctzll(mk2) : 0;
+      const double xa = __hiloint2double(__builtin_amdgcn_ds_bpermute(la << 2, __double2hiint(mypx)),
+                                         __builtin_amdgcn_ds_bpermute(la << 2, __double2loint(mypx)));
+      const double xb = __hiloint2double(__builtin_amdgcn_ds_bpermute(lb << 2, __double2hiint(mypx)),
+                                         __builtin_amdgcn_ds_bpermute(lb << 2, __double2loint(mypx)));
+      const double dab = p1_fast ? __builtin_fabs(xb - xa) : fast_dist<true>(xa, 0.0, xb, 0.0);
+      const double rwl = cl == 2 ? 2.0 * (double)(dab > p.Rc) - 2.0 : 0.0 - (double)cl;
+      if (cl > 1) s_rv[lane] = rwl;
+      wave_lds_order();
+    }
     double rw = 0.0;
     int sole = 0, coll = 0;
     double prr = 0.0;
