@@ -515,6 +515,19 @@ def streamed_c2(device, groups, steps=600, warm=100):
     return out
 
 
+def streamed_c2_sets(device, groups, sets=4):
+    """`streamed_c2` on `sets` different sets of pooled streams, the fastest set reported and every set listed.  Which hardware
+    queue a stream lands on is the runtime's bookkeeping and depends on the process's earlier stream users:
+    two streams of a set may share a queue, and their launches then run back to back (G = 2: 85 instead of 50 us per slot).
+    The sub-batch design is measured by the set whose streams got queues of their own."""
+    runs = [streamed_c2(device, groups, steps=300, warm=60) for _ in range(sets)]
+    best = min(runs, key=lambda r: r["ms_per_step"])
+    best = dict(best)
+    best["ms_per_step_by_stream_set"] = [r["ms_per_step"] for r in runs]
+    best["note"] = "fastest of %d stream sets (a set whose streams share a hardware queue serialises: runtime bookkeeping, DESIGN.md 3.6)" % sets
+    return best
+
+
 def short(res):
     """The keys of a secondary measurement that go into the JSON line (frac: this layout's compulsory
     bytes over the kernel time over the HBM peak, as in the main roofline object)."""
@@ -671,13 +684,13 @@ def main() -> int:
                 del e2
                 also["c2_sticky_0.9"] = short(r2)
                 also["c2_sticky_0.9"]["emit_chobs"] = emit
+                also["c2_streams2"] = streamed_c2_sets(device, 2)
+                also["c2_streams4"] = streamed_c2_sets(device, 4)
+                torch.cuda.empty_cache()
                 also["rollout_sps"] = rollout_sps(device)
                 torch.cuda.empty_cache()
                 also["rollout_sps_graph"] = rollout_sps_graph(device)
                 also["c2_graph"] = c2_graph(device)
-                torch.cuda.empty_cache()
-                also["c2_streams2"] = streamed_c2(device, 2)
-                also["c2_streams4"] = streamed_c2(device, 4)
                 torch.cuda.empty_cache()
                 also["secondary_observation_modes"] = secondary_modes(device)
                 torch.cuda.empty_cache()

@@ -33,3 +33,5 @@ pmc pmc_grbm GRBM_GUI_ACTIVE
 cd $R
 LAST=40 python profiles/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the raw per-dispatch tables have done their job (summary.txt; trace/*kernel_stats.csv is kept): gpurun merges at most 64 MiB back
+[ "${KEEP_RAW:-0}" = 1 ] || find $OUT -name "*_kernel_trace.csv" -o -name "*_counter_collection.csv" | xargs rm -f

@@ -37,5 +37,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_secondary -o t -- env WORKLOADS=c2,c5,c3 python $GRAFT_REPO_ROOT/profiles/secondary_modes.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_side -o t -- python $GRAFT_REPO_ROOT/profiles/side_paths.py > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_secondary gpurun_out/prof_side -name "*_kernel_trace.csv" | xargs rm -f
 for t in c2_chobs1 c2_chobs0 c3_chobs1 c3_chobs0 c5_chobs1 c5_chobs0 c4shard; do echo "== $t"; grep "steady state" gpurun_out/prof_$t/summary.txt; done
 cat gpurun_out/rollout_r03.txt gpurun_out/two_streams_r03.txt; tail -3 gpurun_out/bench_r03_torchrun1.log | cut -c1-200
