@@ -21,9 +21,13 @@ MODES = {
     "type-1 piggy histogram": dict(add_positional_dist_type=1),
     "sorted distances + type-2 histogram": dict(add_positional_dist=True),
 }
+ONLY = os.environ.get("MODE_FILTER", "")              # substring of the mode names to run (profiling passes)
+SLOTS = int(os.environ.get("SLOTS", 300))
 for wl in os.environ.get("WORKLOADS", "c2").split(","):
     N, A, L = SHAPES[wl]
     for name, st in MODES.items():
+        if ONLY and ONLY not in name:
+            continue
         cfg = bench_config(N, A, L, State=st) if st else bench_config(N, A, L)
         env = VecV2VEnv(cfg, batch={"c2": B, "c5": B // 2, "c3": B // 4}[wl], out_dtype=torch.float32)
         env.reset_topology(seed=1)
@@ -33,10 +37,10 @@ for wl in os.environ.get("WORKLOADS", "c2").split(","):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for t in range(200, 500):
+        for t in range(200, 200 + SLOTS):
             env.step(acts[t % 32], t)
         e1.record()
         torch.cuda.synchronize()
-        print("%s %-46s S=%4d  %.1f us / slot  kernel code %d" % (wl, name, cfg.state_space, e0.elapsed_time(e1) / 300 * 1e3,
+        print("%s %-46s S=%4d  %.1f us / slot  kernel code %d" % (wl, name, cfg.state_space, e0.elapsed_time(e1) / SLOTS * 1e3,
                                                                    env.last_kernel()))
         del env

@@ -12,6 +12,7 @@ from collections import defaultdict
 
 d = sys.argv[1]
 LAST = int(os.environ.get("LAST", "40"))
+KF = os.environ.get("KERNEL_FILTER", "step_")        # substring of the kernel names summarised (default: the step kernels)
 
 
 def find(pattern):
@@ -34,7 +35,7 @@ for f in find("*kernel_trace.csv"):
     durs = defaultdict(list)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "step_" in row.get("Kernel_Name", ""):
+            if KF in row.get("Kernel_Name", ""):
                 durs[row["Kernel_Name"]].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
     for k, v in durs.items():
         v.sort()
@@ -47,7 +48,7 @@ for f in find("*counter_collection.csv"):
     acc = defaultdict(list)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "step_" not in row.get("Kernel_Name", ""):
+            if KF not in row.get("Kernel_Name", ""):
                 continue
             acc[(row["Kernel_Name"][:48], row["Counter_Name"])].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
     for (kn, cn), v in sorted(acc.items()):
@@ -65,7 +66,7 @@ for f in find("*kernel_trace.csv"):
     durs = []
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "step_" in row.get("Kernel_Name", ""):
+            if KF in row.get("Kernel_Name", ""):
                 durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
     if durs:
         durs.sort()
