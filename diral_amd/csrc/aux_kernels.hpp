@@ -446,22 +446,40 @@ __global__ void sps_step_wave_kernel(int agents, int A, const T* src, const int3
   }
   unsigned long long todo = __ballot(resel);
   const int i0 = i - lane;
+  // the re-selecting agents of the wave, four at a time: their rows are loaded together (one HBM round trip per batch
+  // instead of one per agent - the kernel is a chain of such round trips), then decided one by one
+  constexpr int NB = 4;
   while (todo) {
-    const int j = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const T* row = src + (size_t)(i0 + j) * A;
-    const int prev_j = __builtin_amdgcn_readlane(action, j);
-    const int own_j = __builtin_amdgcn_readlane(own, j);
-    const unsigned int r_j = (unsigned int)__builtin_amdgcn_readlane((int)r, j);
-    double w[NC];
+    int js[NB];
+    T raw[NB][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int s = lane + 64 * c;
-      w[c] = 0.0;
-      if (s < A) w[c] = CHOBS ? sps_rssi_from_chobs((double)row[s], s == own_j) : (double)row[s];
+    for (int q = 0; q < NB; ++q) {
+      js[q] = todo ? __builtin_ctzll(todo) : -1;               // (wave-uniform)
+      todo &= todo - 1;                                        // (0 stays 0)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int s = lane + 64 * c;
+        raw[q][c] = (T)0;
+        if (js[q] >= 0 && s < A) raw[q][c] = src[(size_t)(i0 + js[q]) * A + s];
+      }
     }
-    const int ch = sps_choose_wave<NC>(w, lane, A, prev_j, threshold, inc_db, r_j);
-    if (lane == j) action = ch;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int j = js[q];
+      if (j < 0) break;
+      const int prev_j = __builtin_amdgcn_readlane(action, j);
+      const int own_j = __builtin_amdgcn_readlane(own, j);
+      const unsigned int r_j = (unsigned int)__builtin_amdgcn_readlane((int)r, j);
+      double w[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int s = lane + 64 * c;
+        w[c] = 0.0;
+        if (s < A) w[c] = CHOBS ? sps_rssi_from_chobs((double)raw[q][c], s == own_j) : (double)raw[q][c];
+      }
+      const int ch = sps_choose_wave<NC>(w, lane, A, prev_j, threshold, inc_db, r_j);
+      if (lane == j) action = ch;
+    }
   }
   if (resel) prev_action[i] = action;                                 // v2x_sps.py:98
   if (live) {
