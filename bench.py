@@ -324,8 +324,9 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     bytes_launch = algorithmic_bytes_per_env_slot(N, A, cfg.state_space) * B
-    layout_launch = layout_bytes_per_env_slot(N, A, cfg.state_space, emit_chobs) * B
     code = env.last_kernel()
+    from diral_amd.config import KERNEL_PACKED
+    layout_launch = layout_bytes_per_env_slot(N, A, cfg.state_space, emit_chobs, packed=bool(code & KERNEL_PACKED)) * B
     res = {
         "workload": name, "N": N, "A": A, "B": B, "L": L, "state_space": cfg.state_space, "cfg": cfg,
         "wall": wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": kernel_ms,
@@ -414,7 +415,7 @@ def c2_graph(device, envs=4096, K=20, replays=50):
     env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
     env.reset_topology(seed=GLOBAL_SEED)
     clock = SlotClock(device)
-    env._ok(env.lib.diral_env_set_clock(env._h, ctypes.c_void_p(clock.ptr())), "diral_env_set_clock")
+    env.set_clock(clock.t)                      # (the env keeps the tensor alive: VecV2VEnv.set_clock)
     acts = [env.sample(seed=100 + i) for i in range(K)]
 
     def k_slots():
@@ -445,7 +446,7 @@ def c2_graph(device, envs=4096, K=20, replays=50):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     env.check()
-    env._ok(env.lib.diral_env_set_clock(env._h, None), "diral_env_set_clock")
+    env.set_clock(None)
     slots = K * replays
     return {"what": "the bench step (c2, %d envs), %d slots per hipGraph (device slot clock, ring of %d action tensors), %d replays"
                     % (envs, K, K, replays),

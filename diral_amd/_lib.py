@@ -93,6 +93,11 @@ def load() -> ctypes.CDLL:
         except AttributeError as exc:
             raise DiralLibraryError("libdiral_env.so lacks symbol %s" % name) from exc
         fn.restype, fn.argtypes = sig[name]
+    from .config import ABI_VERSION
+    got = int(lib.diral_env_abi_version())
+    if got != ABI_VERSION:
+        raise DiralLibraryError("%s speaks ABI %d, this package binds ABI %d (include/diral_env.h): rebuild it with "
+                                "`python -m diral_amd.build`" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -47,6 +47,10 @@ struct DiralEnv {
   uint32_t* tage = nullptr;
   uint32_t* tseq = nullptr;
   uint32_t* told = nullptr;
+  // slow envs first (step_fast64.hpp FastParams::slow_*): three rotating sets of [count (16 words) | list | flag per env]
+  uint32_t* slow = nullptr;
+  uint64_t slow_launches = 0;   // launches that rotated the sets
+  bool slow_first = true;       // DIRAL_NO_SLOW_FIRST=1 at create: blocks = envs in order (A/B timing, tests)
   int32_t* la = nullptr;
   int32_t* pf = nullptr;
   double* metrics = nullptr;
@@ -299,6 +303,13 @@ hipError_t verify_ring(DiralEnv* e, hipStream_t s) {
   return hipGetLastError();
 }
 
+size_t slow_set_words(const DiralEnv* e) { return 16 + (size_t)kFastSlowMax + (size_t)e->B; }
+hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
+  if (!e->slow) return hipSuccess;
+  e->slow_launches = 0;
+  return hipMemsetAsync(e->slow, 0, 3 * slow_set_words(e) * 4, s);
+}
+
 hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
   const int vpl = e->vpl;
   const bool flat_y = e->flat_y;
@@ -340,6 +351,22 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
     f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
+    f.B = p.B;
+    f.slow_cnt_r = nullptr; f.slow_list_r = nullptr; f.slow_flag_r = nullptr;
+    f.slow_cnt_w = nullptr; f.slow_list_w = nullptr; f.slow_flag_w = nullptr; f.slow_cnt_z = nullptr;
+    bool slow_first = false;
+    if (use_fast64 && e->slow && e->slow_first && !stream_is_capturing(s)) {
+      // (a captured launch keeps dispatch order and leaves the sets alone: a replayed graph would not rotate them)
+      const size_t w = slow_set_words(e);
+      uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
+      uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
+      uint32_t* const set_z = e->slow + ((e->slow_launches + 2) % 3) * w;
+      f.slow_cnt_r = set_r; f.slow_list_r = set_r + 16; f.slow_flag_r = set_r + 16 + kFastSlowMax;
+      f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + kFastSlowMax;
+      f.slow_cnt_z = set_z;
+      ++e->slow_launches;
+      slow_first = true;
+    }
     RichParams r = rich_for(e, p);
     r.chobs_out = p.chobs_out;
     r.pf = ((p.flags & DIRAL_F_PROPORTIONAL_FAIR) && p.mode == DIRAL_STEP_MY_STEP) ? p.pf : nullptr;
@@ -353,7 +380,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
                      ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
-    return launch_fast64(f, r, k, p.B, s);
+    return launch_fast64(f, r, k, p.B + (slow_first ? kFastSlowMax : 0), s);
   }
   // the generic FAST instantiation of the general kernel: the plain configuration on sizes the
   // specialised kernels do not take (A > 64, vehicles off the y = 0 lane at N > 64): my_step,
@@ -537,8 +564,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   // unmasked as well
   CREATE_TRY(alloc((void**)&e->tkey, (tab + 512 + 64 * 256) * 4));
   CREATE_TRY(alloc((void**)&e->tx, (tab + 512 + 64 * 256) * 8));
-  // the xpos ring of the specialised kernels (DIRAL_NO_RING: test hook, N <= 64 only - that kernel also runs
-  // from the plane alone, the N > 64 kernels are built for the ring)
+  // the xpos ring of the specialised kernels
   if ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA)) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
@@ -553,6 +579,12 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
       CREATE_TRY(hipMemset(e->tage, 0, (nq * e->NV + 512) * 4));
       CREATE_TRY(hipMemset(e->tseq, 0, ((size_t)e->B * e->NR + 64) * 4));
       CREATE_TRY(hipMemset(e->told, 0, (nq + 16) * 4));
+    }
+    if (e->vpl == 1) {
+      CREATE_TRY(alloc((void**)&e->slow, 3 * slow_set_words(e) * 4));
+      CREATE_TRY(hipMemset(e->slow, 0, 3 * slow_set_words(e) * 4));
+      const char* off = std::getenv("DIRAL_NO_SLOW_FIRST");
+      e->slow_first = !(off && off[0] == '1');
     }
     e->ring_valid = true;                                       // all tables zero: never heard, age 0, xpos 0
   }
@@ -596,6 +628,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(set_attr_general(e->vpl, l.total));
   if (e->vpl == 2 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide2(e->A, e->K));
   if (e->vpl == 4 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide4(e->A, e->K));
+  CREATE_TRY(set_attr_observe(e->N, e->K));
 #undef CREATE_TRY
 
   StepParams& p = e->base;
@@ -633,7 +666,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
 int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
+  void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->slow, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
                   e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
@@ -679,6 +712,7 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
     HIP_TRY(e, hipMemsetAsync(e->tseq, 0, (size_t)e->B * e->NR * 4, s));
     HIP_TRY(e, hipMemsetAsync(e->told, 0, nq * 4, s));
   }
+  HIP_TRY(e, clear_slow_sets(e, s));
   e->plane_valid = true; e->ring_valid = e->ring != nullptr;
   HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
   if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));

@@ -31,6 +31,7 @@ hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSe
 hipError_t set_attr_wide2(int A, int K);
 hipError_t set_attr_wide4(int A, int K);
 hipError_t launch_observe(const ObserveParams& p, const RichParams& r, bool flat, bool out64, int B, hipStream_t s);
+hipError_t set_attr_observe(int N, int K);
 hipError_t launch_general(int vpl, bool fast, const StepParams& p, uint32_t lds, hipStream_t s);
 hipError_t set_attr_general(int vpl, uint32_t lds);
 

@@ -93,7 +93,23 @@ struct FastParams {
   void* rew_out;
   uint8_t* done_out;
   unsigned long long* dbg;
+  int B;                          // envs of the handle (the grid may be larger: slow-first blocks below)
+  // Slow envs first (step_fast64 only).  An env whose tables hold entries beyond the codes runs its
+  // quads on the keyed path and takes two to three times as long as the others; a launch ends when its last workgroup
+  // does, so such a workgroup must not be among the last to START.  Every launch leaves, for the next one, the list of
+  // the envs it found slow (`told` flags set for the next slot) and a flag per env; the next launch runs the listed envs
+  // in its first kFastSlowMax blocks - dispatched first - and the block that would have taken such an env in dispatch
+  // order exits at once.  Three rotating sets (the host counts launches): read set r, build set r + 1, clear the count of
+  // set r + 2.  Null: blocks = envs in order (captured launches: a replayed graph does not rotate).
+  const uint32_t* slow_cnt_r;     // [1] number of listed envs
+  const uint32_t* slow_list_r;    // [kFastSlowMax]
+  const uint32_t* slow_flag_r;    // [B] != 0: listed
+  uint32_t* slow_cnt_w;
+  uint32_t* slow_list_w;
+  uint32_t* slow_flag_w;
+  uint32_t* slow_cnt_z;           // the count the launch after the next will build on: zeroed here
 };
+constexpr int kFastSlowMax = 256;  // listed envs per launch (an env beyond that keeps its place in dispatch order)
 
 // Late-bound kernel arguments.  The compiler hoists the scalar loads of EVERY by-value kernel
 // argument to the kernel entry and then keeps (or spills, through v_writelane / v_readlane - VALU
@@ -124,7 +140,7 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
 }
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, mtab, rtx, inr, px, py, npx, rew, stage, total;
+  uint32_t rv, edges, mask, act, hist, cnt, slow, mtab, rtx, inr, px, py, npx, rew, stage, total;
 };
 // row stride (elements) of the channel-observation staging array [vehicle][resource] of the RICH
 // instantiations: a multiple of 4 elements, so that the write-out reads a 16-byte piece of a row
@@ -132,6 +148,13 @@ struct FastLds {
 // over the banks (the column writes of P1, lane = vehicle, then conflict 4-way: 8 cheap writes
 // per wave)
 __host__ __device__ constexpr int fast_stage_stride(int A) { return (A <= 32 ? 32 : 64) + 4; }
+// histogram row stride (words): odd (lane = row: conflict-free increments) and at least K + 1 - slot K of a row is a
+// spare that takes the increments of entries that do not count (the column loop needs no exec-mask branch then)
+__host__ __device__ constexpr int fast_hist_stride(int K) { return (K + 1) | 1; }
+// gather-source table [vehicle][resource], one BYTE per entry (source lane * 4, the ds_bpermute address, <= 252): the
+// merge reads the sources of FOUR consecutive resources with one ds_read_b32; the row stride of a32 + 4 bytes = 9 / 17
+// words puts the 64 lanes' words - and the byte writes of P1, lane = row - on distinct banks
+__host__ __device__ constexpr int fast_mtab_stride(int A) { return (A <= 32 ? 32 : 64) + 4; }
 __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64, bool flat) {
   FastLds l;
   uint32_t o = 0;
@@ -140,11 +163,10 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
   l.edges = o; o += 8u * (K + 2);
   l.mask = o;  o += 8u * a32;
   l.act = o;   o += 4u * 64;
-  l.hist = o;  o += 4u * (K | 1) * 64;
+  l.hist = o;  o += 4u * fast_hist_stride(K) * 64;
   l.cnt = o;   o += 4u * 64;
-  // [resource][vehicle] gather source lane * 4 (bpermute address): words, or bytes (<= 252) in the
-  // RICH instantiations, which need the room for the staging array
-  l.mtab = o;  o += (rich ? 1u : 4u) * 64 * a32;
+  l.slow = o;  o += 16u;                     // the workgroup holds a quad flagged for the keyed path of the next slot
+  l.mtab = o;  o += 64u * fast_mtab_stride(A);      // [vehicle][resource] gather source lane * 4 (bpermute address), bytes
   l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
   l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
   l.px = l.py = l.npx = l.rew = l.stage = o;
@@ -209,6 +231,25 @@ __device__ inline double wave_sum_f64(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
+}
+
+// Count of trailing zeros of byte BYTE of a word (-1 for a zero byte): one SDWA instruction.  The lag of a thermometer
+// code (0xff << lag) & 0xff.
+template <int BYTE>
+__device__ inline int ffbl_byte(unsigned int w) {
+  int r;
+  static_assert(BYTE >= 0 && BYTE < 4, "byte select");
+  if constexpr (BYTE == 0) asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+  if constexpr (BYTE == 1) asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+  if constexpr (BYTE == 2) asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+  if constexpr (BYTE == 3) asm("v_ffbl_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+  return r;
+}
+// double -> int32, truncating, SATURATING, NaN -> 0 (the hardware conversion; a C cast is undefined out of range)
+__device__ inline int cvt_i32_f64_sat(double x) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 __device__ inline double readlane_f64(double v, int srclane) {
@@ -301,7 +342,8 @@ __device__ DIRAL_OUTLINE double fast_ch_reward(int rd, bool collided, double R) 
 }
 
 #ifdef DIRAL_TIMING
-#define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) { p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 7) { __builtin_amdgcn_s_waitcnt(0); atomicMax(&p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2) + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } } while (0)
 #else
 #define DIRAL_FSTAMP(i) do {} while (0)
 #endif
@@ -323,7 +365,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   int* s_act = reinterpret_cast<int*>(smem + lay.act);
   unsigned int* s_hist = reinterpret_cast<unsigned int*>(smem + lay.hist);
   unsigned int* s_cnt = reinterpret_cast<unsigned int*>(smem + lay.cnt);
-  typedef typename std::conditional<RICH, unsigned char, int>::type mtab_t;
+  typedef unsigned char mtab_t;
   typedef typename std::conditional<OUT64, double, float>::type out_t;
   mtab_t* s_mtab = reinterpret_cast<mtab_t*>(smem + lay.mtab);
   out_t* s_stage = reinterpret_cast<out_t*>(smem + lay.stage);   // RICH only
@@ -333,25 +375,40 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   double* s_py = reinterpret_cast<double*>(smem + lay.py);
   double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
   double* s_rew = reinterpret_cast<double*>(smem + lay.rew);
-  constexpr int MT = 64;                                         // gather-source table row stride (elements)
+  const int MS = fast_mtab_stride(p.A);                          // gather-source table row stride (bytes), [vehicle][resource]
   const int SA = fast_stage_stride(p.A);
 
-  const int b = blockIdx.x;
+  // which env: blocks = envs in order, or (slow envs first) the listed envs in the first kFastSlowMax blocks
+  int b = blockIdx.x;
+  unsigned int listed = 0u;                  // (ordinary block) != 0: this env runs in one of the first blocks
+  unsigned int* const s_slow = reinterpret_cast<unsigned int*>(smem + lay.slow);
+  if (p.slow_cnt_r) {
+    if (blockIdx.x < (unsigned int)kFastSlowMax) {
+      if (blockIdx.x >= *p.slow_cnt_r) return;
+      b = (int)p.slow_list_r[blockIdx.x];
+    } else {
+      b = (int)blockIdx.x - kFastSlowMax;
+      listed = p.slow_flag_r[b];             // a scalar load in flight next to the loads of P0; tested before any store
+    }
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, A = p.A, K = p.K;
-  const int KP = K | 1;
+  const int KP = fast_hist_stride(K);
   const size_t bN = (size_t)b * N;
   const bool live = lane < N;
   constexpr int NV = 64;                       // padded viewer stride (host guarantees p.NV == 64)
   DIRAL_FSTAMP(0);
 #ifdef DIRAL_TIMING
+  // chip-wide clock (s_memrealtime, 100 MHz) at the start and the end of every workgroup, the launches alternating between
+  // two sets: start skew, drain, and the gap between two launches of one stream (profiles/launch_timeline.py)
+  if (tid == 0 && p.dbg) p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2)] = __builtin_amdgcn_s_memrealtime();
   if (lane == 0 && p.dbg) {     // where this wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, behind the stamps
     unsigned int hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    p.dbg[(size_t)gridDim.x * 32 + (size_t)b * 4 + wave] = ((unsigned long long)xcc << 32) | hw;
+    p.dbg[(size_t)p.B * 32 + (size_t)b * 4 + wave] = ((unsigned long long)xcc << 32) | hw;
   }
 #endif
 
@@ -392,6 +449,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   unsigned int* const tsq = p.tseq + (size_t)b * p.NR + (has_cols ? wave * 16 : 0);
   const unsigned int ts_own = tsq[lane & 15];
   __builtin_amdgcn_sched_barrier(0);
+  if (listed) return;                        // (uniform; nothing has been stored yet)
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
   // P1 measures |x_w - x_u| for every (transmitter, vehicle) pair; |dx| IS the reference's sqrt(fl(dx^2)) iff dx == 0
   // or |dx| >= 2^-500 (fast_dist).  If every position of the env is 0 or at least 2^-447 in magnitude, every NONZERO
@@ -412,6 +470,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   }
   if (EXTRA && p.nomove) mynpx = mypx;                                         // network.py:302-305: no mobility, no move
   if (wave == 0) {
+    if (lane == 0) s_slow[0] = 0u;
     s_act[lane] = myact; s_cnt[lane] = 0u;
     if constexpr (RICH) {
       s_px[lane] = mypx; s_npx[lane] = mynpx; s_rew[lane] = 0.0;
@@ -427,20 +486,28 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   const bool dist_obs = RICH && (p.chobs_mode & 2) != 0;
   const bool rd2_lanes = FLAT && !CH && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS) && !(EXTRA && p.design);
   const bool emit_chobs = RICH && (p.chobs_mode & 1) != 0;
+  // (the transmitter masks of the owned resources are collected in lanes 0, 1, ... of `mkv` - a compare and two selects per
+  // resource - and stored to s_mask with one instruction after the loop: a one-lane store per resource is an exec-mask
+  // round trip each)
+  unsigned int mkv_lo = 0u, mkv_hi = 0u;
+  int slot = 0;
+  const bool need_rw = !CH && !(EXTRA && p.design) && !rd2_lanes;      // collision reward per resource, here (uniform)
 #pragma unroll 1
-  for (int i = wave; i < A; i += 4) {
+  for (int i = wave; i < A; i += 4, ++slot) {
     const unsigned long long mk = __ballot(myact == i);     // tx set (test_env.py:153-157)
     const int c = __popcll(mk);
-    if (lane == 0) s_mask[i] = mk;
-    // Network.find_closest_tx (network.py:378-398): ascending id, strict '<'
+    mkv_lo = lane == slot ? (unsigned int)mk : mkv_lo;
+    mkv_hi = lane == slot ? (unsigned int)(mk >> 32) : mkv_hi;
+    // Network.find_closest_tx (network.py:378-398): ascending id, strict '<'.  `bid` starts as the own lane: a
+    // transmitter of resource i is never its own receiver, so "bid == lane" IS "no transmitter in range"
     double best = 100000.0;
-    int bid = -1;
+    int bid = lane;
     auto search = [&](auto fast_tag) {
       constexpr bool ABS = decltype(fast_tag)::value;     // |dx| without the per-pair exponent test (p1_fast)
       unsigned long long m = mk;
       while (m) {
         const int w = __builtin_ctzll(m);
-        m &= m - 1;
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(w));      // m &= ~(1 << w): one scalar instruction (m & (m - 1): three)
         double d, keep;                                     // `best` holds `keep`: the distance, or (ABS) the SIGNED difference -
         if constexpr (ABS) {                                // its magnitude is taken by the compares' source modifiers and once
           keep = mypx - readlane_f64(mypx, w);              // behind the loop instead of with an extra instruction per transmitter
@@ -470,8 +537,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (FLAT && p1_fast) search(std::true_type{});
     else search(std::false_type{});
     best = __builtin_fabs(best);
-    const bool got = live && (myact != i) && (bid >= 0);
-    s_mtab[i * MT + lane] = (got ? bid : lane) << 2;
+    const bool self = !live || myact == i;                  // padded lanes and the transmitters of i gather from themselves
+    const int src_lane = self ? lane : bid;
+    const bool got = src_lane != lane;
+    s_mtab[lane * MS + i] = (mtab_t)(src_lane << 2);
     if constexpr (RICH) {
       if (emit_chobs) {
         // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432): 0 on the own
@@ -503,11 +572,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // reward of a colliding resource (test_env.py:159-199).  The common case - reward_design 2 with the distance weight of
     // network.py:291-295 on the one-lane highway - is computed for ALL resources at once in P2, one lane per resource
     // (`rd2_lanes`): here it cost every wave ~10 instructions per owned resource
-    if (!CH && c > 1 && !(EXTRA && p.design) && !rd2_lanes) {
-      const double rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
-      if (lane == 0) s_rv[i] = rw;
+    if (need_rw) {
+      if (c > 1) {
+        const double rw = fast_collision_reward(p.reward_design, p.flags, p.L, p.Rc, N, mk, c, mypx, mypy);
+        if (lane == 0) s_rv[i] = rw;
+      }
     }
   }
+  if (lane < slot) s_mask[wave + 4 * lane] = ((unsigned long long)mkv_hi << 32) | mkv_lo;
   DIRAL_FSTAMP(2);
   __syncthreads();
 
@@ -666,9 +738,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // sequence-number overflow (24 bits: the keyed path packs (seq << 8) | lane)
   if (tkov >= (1u << 24) - 1u) atomicOr(lpr->err, kErrSeq);
   unsigned int cold[4];                                         // the codes after the stamp, before the merge
+  const unsigned int own_byte = own_here ? (0xffu << (8 * (own_col & 3))) : 0u;   // this lane's own entry in its quad's words
   {
     // Vehicle.periodic_update (vehicle.py:56-70)
-    const unsigned int own_byte = own_here ? (0xffu << (8 * (own_col & 3))) : 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned int om = (own_col >> 2) == q ? own_byte : 0u;
@@ -698,26 +770,59 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (h0) ringp[lane] = px0;
       if (h1) ringp[64 + lane] = px1;
     }
+    // ... and re-arranged by LAG for the lookups of P3b: lane l takes the stamp (l & 7) numbers behind the fresh
+    // one of its subject, ring[k][(t_k - (l & 7)) & 7].  An entry's xpos is then the value of lane 8 (c & 7) + lag -
+    // the lag straight from the code (count of trailing zeros), no sequence number, no per-column v_readlane
+    const int r0 = (int)(((unsigned int)lane & 56u) | ((tk0 - (unsigned int)lane) & 7u)) << 2;
+    const int r1 = (int)(((unsigned int)lane & 56u) | ((tk1 - (unsigned int)lane) & 7u)) << 2;
+    ringv0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(r0, __double2hiint(ringv0)),
+                              __builtin_amdgcn_ds_bpermute(r0, __double2loint(ringv0)));
+    ringv1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(r1, __double2hiint(ringv1)),
+                              __builtin_amdgcn_ds_bpermute(r1, __double2loint(ringv1)));
   }
+  // Vehicle.received_update for the resources in ascending order: `step(m4)` merges this lane's
+  // words with those of lane m4 / 4.  The gather sources of FOUR consecutive resources arrive with one ds_read_b32
+  // of this vehicle's table row (the next word a group ahead); a resource nobody transmits on has the identity row -
+  // its step is skipped (uniform test of the active-resource mask)
+  auto merge_walk = [&](auto&& step) {
+    const unsigned int* const mrow = reinterpret_cast<const unsigned int*>(s_mtab + lane * MS);   // MS % 4 == 0
+    const int ng = A >> 2;
+    unsigned int mw = mrow[0];
+    unsigned long long act = actw;
+#pragma unroll 1
+    for (int g = 0; g < ng; ++g) {
+      const unsigned int w = mw;
+      mw = mrow[g + 1];                                          // (word ng: the tail resources, or the row's padding)
+      const unsigned int a4 = (unsigned int)act & 15u;
+      act >>= 4;
+      if (a4 & 1u) step((int)(w & 255u));
+      if (a4 & 2u) step((int)((w >> 8) & 255u));
+      if (a4 & 4u) step((int)((w >> 16) & 255u));
+      if (a4 & 8u) step((int)(w >> 24));
+    }
+    for (int i = 0; i < (A & 3); ++i) {
+      if ((unsigned int)act & (1u << i)) step((int)((mw >> (8 * i)) & 255u));
+    }
+  };
   if (badq != 15u) {
     // the coded merge (the words of a bad quad are merged along - meaningless, never read; none at all when every
     // quad of the wave is keyed: a sparse topology)
-    unsigned long long rem = actw;
-    int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-    while (rem) {
-      rem &= rem - 1;
-      const int m4 = m_next;
-      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+    merge_walk([&](int m4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) cw[q] |= (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)cw[q]);
-    }
+    });
   }
   DIRAL_FSTAMP(4);
 
   // ---- P3b: the entry's xpos, the table words, the histogram -----------------------
   unsigned int mycnt = 0u;
+#ifdef DIRAL_TIMING
+  unsigned int dbg_path = badq;          // which path the wave's quads took: bits 0-3 keyed, bits 4-7 the general column loop
+#endif
   const double inv_w = p.inv_w;
+  // inv_w * 2^20 (exact: the exponent field + 20) and K * 2^20: the fixed-point bin of the fast quads
+  const double inv_w20 = __hiloint2double(__double2hiint(inv_w) + (20 << 20), __double2loint(inv_w));
+  const unsigned int k20 = (unsigned int)K << 20;
   unsigned int* const hrow = s_hist + lane * KP;
   // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) of one entry:
   // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
@@ -756,9 +861,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       mycnt += 1u;
     }
   };
-  // xpos of (column c, sequence number seq) from the ring rows
-  auto ring_x = [&](double rv, int c, unsigned int seq) -> double {
-    const int src = (int)((((unsigned int)c & 7u) << 3) | (seq & 7u)) << 2;
+  // xpos of column c's entry that lags its subject by `lag` (0..7) stamps, from the lag-ordered ring rows
+  auto ring_x = [&](double rv, int c, unsigned int lag) -> double {
+    const int src = (int)((((unsigned int)c & 7u) << 3) | (lag & 7u)) << 2;
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(rv)),
                             __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
   };
@@ -781,6 +886,68 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       tc[q * NV + lane] = cnq;
       ta[q * NV + lane] = agq;
       const double rv = q >= 2 ? ringv1 : ringv0;
+      if constexpr (FLAT) {
+        // -- the FAST quad: no viewer holds a never-heard entry (code 0) or one at lag 7 (0x80: hand-over) about these
+        //    four subjects - every quad of a dense topology in steady state.  Straight-line, four columns, no
+        //    exec-mask branch:
+        //    * the lag is the count of trailing zeros of the code byte, the xpos the lag-ordered ring value;
+        //    * whether the entry counts - vehicle exists, not the own entry, age < limit - is ONE byte compare against
+        //      the age word with the own byte (and every byte of a padded lane) forced to 255 (age_limit <= 255);
+        //    * the bin in fixed point: ti = trunc((v + Rb) * inv_w * 2^20); 0 <= ti <= K * 2^20 is the range test
+        //      |v| < Rb, ti >> 20 the bin, and when the 20 fraction bits are neither all 0 nor all 1 the value is at least
+        //      2^-20 bin widths inside that bin (`hist_bin_estimate`: the estimate is within 2^-45 of exact) - else
+        //      (an edge hit, |v| at Rb) the lane takes the exact statement below, behind a uniform branch;
+        //    * an entry that does not count increments the spare slot K of the row.
+        const unsigned int y7 = cnq & 0x7f7f7f7fu;
+        const bool rare = live && ((y7 + 0x7f7f7f7fu) & 0x80808080u) != 0x80808080u;   // a byte with (code & 0x7f) == 0
+#ifdef DIRAL_TIMING
+        if (__ballot(rare) != 0ull) dbg_path |= 16u << q;
+#endif
+        if (__ballot(rare) == 0ull) {
+          const unsigned int agt = live ? (agq | ((own_col >> 2) == q ? own_byte : 0u)) : 0xffffffffu;
+          auto column = [&](auto cc_tag) {
+            constexpr int cc = decltype(cc_tag)::value;
+            const int c = 4 * q + cc;
+            const int src = (ffbl_byte<cc>(cnq) << 2) + ((c & 7) << 5);
+            const double xg = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(rv)),
+                                               __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
+            const double v = xg - mynpx;
+            const int ti = cvt_i32_f64_sat((v + p.Rb) * inv_w20);
+            const bool agev = ((agt >> (8 * cc)) & 255u) < (unsigned int)p.age_limit;
+            const bool in = (unsigned int)ti <= k20;
+            const bool edge = ((unsigned int)(ti + 1) & 0xfffffu) <= 1u;
+            const bool m = agev && in;
+            const bool need = m && edge;
+            bool cnt = m && !need;
+            int bin = ti >> 20;
+            if (need) {                                            // (rare: an exact edge hit, |v| at Rb)
+              double vv = v;
+              cnt = __builtin_fabs(vv) < p.Rb;
+              bin = 0;
+              if (cnt) {
+                bool unsafe;
+                bin = hist_bin_clamp(hist_bin_estimate(vv, p.Rb, inv_w, K, unsafe), K);
+                if (((unsigned int)__double2hiint(vv) & 0x7fffffffu) < 0x20b00000u) {   // |v| below 2^-500 (its square underflows) or 0
+                  const double d = dist_general(mynpx - xg, 0.0);
+                  vv = (vv > 0.0) ? d : -d;
+                }
+                const double e0 = s_edges[bin], e1 = s_edges[bin + 1];
+                bin += (vv >= e1 ? 1 : 0) - (vv < e0 ? 1 : 0);
+              }
+            }
+#ifdef DIRAL_DEBUG_XG
+            if (p.dbg) p.dbg[((size_t)b * 64 + wave * 16 + c) * 64 + lane] = (unsigned long long)__double_as_longlong(xg);
+#endif
+            atomicAdd(&hrow[cnt ? bin : K], 1u);
+            mycnt += cnt ? 1u : 0u;
+          };
+          column(std::integral_constant<int, 0>{});
+          column(std::integral_constant<int, 1>{});
+          column(std::integral_constant<int, 2>{});
+          column(std::integral_constant<int, 3>{});
+          continue;
+        }
+      }
       bool hand = false;
 #pragma unroll 1
       for (int cc = 0; cc < 4; ++cc) {
@@ -793,7 +960,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         const unsigned int tk8 = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c) - 8u;
         unsigned int seqn;
         asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(seqn) : "v"(rf), "s"(tk8));   // popcount(rf) + tk8
-        double xg = ring_x(rv, c, seqn);
+        double xg = ring_x(rv, c, tk8 - seqn);                      // lag = t_k - seq (tk8 = t_k mod 8)
         if ((rf & 0x7fu) == 0u) {                                   // 0: never heard; 0x80: lag 7 - both rare, one test
           // (the plane row through a scalar base + lane offset, formed here: per-lane 64-bit pointers stepping from
           // column to column cost the common path two VALU instructions per column)
@@ -843,16 +1010,10 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
             const unsigned int seq = r ? tk_own - 8u + (unsigned int)__popc(r) : (wr >> 8);
             k0[i] = kq[i] = (seq << 8) | (unsigned int)lane;
           }
-          unsigned long long rem = actw;
-          int m_next = rem ? (int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0;
-#pragma unroll 1
-          while (rem) {
-            rem &= rem - 1;
-            const int m4 = m_next;
-            if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT + lane];
+          merge_walk([&](int m4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
-          }
+          });
           unsigned int ncode = 0u, nage = 0u;
           bool keep = false;
 #pragma unroll
@@ -866,7 +1027,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
             const bool upd = seqf != seq0;
             // a coded entry's xpos is in the ring, not (necessarily) in the plane.  (The lookup is unconditional: under a
             // branch the ds_bpermute would run with the code-0 lanes switched off - and read 0 from them.)
-            const double xr = ring_x(rv, c, seq0);
+            const double xr = ring_x(rv, c, tk_own - seq0);
             const double x_cur = r ? xr : xp4[i];
             const double xs = (lane == k) ? mypx : x_cur;             // own stamp (vehicle.py:63)
             const int src4 = (int)(kq[i] & 255u) << 2;
@@ -899,11 +1060,29 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (newf != badq || handed) {
       if (lane < 4) lpr->told[qbase + lane] = (newf >> lane) & 1u;
     }
+    if (newf && lane == 0) s_slow[0] = 1u;                        // (zeroed in P0, two barriers ago)
   }
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
+#ifdef DIRAL_TIMING
+  if (lane == 0 && p.dbg) p.dbg[(size_t)p.B * 48 + (size_t)b * 4 + wave] = dbg_path;
+#endif
   DIRAL_FSTAMP(5);
   __syncthreads();
   DIRAL_FSTAMP(6);
+  if (tid == 0) {
+    // the next launch's order: a slow env asks for a place among the first blocks
+    const LateFastArgs ls = (LateFastArgs)late_kernarg_base();
+    uint32_t* const flag_w = ls->slow_flag_w;
+    if (flag_w) {
+      unsigned int fl = 0u;
+      if (s_slow[0]) {
+        const unsigned int pos = atomicAdd(ls->slow_cnt_w, 1u);
+        if (pos < (unsigned int)kFastSlowMax) { ls->slow_list_w[pos] = (unsigned int)b; fl = 1u; }
+      }
+      flag_w[b] = fl;
+      if (b == 0) *ls->slow_cnt_z = 0u;
+    }
+  }
 
   // ---- P4: state = [one-hot(action) (A) | histogram (K)] ---------------------------
   // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
@@ -918,7 +1097,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     auto chv = [&](int u, int i) -> double {
       if (s_act[u] == i || s_mask[i] == 0ull) return 0.0;
       if (!dist_obs) return 1.0;
-      const int src = s_mtab[i * MT + u] >> 2;
+      const int src = s_mtab[u * MS + i] >> 2;
       if (src == u) return 100000.0;
       return fast_dist<FLAT>(s_px[src], FLAT ? 0.0 : s_py[src], s_px[u], FLAT ? 0.0 : s_py[u]);
     };

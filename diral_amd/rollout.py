@@ -75,21 +75,29 @@ class GraphRollout:
         self.shaped = [torch.empty((B, N), dtype=dt, device=dev) for _ in range(2)]
         self.sum_r = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
         self.coll = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
-        env._ok(env.lib.diral_env_set_clock(env._h, ctypes.c_void_p(self.clock.ptr())), "diral_env_set_clock")
         self.graph = None
         self._slots_run = 0
-        if capture:
-            # a first eager pass: output buffers exist, the ring <-> plane state is settled (a conversion launch must
-            # not be captured: DIRAL_ERR_CAPTURE), lazy initialisations are done
-            self._run_slots(eager=True)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            self._stream = torch.cuda.Stream(device=dev)
-            self._stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._stream):
-                with torch.cuda.graph(self.graph, stream=self._stream):
-                    self._run_slots(eager=False)
-            torch.cuda.current_stream(dev).wait_stream(self._stream)
+        self._closed = False
+        env.set_clock(self.clock.t)            # the env holds the tensor from here on (VecV2VEnv.set_clock)
+        try:
+            if capture:
+                # a first eager pass: output buffers exist, the ring <-> plane state is settled (a conversion launch
+                # must not be captured: DIRAL_ERR_CAPTURE), lazy initialisations are done
+                self._run_slots(eager=True)
+                torch.cuda.synchronize(dev)
+                self.graph = torch.cuda.CUDAGraph()
+                self._stream = torch.cuda.Stream(device=dev)
+                self._stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(self._stream):
+                    with torch.cuda.graph(self.graph, stream=self._stream):
+                        self._run_slots(eager=False)
+                torch.cuda.current_stream(dev).wait_stream(self._stream)
+        except BaseException:
+            # (DIRAL_ERR_CAPTURE, an unsupported reward design for my_step_ch, ...): the env must not keep
+            # reading a clock that belongs to a rollout that never came to be
+            self.graph = None
+            self.close()
+            raise
 
     def _one_slot(self, k: int) -> None:
         env, pol = self.env, self.pol
@@ -128,4 +136,22 @@ class GraphRollout:
         return self.env._obs, self.shaped[i], self.actions[i]
 
     def close(self) -> None:
-        self.env._ok(self.env.lib.diral_env_set_clock(self.env._h, None), "diral_env_set_clock")
+        """Remove the slot clock from the env (idempotent).  Also runs on `with`-exit and when the object is dropped."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        env = self.env
+        if getattr(env, "_h", None) and env._clock is self.clock.t:
+            env.set_clock(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -28,17 +28,21 @@ def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
 
 
 def packed_table(n: int) -> bool:
-    """Which kernels store the table as packed codes + ages (2 B per entry): step_fast64 (N <= 64) and
-    step_wide at N > 128; N in (64, 128] keeps the 4-byte (seq, age) word (csrc/step_wide.hpp)."""
+    """The DEFAULT table form by size: packed codes + ages (2 B per entry) for step_fast64 (N <= 64) and step_wide at
+    N > 128 on dense topologies; N in (64, 128] keeps the 4-byte (seq, age) word (csrc/step_wide.hpp).  The runtime
+    chooses per handle (density, DIRAL_TABLE_FORM: csrc/diral_env.hip use_packed_table): callers that have a handle
+    pass `packed = bool(env.last_kernel() & KERNEL_PACKED)` to layout_bytes_per_env_slot instead of relying on this."""
     return n <= 64 or n > 128
 
 
-def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4) -> int:
+def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4, packed=None) -> int:
     """What csrc/step_fast64.hpp / step_wide.hpp HAVE to move per env-slot in steady state - the compulsory
     bytes of this build's table layout: every table entry's stored form read and written once (packed: one
     code byte + one age byte; else the 4-byte (seq, age) word), the subjects' ring rows read and one stamp each
     written, the subjects' own sequence numbers (packed form), the per-vehicle arrays, reward and state, and
     the channel observation only when it is requested."""
-    entry = 2 if packed_table(n) else 4
-    table = 2 * entry * n * n + 64 * n + 8 * n + (8 * n if packed_table(n) else 0)
+    if packed is None:
+        packed = packed_table(n)
+    entry = 2 if packed else 4
+    table = 2 * entry * n * n + 64 * n + 8 * n + (8 * n if packed else 0)
     return table + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)

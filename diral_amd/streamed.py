@@ -90,8 +90,11 @@ class StreamedVecEnv:
         (e.g. pre-generated and synchronised long ago) - the event hand-shake with the caller's stream is skipped."""
         if t is None:
             t = self.t
+        converted = False
         if actions.dtype != torch.int32 or not actions.is_contiguous() or tuple(actions.shape) != (self.B, self.N):
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous().view(self.B, self.N)
+            converted = True
+            actions_ready = False                  # produced on the caller's stream just now: the hand-shake is needed
         if self._views[0] is not actions:
             self._views = (actions, [actions[start:start + count] for start, count in self.slices])
         views = self._views[1]
@@ -101,6 +104,11 @@ class StreamedVecEnv:
             if not actions_ready:
                 self.streams[g].wait_event(self._ready)
             self.envs[g]._step(self.step_mode, views[g], t, want_chobs=self.want_chobs, stream=self._raw[g])
+            if converted:
+                # a tensor this call allocated on the caller's stream and the sub-batch streams read: without the
+                # note the caching allocator may hand its block out again (on the caller's stream) while a launch
+                # of a sub-batch stream is still reading it
+                actions.record_stream(self.streams[g])
         self.t = int(t) + 1
         if sync:
             self.wait()
@@ -113,9 +121,15 @@ class StreamedVecEnv:
             cur.wait_stream(s)
 
     def update_velocity(self, draws=None, seed: Optional[int] = None) -> None:
+        """As VecV2VEnv.update_velocity, per sub-batch on its stream: behind the caller's stream (which produced
+        `draws`), and joined afterwards (the draws tensor may be released by the caller right after the call)."""
+        cur = torch.cuda.current_stream(self.device)
+        d = None if draws is None else torch.as_tensor(draws)
         for (start, count), e, s in zip(self.slices, self.envs, self.streams):
+            s.wait_stream(cur)
             with torch.cuda.stream(s):
-                e.update_velocity(None if draws is None else torch.as_tensor(draws)[start:start + count], seed)
+                e.update_velocity(None if d is None else d[start:start + count], seed)
+        self.wait()
 
     def metrics(self, clear: bool = False) -> torch.Tensor:
         self.wait()

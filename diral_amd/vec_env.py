@@ -149,10 +149,12 @@ class VecV2VEnv:
         self.speculate_state = bool(speculate_state)
         self._spec: Optional[tuple] = None      # what the speculative state of the last my_step* is valid for
         self._vel_calls = 0                     # default-seed counter of update_velocity()
+        self._clock: Optional[torch.Tensor] = None   # device slot clock installed by set_clock(); kept alive here
 
     # ---- lifetime -------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
+            self._clock = None
             self.lib.diral_env_destroy(self._h)
             self._h = None
 
@@ -201,6 +203,20 @@ class VecV2VEnv:
         """Tests / A-B timing: run every step on the general kernel (csrc/step_kernel.hpp)."""
         self._ok(self.lib.diral_env_set_option(self._h, OPT_KERNEL_PATH, PATH_GENERAL if on else PATH_AUTO),
                  "diral_env_set_option")
+
+    def set_clock(self, clock: Optional[torch.Tensor]) -> None:
+        """Install (or, with None, remove) a device slot clock: an int64 tensor of one element on this env's device.
+        While it is set the kernels read the slot number as ``t + clock[0]`` on the device (`done`, arrival stamps,
+        trace replay) - what lets a captured hipGraph of K steps replay with a clock that moves on
+        (`diral_env_set_clock`).  The env keeps a reference to the tensor: the C handle only stores its raw
+        address, and a freed block would be handed out again by the caching allocator."""
+        if clock is not None:
+            if (not isinstance(clock, torch.Tensor) or clock.dtype != torch.int64 or clock.numel() != 1
+                    or clock.device != self.device or not clock.is_contiguous()):
+                raise ValueError("the slot clock must be a contiguous int64 tensor of one element on %s" % (self.device,))
+        self._ok(self.lib.diral_env_set_clock(self._h, ctypes.c_void_p(clock.data_ptr()) if clock is not None else None),
+                 "diral_env_set_clock")
+        self._clock = clock
 
     def last_kernel(self) -> int:
         """config.KERNEL_* code of the kernel the last step / observe call launched."""
