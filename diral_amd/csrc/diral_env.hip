@@ -303,7 +303,7 @@ hipError_t verify_ring(DiralEnv* e, hipStream_t s) {
   return hipGetLastError();
 }
 
-size_t slow_set_words(const DiralEnv* e) { return 16 + (size_t)kFastSlowMax + (size_t)e->B; }
+size_t slow_set_words(const DiralEnv* e) { return 16 + (size_t)fast_slow_max(e->B) + (size_t)e->B; }
 hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
   if (!e->slow) return hipSuccess;
   e->slow_launches = 0;
@@ -361,8 +361,8 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
       uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
       uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
       uint32_t* const set_z = e->slow + ((e->slow_launches + 2) % 3) * w;
-      f.slow_cnt_r = set_r; f.slow_list_r = set_r + 16; f.slow_flag_r = set_r + 16 + kFastSlowMax;
-      f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + kFastSlowMax;
+      f.slow_cnt_r = set_r; f.slow_list_r = set_r + 16; f.slow_flag_r = set_r + 16 + fast_slow_max(e->B);
+      f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + fast_slow_max(e->B);
       f.slow_cnt_z = set_z;
       ++e->slow_launches;
       slow_first = true;
@@ -380,7 +380,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
                      ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
-    return launch_fast64(f, r, k, p.B + (slow_first ? kFastSlowMax : 0), s);
+    return launch_fast64(f, r, k, p.B + (slow_first ? fast_slow_max(p.B) : 0), s);
   }
   // the generic FAST instantiation of the general kernel: the plain configuration on sizes the
   // specialised kernels do not take (A > 64, vehicles off the y = 0 lane at N > 64): my_step,

@@ -98,18 +98,19 @@ struct FastParams {
   // quads on the keyed path and takes two to three times as long as the others; a launch ends when its last workgroup
   // does, so such a workgroup must not be among the last to START.  Every launch leaves, for the next one, the list of
   // the envs it found slow (`told` flags set for the next slot) and a flag per env; the next launch runs the listed envs
-  // in its first kFastSlowMax blocks - dispatched first - and the block that would have taken such an env in dispatch
+  // in its first fast_slow_max(B) blocks - dispatched first - and the block that would have taken such an env in dispatch
   // order exits at once.  Three rotating sets (the host counts launches): read set r, build set r + 1, clear the count of
   // set r + 2.  Null: blocks = envs in order (captured launches: a replayed graph does not rotate).
   const uint32_t* slow_cnt_r;     // [1] number of listed envs
-  const uint32_t* slow_list_r;    // [kFastSlowMax]
+  const uint32_t* slow_list_r;    // [fast_slow_max(B)]
   const uint32_t* slow_flag_r;    // [B] != 0: listed
   uint32_t* slow_cnt_w;
   uint32_t* slow_list_w;
   uint32_t* slow_flag_w;
   uint32_t* slow_cnt_z;           // the count the launch after the next will build on: zeroed here
 };
-constexpr int kFastSlowMax = 256;  // listed envs per launch (an env beyond that keeps its place in dispatch order)
+// listed envs per launch (an env beyond that keeps its place in dispatch order): an eighth of the batch, 16 ... 2048
+__host__ __device__ inline int fast_slow_max(int B) { const int m = B >> 3; return m < 16 ? 16 : (m > 2048 ? 2048 : m); }
 
 // Late-bound kernel arguments.  The compiler hoists the scalar loads of EVERY by-value kernel
 // argument to the kernel entry and then keeps (or spills, through v_writelane / v_readlane - VALU
@@ -378,16 +379,17 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   const int MS = fast_mtab_stride(p.A);                          // gather-source table row stride (bytes), [vehicle][resource]
   const int SA = fast_stage_stride(p.A);
 
-  // which env: blocks = envs in order, or (slow envs first) the listed envs in the first kFastSlowMax blocks
+  // which env: blocks = envs in order, or (slow envs first) the listed envs in the first fast_slow_max(B) blocks
   int b = blockIdx.x;
   unsigned int listed = 0u;                  // (ordinary block) != 0: this env runs in one of the first blocks
   unsigned int* const s_slow = reinterpret_cast<unsigned int*>(smem + lay.slow);
   if (p.slow_cnt_r) {
-    if (blockIdx.x < (unsigned int)kFastSlowMax) {
+    const int smax = fast_slow_max(p.B);
+    if (blockIdx.x < (unsigned int)smax) {
       if (blockIdx.x >= *p.slow_cnt_r) return;
       b = (int)p.slow_list_r[blockIdx.x];
     } else {
-      b = (int)blockIdx.x - kFastSlowMax;
+      b = (int)blockIdx.x - smax;
       listed = p.slow_flag_r[b];             // a scalar load in flight next to the loads of P0; tested before any store
     }
   }
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #ifdef DIRAL_TIMING
   // chip-wide clock (s_memrealtime, 100 MHz) at the start and the end of every workgroup, the launches alternating between
   // two sets: start skew, drain, and the gap between two launches of one stream (profiles/launch_timeline.py)
-  if (tid == 0 && p.dbg) p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2)] = __builtin_amdgcn_s_memrealtime();
-  if (lane == 0 && p.dbg) {     // where this wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, behind the stamps
+  if (tid == 0 && p.dbg && !listed) p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2)] = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && p.dbg && !listed) {     // where this wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, behind the stamps
     unsigned int hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -715,6 +717,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // the KEYED path below - 32-bit keys (seq << 8) | source lane, sequence numbers rebuilt from the codes or read
   // from `tkey` - until the entry is refreshed.  Never-heard entries (seq 0) are code 0 with tkey.seq == 0; their
   // ghost xpos (0, or whatever was imported) lives in `tx`, their ages in the age words like everybody's.
+  // (no resource in use - or no tables at all, `notab` - : no merge.  The test also keeps the backend alive: without a
+  // use of the mask here the RICH instantiations die with "illegal VGPR to SGPR copy" - hipcc 7.2)
   const unsigned long long actw = notab ? 0ull : __ballot(lane < A && s_mask[lane < A ? lane : 0] != 0ull);
   const LateFastArgs lpr = (LateFastArgs)late_kernarg_base();
   // the xpos rings of this wave's 16 subjects: lane l holds slot l & 7 of subject l >> 3 (ringv0) / 8 + (l >> 3)
@@ -780,37 +784,51 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     ringv1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(r1, __double2hiint(ringv1)),
                               __builtin_amdgcn_ds_bpermute(r1, __double2loint(ringv1)));
   }
-  // Vehicle.received_update for the resources in ascending order: `step(m4)` merges this lane's
-  // words with those of lane m4 / 4.  The gather sources of FOUR consecutive resources arrive with one ds_read_b32
-  // of this vehicle's table row (the next word a group ahead); a resource nobody transmits on has the identity row -
-  // its step is skipped (uniform test of the active-resource mask)
-  auto merge_walk = [&](auto&& step) {
+  // Vehicle.received_update for the resources in ascending order: w[j] = comb(w[j], w[j] of lane
+  // m_i / 4) for the resources i in use and the wave's four words j.  The gather sources of FOUR consecutive resources
+  // arrive with one ds_read_b32 of this vehicle's table row (the next word a group ahead); a resource nobody transmits on
+  // is skipped (its row is the identity; uniform test of the active mask).  SOFTWARE-PIPELINED by one step: the four
+  // words are four independent dependency chains (gather, combine, gather ...), so a step first combines what the
+  // previous step's gathers brought and then issues its own - word j's gather leaves as soon as ITS combine is done,
+  // while the gathers of the other words are still in flight (LDS operations return in order): a step costs one LDS
+  // round trip instead of four issue slots plus a round trip.  (`t` starts as the words themselves: comb(w, w) = w.)
+  auto merge_walk = [&](unsigned int (&w)[4], auto&& comb) {
     const unsigned int* const mrow = reinterpret_cast<const unsigned int*>(s_mtab + lane * MS);   // MS % 4 == 0
     const int ng = A >> 2;
     unsigned int mw = mrow[0];
     unsigned long long act = actw;
+    int t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (int)w[j];
+    auto step = [&](int m4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[j] = comb(w[j], (unsigned int)t[j]);
+        t[j] = __builtin_amdgcn_ds_bpermute(m4, (int)w[j]);
+        __builtin_amdgcn_sched_barrier(0);                       // (keep the chains interleaved: the scheduler would regroup)
+      }
+    };
 #pragma unroll 1
     for (int g = 0; g < ng; ++g) {
-      const unsigned int w = mw;
+      const unsigned int cur = mw;
       mw = mrow[g + 1];                                          // (word ng: the tail resources, or the row's padding)
       const unsigned int a4 = (unsigned int)act & 15u;
       act >>= 4;
-      if (a4 & 1u) step((int)(w & 255u));
-      if (a4 & 2u) step((int)((w >> 8) & 255u));
-      if (a4 & 4u) step((int)((w >> 16) & 255u));
-      if (a4 & 8u) step((int)(w >> 24));
+      if (a4 & 1u) step((int)(cur & 255u));
+      if (a4 & 2u) step((int)((cur >> 8) & 255u));
+      if (a4 & 4u) step((int)((cur >> 16) & 255u));
+      if (a4 & 8u) step((int)(cur >> 24));
     }
     for (int i = 0; i < (A & 3); ++i) {
       if ((unsigned int)act & (1u << i)) step((int)((mw >> (8 * i)) & 255u));
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = comb(w[j], (unsigned int)t[j]);
   };
   if (badq != 15u) {
     // the coded merge (the words of a bad quad are merged along - meaningless, never read; none at all when every
     // quad of the wave is keyed: a sparse topology)
-    merge_walk([&](int m4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cw[q] |= (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)cw[q]);
-    });
+    if (actw != 0ull) merge_walk(cw, [](unsigned int a, unsigned int b) { return a | b; });
   }
   DIRAL_FSTAMP(4);
 
@@ -1010,10 +1028,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
             const unsigned int seq = r ? tk_own - 8u + (unsigned int)__popc(r) : (wr >> 8);
             k0[i] = kq[i] = (seq << 8) | (unsigned int)lane;
           }
-          merge_walk([&](int m4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) kq[i] = max(kq[i], (unsigned int)__builtin_amdgcn_ds_bpermute(m4, (int)kq[i]));
-          });
+          merge_walk(kq, [](unsigned int a, unsigned int b) { return a > b ? a : b; });
           unsigned int ncode = 0u, nage = 0u;
           bool keep = false;
 #pragma unroll
@@ -1077,7 +1092,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       unsigned int fl = 0u;
       if (s_slow[0]) {
         const unsigned int pos = atomicAdd(ls->slow_cnt_w, 1u);
-        if (pos < (unsigned int)kFastSlowMax) { ls->slow_list_w[pos] = (unsigned int)b; fl = 1u; }
+        if (pos < (unsigned int)fast_slow_max(ls->B)) { ls->slow_list_w[pos] = (unsigned int)b; fl = 1u; }
       }
       flag_w[b] = fl;
       if (b == 0) *ls->slow_cnt_z = 0u;

@@ -31,6 +31,7 @@ full = np.zeros((B * 4096,), np.uint64)
 assert fn(env._h, full.ctypes.data_as(ctypes.c_void_p), 512) == 0
 rt = full[B * 40:B * 44].astype(np.int64).reshape(2, B, 2) * 10e-3     # us; set = slot parity: [0] = slot 62, [1] = slot 63
 prev, last = rt[0], rt[1]
+assert (last[:, 0] > 0).all() and (last[:, 1] > 0).all(), "a workgroup left no stamp"
 t0 = last[:, 0].min()
 st = np.sort(last[:, 0] - t0)
 en = np.sort(last[:, 1] - t0)
