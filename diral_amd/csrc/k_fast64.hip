@@ -14,7 +14,7 @@ struct LaunchFast64 {
 }  // namespace
 
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
-  const LaunchFast64 l{f, r, dim3(B), fast_lds_layout(f.K, f.A, k.rich, k.out64, k.flat).total, s};
+  const LaunchFast64 l{f, r, dim3(B), fast_lds_layout(f.K, f.A, k.rich, k.out64, k.flat, k.ch || k.extra).total, s};
   bool_dispatch(l, std::integer_sequence<bool>{}, k.flat, k.out64, k.ch, k.extra, k.rich);
   return hipGetLastError();
 }

@@ -156,7 +156,7 @@ __host__ __device__ constexpr int fast_hist_stride(int K) { return (K + 1) | 1; 
 // merge reads the sources of FOUR consecutive resources with one ds_read_b32; the row stride of a32 + 4 bytes = 9 / 17
 // words puts the 64 lanes' words - and the byte writes of P1, lane = row - on distinct banks
 __host__ __device__ constexpr int fast_mtab_stride(int A) { return (A <= 32 ? 32 : 64) + 4; }
-__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64, bool flat) {
+__host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool out64, bool flat, bool ratios = true) {
   FastLds l;
   uint32_t o = 0;
   const uint32_t a32 = A <= 32 ? 32u : 64u;
@@ -168,8 +168,9 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
   l.cnt = o;   o += 4u * 64;
   l.slow = o;  o += 16u;                     // the workgroup holds a quad flagged for the keyed path of the next slot
   l.mtab = o;  o += 64u * fast_mtab_stride(A);      // [vehicle][resource] gather source lane * 4 (bpermute address), bytes
-  l.rtx = o;   o += 8u * 64;                // my_step_ch: reception ratio R per transmitter
-  l.inr = o;   o += 4u * 64;                // my_step_ch: receivers in range per transmitter
+  // (CH and EXTRA instantiations only - `ratios`: without them the RICH workgroup of A <= 32 stays at 20 KB, eight per CU)
+  l.rtx = o;   o += ratios ? 8u * 64 : 0u;  // my_step_ch: reception ratio R per transmitter
+  l.inr = o;   o += ratios ? 4u * 64 : 0u;  // my_step_ch: receivers in range per transmitter
   l.px = l.py = l.npx = l.rew = l.stage = o;
   if (rich) {                               // RICH output tail (rich_out.hpp): per-vehicle values by index
     l.px = o;  o += 8u * 64;
@@ -359,7 +360,7 @@ __device__ DIRAL_OUTLINE double fast_ch_reward(int rd, bool collided, double R) 
 template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH>
 __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64, FLAT);
+  const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64, FLAT, CH || EXTRA);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
   double* s_edges = reinterpret_cast<double*>(smem + lay.edges);
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem + lay.mask);
@@ -471,6 +472,13 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     mynpx = p.trace[(base + (size_t)tt) * N + lane];
   }
   if (EXTRA && p.nomove) mynpx = mypx;                                         // network.py:302-305: no mobility, no move
+  if (wave == 1) {
+    // the transmitter sets of ALL resources (test_env.py:153-157) for P2 and the RICH tail: every vehicle ORs its bit
+    // into the mask of its resource - one 64-bit LDS atomic for the wave, behind the zeroing (a wave's LDS operations
+    // execute in order); the waves of P1 use their own ballots
+    if (lane < (A <= 32 ? 32 : 64)) s_mask[lane] = 0ull;          // (the array holds 32 or 64 masks)
+    if (myact >= 0) atomicOr(&s_mask[myact], 1ull << lane);
+  }
   if (wave == 0) {
     if (lane == 0) s_slow[0] = 0u;
     s_act[lane] = myact; s_cnt[lane] = 0u;
@@ -488,26 +496,21 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   const bool dist_obs = RICH && (p.chobs_mode & 2) != 0;
   const bool rd2_lanes = FLAT && !CH && p.reward_design == 2 && !(p.flags & DIRAL_F_TOY_WEIGHTS) && !(EXTRA && p.design);
   const bool emit_chobs = RICH && (p.chobs_mode & 1) != 0;
-  // (the transmitter masks of the owned resources are collected in lanes 0, 1, ... of `mkv` - a compare and two selects per
-  // resource - and stored to s_mask with one instruction after the loop: a one-lane store per resource is an exec-mask
-  // round trip each)
-  unsigned int mkv_lo = 0u, mkv_hi = 0u;
-  int slot = 0;
   const bool need_rw = !CH && !(EXTRA && p.design) && !rd2_lanes;      // collision reward per resource, here (uniform)
+  mtab_t* const mtab_row = s_mtab + lane * MS;               // this vehicle's rows of the gather table / the staging array
+  out_t* const stage_row = s_stage + lane * SA;
 #pragma unroll 1
-  for (int i = wave; i < A; i += 4, ++slot) {
+  for (int i = wave; i < A; i += 4) {
     const unsigned long long mk = __ballot(myact == i);     // tx set (test_env.py:153-157)
     const int c = __popcll(mk);
-    mkv_lo = lane == slot ? (unsigned int)mk : mkv_lo;
-    mkv_hi = lane == slot ? (unsigned int)(mk >> 32) : mkv_hi;
     // Network.find_closest_tx (network.py:378-398): ascending id, strict '<'.  `bid` starts as the own lane: a
     // transmitter of resource i is never its own receiver, so "bid == lane" IS "no transmitter in range"
     double best = 100000.0;
     int bid = lane;
     auto search = [&](auto fast_tag) {
       constexpr bool ABS = decltype(fast_tag)::value;     // |dx| without the per-pair exponent test (p1_fast)
-      unsigned long long m = mk;
-      while (m) {
+      unsigned long long m = mk;                            // (not empty: the caller's test)
+      do {
         const int w = __builtin_ctzll(m);
         asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(w));      // m &= ~(1 << w): one scalar instruction (m & (m - 1): three)
         double d, keep;                                     // `best` holds `keep`: the distance, or (ABS) the SIGNED difference -
@@ -534,15 +537,17 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           const int n = 1 + __popcll(__ballot((myact == i) && (lane != w) && (d < 2.0 * p.Rc)));
           if (lane == 0) s_rtx[w] = (n == 1) ? 1.0 : -(double)n;
         }
-      }
+      } while (m);
     };
-    if (FLAT && p1_fast) search(std::true_type{});
-    else search(std::false_type{});
+    if (mk != 0ull) {
+      if (FLAT && p1_fast) search(std::true_type{});
+      else search(std::false_type{});
+    }
     best = __builtin_fabs(best);
     const bool self = !live || myact == i;                  // padded lanes and the transmitters of i gather from themselves
     const int src_lane = self ? lane : bid;
     const bool got = src_lane != lane;
-    s_mtab[lane * MS + i] = (mtab_t)(src_lane << 2);
+    mtab_row[i] = (mtab_t)(src_lane << 2);
     if constexpr (RICH) {
       if (emit_chobs) {
         // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432): 0 on the own
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         // Straight from the registers of the search into the staging array (lane = row); rows leave
         // coalesced after the barrier.
         const double ob = (myact == i || c == 0) ? 0.0 : (dist_obs ? best : 1.0);
-        s_stage[lane * SA + i] = (out_t)ob;
+        stage_row[i] = (out_t)ob;
       }
     }
     if (EXTRA && CH && p.la && got) p.la[(bN + bid) * N + lane] = (int32_t)(p.t + (p.t_dev ? *p.t_dev : 0ll));   // test_env.py:436
@@ -581,7 +586,6 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
     }
   }
-  if (lane < slot) s_mask[wave + 4 * lane] = ((unsigned long long)mkv_hi << 32) | mkv_lo;
   DIRAL_FSTAMP(2);
   __syncthreads();
 
