@@ -402,6 +402,43 @@ def rollout_sps_graph(device, envs=4096, K=50, replays=8):
     return out
 
 
+def rollout_sps_fused(device, envs=4096, slots=400, warm=80, write_chobs=False):
+    """The closed loop of `rollout_sps` as ONE launch per slot (`diral_env_step_policy`: env step + reward shaping + SPS
+    decision, the channel observation handed over in LDS and - unless `write_chobs` - never written to HBM); eager
+    launches from Python, two action buffers alternating.  Same decisions and rewards as the three-launch loop
+    (tests/test_gpu_parity.py::test_fused_policy_slot_equals_three_launches)."""
+    from diral_amd import c2_config
+    from diral_amd.sps import SpsPolicy
+    cfg = c2_config()
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
+    env.reset_topology(seed=GLOBAL_SEED)
+    pol = SpsPolicy(env.B, env.N, env.A, device=device, seed=0)
+    acts = [pol.prev_action.clone(), torch.empty_like(pol.prev_action)]
+    shaped = [torch.empty((envs, env.N), dtype=torch.float32, device=device) for _ in range(2)]
+    sum_r = [torch.empty((envs,), dtype=torch.float32, device=device) for _ in range(2)]
+    coll = [torch.empty((envs,), dtype=torch.float32, device=device) for _ in range(2)]
+    t0 = None
+    for t in range(warm + slots):
+        if t == warm:
+            torch.cuda.synchronize(device)
+            env.metrics(clear=True)
+            t0 = time.perf_counter()
+        i = t & 1
+        env.step_policy(acts[i], t, pol, acts[i ^ 1], shaped_out=shaped[i], sum_r_out=sum_r[i], collision_out=coll[i],
+                        global_reward_avg=True, want_chobs=write_chobs)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    from diral_amd.config import KERNEL_POLICY
+    assert env.last_kernel() & KERNEL_POLICY
+    m = env.metrics().sum(0)
+    return {"what": "the closed loop of rollout_sps as ONE launch per slot (diral_env_step_policy: c2 env step + driver reward "
+                    "shaping + SPS decision; channel observation %s), %d envs, %d slots" % (
+                        "also written to HBM" if write_chobs else "kept on the chip", envs, slots),
+            "agent_steps_per_s": envs * env.N * slots / dt, "ms_per_slot": dt / slots * 1e3,
+            "collision_fraction": float(m[3] / (m[2] + m[3]))}
+
+
 def c2_graph(device, envs=4096, K=20, replays=50):
     """The headline step (c2: state + reward + channel observation, iid-uniform actions from a ring of K action tensors)
     with K slots captured into ONE hipGraph (slot number on the device: diral_env_set_clock) and replayed: what is left of
@@ -691,6 +728,8 @@ def main() -> int:
                 also["rollout_sps"] = rollout_sps(device)
                 torch.cuda.empty_cache()
                 also["rollout_sps_graph"] = rollout_sps_graph(device)
+                also["rollout_sps_fused"] = rollout_sps_fused(device)
+                also["rollout_sps_fused_chobs"] = rollout_sps_fused(device, write_chobs=True)
                 also["c2_graph"] = c2_graph(device)
                 torch.cuda.empty_cache()
                 also["secondary_observation_modes"] = secondary_modes(device)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "diral_env_set_trace", "diral_env_set_option", "diral_env_last_kernel",
     "diral_sps_window_from_chobs", "diral_sps_step_chobs", "diral_driver_shape",
     "diral_env_export_entries", "diral_env_import_entries",
-    "diral_env_set_clock", "diral_clock_add", "diral_sps_step_chobs_clocked",
+    "diral_env_set_clock", "diral_clock_add", "diral_sps_step_chobs_clocked", "diral_env_step_policy",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load() -> ctypes.CDLL:
         "diral_env_set_clock": (I, [P, P]),
         "diral_clock_add": (I, [P, I64, P]),
         "diral_sps_step_chobs_clocked": (I, [I, I, P, I, P, P, P, D, D, D, U64, P, P, P]),
+        "diral_env_step_policy": (I, [P, I, P, I64, P, P, P, P, I, P, P]),
     }
     for name in SYMBOLS:
         try:

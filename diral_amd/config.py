@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1
@@ -56,6 +56,7 @@ KERNEL_EXTRA = 32
 KERNEL_CH = 64
 KERNEL_RING = 128
 KERNEL_PACKED = 256
+KERNEL_POLICY = 512
 
 MAX_USERS = 256
 MAX_CHANNELS = 256
@@ -97,6 +98,35 @@ class DiralCfg(ctypes.Structure):
         ("highway_height", ctypes.c_double),
         ("communication_range", ctypes.c_double),
         ("bin_range", ctypes.c_double),
+    ]
+
+
+class DiralSlotPolicy(ctypes.Structure):
+    """ctypes image of ``struct DiralSlotPolicy`` (include/diral_env.h): the policy epilogue of
+    ``diral_env_step_policy``."""
+
+    _fields_ = [
+        ("struct_bytes", ctypes.c_uint32),
+        ("shape_flags", ctypes.c_int32),
+        ("pen_threshold", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+        ("pen_value", ctypes.c_double),
+        ("shaped_out", ctypes.c_void_p),
+        ("sum_r_out", ctypes.c_void_p),
+        ("collision_out", ctypes.c_void_p),
+        ("pen_counter", ctypes.c_void_p),
+        ("pen_prev_actions", ctypes.c_void_p),
+        ("sps_prev_action", ctypes.c_void_p),
+        ("sps_counter", ctypes.c_void_p),
+        ("rssi_threshold", ctypes.c_double),
+        ("inc_db", ctypes.c_double),
+        ("keep_prob", ctypes.c_double),
+        ("draw_counter", ctypes.c_void_p),
+        ("draw_keep", ctypes.c_void_p),
+        ("draw_choice", ctypes.c_void_p),
+        ("seed", ctypes.c_uint64),
+        ("seed_clock", ctypes.c_void_p),
+        ("actions_out", ctypes.c_void_p),
     ]
 
 

@@ -3,21 +3,9 @@
 // metric read-out.  All are elementwise / tiny; none is on the hot path.
 #pragma once
 #include "common.hpp"
+#include "policy_device.hpp"
 
 namespace diral {
-
-// counter-based generator (splitmix64 finaliser over seed/stream/index); the
-// reference uses unseeded global RNGs, so only the distribution matters.
-__device__ inline uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ inline uint64_t rng_u64(uint64_t seed, uint64_t stream, uint64_t idx) {
-  return mix64(mix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx);
-}
-__device__ inline double rng_unit(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
 
 // Network.initialize_mobility_topology (network.py:92-119): x = randint(0, L)
 // (integer valued), y = randint(0, H/2) = 0, v = 1.7 if mobility_vary else
@@ -309,16 +297,6 @@ __device__ inline int sps_choose(W w, int A, int prev, double threshold, double 
   return chosen;
 }
 
-// SemiPersistentScheduling.step (algorithms/v2x_sps.py:76-104); one thread per agent.
-// Returns true when the agent has to choose a new resource (then `cnt` is already redrawn).
-__device__ inline bool sps_advance(int i, int& cnt, double keep_prob, const int32_t* draw_counter,
-                                   const double* draw_keep, uint64_t seed) {
-  if (cnt != 0) { cnt -= 1; return false; }                        // v2x_sps.py:85-89
-  cnt = draw_counter ? draw_counter[i] : 5 + (int)(rng_u64(seed, 7, (uint64_t)i) % 12ull);   // randint(5, 16)
-  const double u = draw_keep ? draw_keep[i] : rng_unit(rng_u64(seed, 8, (uint64_t)i));
-  return !(u < keep_prob);                                         // v2x_sps.py:93-98
-}
-
 __global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* prev_action, int32_t* counter,
                                 double threshold, double inc_db, double keep_prob, const int32_t* draw_counter,
                                 const double* draw_keep, const int32_t* draw_choice, uint64_t seed,
@@ -338,89 +316,12 @@ __global__ void sps_step_kernel(int agents, int A, const double* win, int32_t* p
   actions_out[i] = action;
 }
 
-// Build extension (the reference never wires SPS to the toy env): an RSSI-like selection window
-// from the toy env's type-2 channel observation `obs[user][i]` (test_env.py:206, 240,
-// network.py:385): distance d to the nearest in-range transmitter -> log-distance path loss
-// -40 - 30 log10(max(d, 1)) dB; 100000 (busy, nobody in range) -> -160; 0 (idle) -> -200; the
-// agent's own resource reads as busy (-60).  Lower = quieter.
-__device__ inline double sps_rssi_from_chobs(double d, bool own) {
-  if (own) return -60.0;
-  if (d >= 100000.0) return -160.0;
-  if (d > 0.0) return -40.0 - 30.0 * log10(d < 1.0 ? 1.0 : d);
-  return -200.0;
-}
-
 template <typename T>
 __global__ void sps_window_kernel(size_t total, int A, const T* chobs, const int32_t* actions, double* win) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const size_t i = e / A;
   win[e] = sps_rssi_from_chobs((double)chobs[e], (int)(e - i * A) == actions[i]);
-}
-
-// ---- wave-cooperative SPS step (A <= 256) ------------------------------------------------
-// Re-selection is rare (counter expiry x 20 % = 1.7 % of the agents per slot), but with one
-// thread per agent almost every wave holds one such lane and then runs at the speed of that
-// lane's serial window scan.  Here the 64 lanes of the wave serve each of their re-selecting
-// agents together: lane s holds subframe s (+64c) of that agent's window - one coalesced row
-// read, one log10 per lane - the threshold loop is a ballot + popcount, and the stable-sort
-// position of every candidate is counted against the candidates' values read lane by lane.
-constexpr int kSpsWaveMaxA = 256;
-
-__device__ inline double sps_readlane(double v, int j) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
-}
-
-// choose_new_resource (algorithms/v2x_sps.py:24-74) for ONE agent by the whole wave; every argument
-// but `w` / `lane` is wave-uniform, and so is the result.
-template <int NC>
-__device__ inline int sps_choose_wave(const double (&w)[NC], int lane, int A, int prev, double threshold, double inc_db,
-                                      unsigned int r) {
-  const double min_sA = (double)A / 5.0;                           // len(selection_window)/5
-  double thr_next = threshold, thr = threshold;
-  unsigned long long el[NC];                                       // sA: candidates of chunk c
-  int n_sa = 0;
-  for (int it = 0; it < 100000; ++it) {                            // while len(sA) < min_sA
-    thr = thr_next;
-    n_sa = 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int s = lane + 64 * c;
-      el[c] = __ballot(s < A && s != prev && w[c] < thr);
-      n_sa += __popcll(el[c]);
-    }
-    thr_next = thr + inc_db;                                       // tmp_threshold += self.inc_dB
-    if (!((double)n_sa < min_sA)) break;
-  }
-  const double min_len = min_sA < (double)n_sa ? min_sA : (double)n_sa;
-  int need = (int)min_len;
-  if ((double)need < min_len) need += 1;                           // sB grows until len(sB) >= min_len
-  if (need < 1) need = 1;
-  const int pick = (int)(r % (unsigned int)need);                  // random.choice(sB)
-  // position of every candidate in sorted(sA.items(), key=value): a stable sort, i.e. ordered by
-  // (value, subframe)
-  int rank[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) rank[c] = 0;
-#pragma unroll
-  for (int cj = 0; cj < NC; ++cj) {
-    unsigned long long m = el[cj];
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      const double wj = sps_readlane(w[cj], j);
-      const int sj = j + 64 * cj;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) rank[c] += (wj < w[c] || (wj == w[c] && sj < lane + 64 * c)) ? 1 : 0;
-    }
-  }
-  int chosen = prev;                                               // (only if sA stayed empty: cannot happen)
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const unsigned long long hit = __ballot(((el[c] >> lane) & 1ull) && rank[c] == pick);
-    if (hit) chosen = __builtin_ctzll(hit) + 64 * c;
-  }
-  return chosen;
 }
 
 // SemiPersistentScheduling.step for 64 agents per wave.  CHOBS: `src` is the env's channel observation
@@ -472,12 +373,10 @@ __global__ void sps_step_wave_kernel(int agents, int A, const T* src, const int3
       const unsigned int r_j = (unsigned int)__builtin_amdgcn_readlane((int)r, j);
       double w[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int s = lane + 64 * c;
-        w[c] = 0.0;
-        if (s < A) w[c] = CHOBS ? sps_rssi_from_chobs((double)raw[q][c], s == own_j) : (double)raw[q][c];
-      }
-      const int ch = sps_choose_wave<NC>(w, lane, A, prev_j, threshold, inc_db, r_j);
+      for (int c = 0; c < NC; ++c) w[c] = (lane + 64 * c < A) ? (double)raw[q][c] : 0.0;
+      int ch;
+      if constexpr (CHOBS) ch = sps_choose_chobs_wave<NC>(w, lane, A, prev_j, own_j, threshold, inc_db, r_j);
+      else ch = sps_choose_wave<NC>(w, lane, A, prev_j, threshold, inc_db, r_j);
       if (lane == j) action = ch;
     }
   }
@@ -530,15 +429,6 @@ constexpr int kShapeEnvsPerBlock = 64;
 // tail: numpy/_core/src/umath/loops_utils.h pairwise_sum) is walked with lane shuffles, and every lane rewrites its own
 // reward.  (The thread-per-env kernel below reads 64 strided rows per wave and sums them one element at a time:
 // 12 us at 4096 envs against 3 us here.)
-template <typename T>
-__device__ inline T shfl_t(T v, int src) {
-  if constexpr (sizeof(T) == 8) {
-    const double d = (double)v;
-    return (T)__hiloint2double(__shfl(__double2hiint(d), src), __shfl(__double2loint(d), src));
-  } else {
-    return __shfl(v, src);
-  }
-}
 constexpr int kShapeWaveBlock = 256;
 template <typename T>
 __global__ __launch_bounds__(kShapeWaveBlock) void driver_shape_wave_kernel(int envs, int N, int A, const T* reward_in,
@@ -553,19 +443,7 @@ __global__ __launch_bounds__(kShapeWaveBlock) void driver_shape_wave_kernel(int 
   const size_t g = (size_t)b * N + lane;
   const bool live = lane < N;
   const T a = live ? reward_in[g] : (T)0;
-  // r[j] = a[j] + a[8 + j] + a[16 + j] + ... (in that order) for j = 0..7, over the whole blocks of eight
-  const int nb = N >> 3;
-  T r = a;
-  for (int i = 1; i < nb; ++i) {
-    const T v = shfl_t(a, (lane & 7) + 8 * i);
-    r = r + v;
-  }
-  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): a shuffle-down tree over lanes 0..7
-  T t = r + shfl_t(r, lane + 1);
-  t = t + shfl_t(t, lane + 2);
-  t = t + shfl_t(t, lane + 4);
-  T sr = shfl_t(t, 0);
-  for (int i = nb * 8; i < N; ++i) sr = sr + shfl_t(a, i);          // the sequential tail
+  const T sr = np_row_sum_wave(a, N, lane);
   if (lane == 0) {
     if (sum_r_out) sum_r_out[b] = sr;
     if (collision_out) collision_out[b] = (T)A - sr;

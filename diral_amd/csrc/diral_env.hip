@@ -310,7 +310,10 @@ hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
   return hipMemsetAsync(e->slow, 0, 3 * slow_set_words(e) * 4, s);
 }
 
-hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
+// `pol` / `fused`: diral_env_step_policy - when the configuration runs on the POL instantiation of step_fast64 the policy
+// epilogue is part of this launch and *fused is set; otherwise the plain step is launched and the caller adds the two
+// policy launches
+hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, const PolParams* pol = nullptr, bool* fused = nullptr) {
   const int vpl = e->vpl;
   const bool flat_y = e->flat_y;
   const bool spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
@@ -380,7 +383,15 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s) {
                      ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
-    return launch_fast64(f, r, k, p.B + (slow_first ? fast_slow_max(p.B) : 0), s);
+    const int grid = p.B + (slow_first ? fast_slow_max(p.B) : 0);
+    if (pol && k.flat && !k.ch && !k.extra && p.N >= 8) {
+      // the policy epilogue: RICH instantiation (the channel observation is staged in LDS whether or not it is written out)
+      if (!k.rich) { r.plain_state = 1; }
+      e->last_kernel |= DIRAL_KERNEL_RICH | DIRAL_KERNEL_POLICY;
+      if (fused) *fused = true;
+      return launch_fast64_policy(f, r, *pol, k.out64, grid, s);
+    }
+    return launch_fast64(f, r, k, grid, s);
   }
   // the generic FAST instantiation of the general kernel: the plain configuration on sizes the
   // specialised kernels do not take (A > 64, vehicles off the y = 0 lane at N > 64): my_step,
@@ -746,6 +757,55 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
+}
+
+static int sps_step_chobs_impl(int agents, int num_channels, const void* chobs, int chobs_dtype, const int32_t* actions,
+                               int32_t* prev_action, int32_t* counter, double rssi_threshold, double inc_db,
+                               double keep_prob, const int32_t* draw_counter, const double* draw_keep,
+                               const int32_t* draw_choice, uint64_t seed, const long long* clock, int32_t* actions_out,
+                               void* stream);
+
+int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t t, void* state_out, void* rew_out,
+                          uint8_t* done_out, void* chobs_out, int out_dtype, const DiralSlotPolicy* pol, void* stream) {
+  if (!e || !actions || !pol || pol->struct_bytes != sizeof(DiralSlotPolicy)) return DIRAL_ERR_BAD_ARG;
+  if (!pol->sps_prev_action || !pol->sps_counter || !pol->actions_out) return DIRAL_ERR_BAD_ARG;
+  if (mode != DIRAL_STEP_MY_STEP && mode != DIRAL_STEP_MY_STEP_CH) return DIRAL_ERR_BAD_ARG;
+  if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  if (mode == DIRAL_STEP_MY_STEP_CH && (e->cfg.reward_design < 2 || e->cfg.reward_design > 4)) return DIRAL_ERR_BAD_CONFIG;
+  if (pol->shaped_out && !rew_out) return DIRAL_ERR_BAD_ARG;                 // (the three-launch form shapes rew_out)
+  if ((pol->shape_flags & ~5) != 0) return DIRAL_ERR_BAD_ARG;                // global_reward_avg | stuck-action penalty
+  if (pol->shaped_out && (pol->shape_flags & 4) && (!pol->pen_counter || !pol->pen_prev_actions)) return DIRAL_ERR_BAD_ARG;
+  if (e->A > kSpsWaveMaxA) return DIRAL_ERR_UNSUPPORTED;
+  DeviceGuard guard(e->device);
+  StepParams p = e->base;
+  p.mode = mode; p.t = t; p.episode = 0.0; p.eps = 1.0; p.out_f64 = (out_dtype == DIRAL_F64);
+  p.actions = actions;
+  p.state_out = e->S > 0 ? state_out : nullptr;
+  p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
+  p.chobs_in = nullptr; p.rew_in = nullptr;
+  PolParams q;
+  q.shape_flags = pol->shape_flags; q.pen_threshold = pol->pen_threshold; q.pen_value = pol->pen_value;
+  q.shaped_out = pol->shaped_out; q.sum_r_out = pol->sum_r_out; q.coll_out = pol->collision_out;
+  q.pen_counter = pol->pen_counter; q.pen_prev = pol->pen_prev_actions;
+  q.sps_prev = pol->sps_prev_action; q.sps_counter = pol->sps_counter;
+  q.threshold = pol->rssi_threshold; q.inc_db = pol->inc_db; q.keep_prob = pol->keep_prob;
+  q.draw_counter = pol->draw_counter; q.draw_keep = pol->draw_keep; q.draw_choice = pol->draw_choice;
+  q.seed = pol->seed; q.clock = (const long long*)pol->seed_clock; q.actions_out = pol->actions_out;
+  bool fused = false;
+  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, &q, &fused));
+  HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
+  if (fused) return DIRAL_OK;
+  // the same slot as three launches (configurations the POL instantiation does not take)
+  if (!chobs_out) return DIRAL_ERR_UNSUPPORTED;
+  if (pol->shaped_out) {
+    const int st = diral_driver_shape(e->B, e->N, e->A, rew_out, out_dtype, actions, nullptr, nullptr, pol->pen_counter,
+                                      pol->pen_prev_actions, pol->shape_flags, pol->pen_threshold, pol->pen_value,
+                                      pol->shaped_out, pol->sum_r_out, pol->collision_out, nullptr, nullptr, stream);
+    if (st != DIRAL_OK) return st;
+  }
+  return sps_step_chobs_impl(e->B * e->N, e->A, chobs_out, out_dtype, actions, pol->sps_prev_action, pol->sps_counter,
+                             pol->rssi_threshold, pol->inc_db, pol->keep_prob, pol->draw_counter, pol->draw_keep,
+                             pol->draw_choice, pol->seed, (const long long*)pol->seed_clock, pol->actions_out, stream);
 }
 
 int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_in, const double* rew_in,

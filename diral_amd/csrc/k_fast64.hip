@@ -5,17 +5,26 @@
 namespace diral {
 namespace {
 struct LaunchFast64 {
-  const FastParams& f; const RichParams& r; dim3 g; uint32_t lds; hipStream_t s;
+  const FastParams& f; const RichParams& r; const PolParams& q; dim3 g; uint32_t lds; hipStream_t s;
   template <bool FL, bool O, bool C, bool X, bool R>
   void operator()(std::integer_sequence<bool, FL, O, C, X, R>) const {
-    hipLaunchKernelGGL((step_fast64_kernel<FL, O, C, X, R>), g, dim3(256), lds, s, f, r);
+    hipLaunchKernelGGL((step_fast64_kernel<FL, O, C, X, R>), g, dim3(256), lds, s, f, r, q);
   }
 };
 }  // namespace
 
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
-  const LaunchFast64 l{f, r, dim3(B), fast_lds_layout(f.K, f.A, k.rich, k.out64, k.flat, k.ch || k.extra).total, s};
+  static const PolParams no_policy{};
+  const LaunchFast64 l{f, r, no_policy, dim3(B), fast_lds_layout(f.K, f.A, k.rich, k.out64, k.flat, k.ch || k.extra).total, s};
   bool_dispatch(l, std::integer_sequence<bool>{}, k.flat, k.out64, k.ch, k.extra, k.rich);
+  return hipGetLastError();
+}
+
+// the POL instantiations (policy epilogue): the flat highway, my_step, no EXTRA switches, RICH
+hipError_t launch_fast64_policy(const FastParams& f, const RichParams& r, const PolParams& q, bool out64, int B, hipStream_t s) {
+  const uint32_t lds = fast_lds_layout(f.K, f.A, true, out64, true, false).total;
+  if (out64) hipLaunchKernelGGL((step_fast64_kernel<true, true, false, false, true, true>), dim3(B), dim3(256), lds, s, f, r, q);
+  else hipLaunchKernelGGL((step_fast64_kernel<true, false, false, false, true, true>), dim3(B), dim3(256), lds, s, f, r, q);
   return hipGetLastError();
 }
 }  // namespace diral

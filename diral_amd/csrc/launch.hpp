@@ -12,6 +12,7 @@
 namespace diral {
 
 struct FastParams;   // step_fast64.hpp
+struct PolParams;    // policy_device.hpp
 struct ObserveParams;   // observe_kernel.hpp
 
 // which instantiation of a specialised kernel to launch
@@ -26,6 +27,7 @@ struct KernelSel {
 };
 
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
+hipError_t launch_fast64_policy(const FastParams& f, const RichParams& r, const PolParams& q, bool out64, int B, hipStream_t s);
 hipError_t launch_wide2(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t set_attr_wide2(int A, int K);

@@ -27,6 +27,7 @@
 //   * branch-free histogram bin search; rare paths out of line.
 #pragma once
 #include "common.hpp"
+#include "policy_device.hpp"
 #include "rich_out.hpp"
 #include "step_kernel.hpp"
 
@@ -128,6 +129,9 @@ __device__ inline unsigned long long late_kernarg_base() {
 // byte offset of the second kernel argument (RichParams) in the kernarg segment
 constexpr unsigned long long kRichArgOffset = (sizeof(FastParams) + alignof(RichParams) - 1) / alignof(RichParams) * alignof(RichParams);
 typedef const __attribute__((address_space(4))) RichParams* LateRichArgs;
+// ... and of the third (PolParams)
+constexpr unsigned long long kPolArgOffset = (kRichArgOffset + sizeof(RichParams) + alignof(PolParams) - 1) / alignof(PolParams) * alignof(PolParams);
+typedef const __attribute__((address_space(4))) PolParams* LatePolArgs;
 __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
   const LateRichArgs a = (LateRichArgs)(kernarg_base + kRichArgOffset);
   RichParams r;
@@ -343,6 +347,39 @@ __device__ DIRAL_OUTLINE double fast_ch_reward(int rd, bool collided, double R) 
   return 1.0;
 }
 
+// The SPS agents of one env decide from the channel observation staged in LDS (POL instantiations): what
+// sps_step_wave_kernel<1, T, true> does with the rows it loads from HBM, for the 64 lanes = vehicles of this wave.
+// `stage`: [vehicle][SA] of out dtype, as written to chobs_out; `own`: this slot's action of the lane's vehicle.
+// Out of line: log10 and the candidate ranking stay out of the step kernel's register allocation; runs once per env.
+template <typename T>
+__device__ DIRAL_OUTLINE void fast_sps_decide(const T* stage, int SA, int A, int N, size_t bN, int lane, int own,
+                                              int action, int cnt, const PolParams* q) {
+  // (`action`, `cnt`: the agent's prev_action and reselection counter, loaded by the caller ahead of P3)
+  const uint64_t seed = q->seed + (q->clock ? (uint64_t)*q->clock : 0ull);
+  const int i = (int)bN + lane;
+  const bool live = lane < N;
+  const bool resel = live && sps_advance(i, cnt, q->keep_prob, q->draw_counter, q->draw_keep, seed);
+  unsigned int r = 0;
+  if (resel) r = q->draw_choice ? (unsigned int)q->draw_choice[i] : (unsigned int)(rng_u64(seed, 9, (uint64_t)i) >> 33);
+  unsigned long long todo = __ballot(resel);
+  while (todo) {
+    const int j = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int prev_j = __builtin_amdgcn_readlane(action, j);
+    const int own_j = __builtin_amdgcn_readlane(own, j);
+    const unsigned int r_j = (unsigned int)__builtin_amdgcn_readlane((int)r, j);
+    double d[1];
+    d[0] = lane < A ? (double)stage[j * SA + lane] : 0.0;
+    const int ch = sps_choose_chobs_wave<1>(d, lane, A, prev_j, own_j, q->threshold, q->inc_db, r_j);
+    if (lane == j) action = ch;
+  }
+  if (resel) q->sps_prev[i] = action;                                 // v2x_sps.py:98
+  if (live) {
+    q->sps_counter[i] = cnt;
+    q->actions_out[i] = action;
+  }
+}
+
 #ifdef DIRAL_TIMING
 #define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) { p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     if ((i) == 7) { __builtin_amdgcn_s_waitcnt(0); atomicMax(&p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2) + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } } while (0)
@@ -357,8 +394,12 @@ __device__ DIRAL_OUTLINE double fast_ch_reward(int rd, bool collided, double R) 
 // the plain instantiations stay free of them (they cost the headline kernel 4 spilled VGPRs).
 // RICH: the output tail of rich_out.hpp (channel observation output, the cheap State flags)
 // instead of the fixed [one-hot | histogram] state; `r` is only read by these instantiations.
-template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH>
-__global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r) {
+// POL: the policy epilogue (PolParams: reward shaping + the SPS agents' decisions for the next slot) - RICH instantiations
+// of my_step only; `q` is only read by these.
+template <bool FLAT, bool OUT64, bool CH, bool EXTRA, bool RICH, bool POL = false>
+__global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(const FastParams p, const RichParams r,
+                                                                                const PolParams q) {
+  static_assert(!POL || (RICH && !CH), "the policy epilogue needs the staged channel observation of a my_step slot");
   extern __shared__ __align__(16) unsigned char smem[];
   const FastLds lay = fast_lds_layout(p.K, p.A, RICH, OUT64, FLAT, CH || EXTRA);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
@@ -549,7 +590,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const bool got = src_lane != lane;
     mtab_row[i] = (mtab_t)(src_lane << 2);
     if constexpr (RICH) {
-      if (emit_chobs) {
+      if (emit_chobs || POL) {
         // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240, 306, 432): 0 on the own
         // resource or an unused one; my_step with State.type 2: the distance to the closest in-range
         // transmitter, 100000 (network.py:385) when none is in range; otherwise the constant 1.
@@ -694,6 +735,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
           stream_store(co + e, s_stage[u * SA + (e - u * A)]);
         }
       }
+    }
+  }
+  int pol_action = 0, pol_cnt = 1;          // POL, wave 3: the agents' policy state, loaded here and used behind P3
+  if constexpr (POL) {
+    if (wave == 3 && live) {
+      const LatePolArgs lq = (LatePolArgs)(late_kernarg_base() + kPolArgOffset);
+      pol_action = lq->sps_prev[bN + lane];
+      pol_cnt = lq->sps_counter[bN + lane];
     }
   }
   DIRAL_FSTAMP(3);
@@ -1082,6 +1131,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     if (newf && lane == 0) s_slow[0] = 1u;                        // (zeroed in P0, two barriers ago)
   }
   if (mycnt) atomicAdd(&s_cnt[lane], mycnt);
+  if constexpr (POL) {
+    // the SPS agents' decisions for the next slot (algorithms/v2x_sps.py:76-104): wave 3, in the time it would
+    // otherwise wait at the barrier for wave 0 (which did P2); the staging array is complete since the P1 barrier
+    if (wave == 3) {
+      const PolParams* const qp = reinterpret_cast<const PolParams*>(late_kernarg_base() + kPolArgOffset);
+      fast_sps_decide<out_t>(s_stage, SA, A, N, bN, lane, s_act[lane], pol_action, pol_cnt, qp);
+    }
+  }
 #ifdef DIRAL_TIMING
   if (lane == 0 && p.dbg) p.dbg[(size_t)p.B * 48 + (size_t)b * 4 + wave] = dbg_path;
 #endif
@@ -1100,6 +1157,41 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       }
       flag_w[b] = fl;
       if (b == 0) *ls->slow_cnt_z = 0u;
+    }
+  }
+
+  if constexpr (POL) {
+    // the driver's reward shaping (main_test.py:171, 178, 194-206; diral_driver_shape without the information-age
+    // terms) of this env: wave 1, lane = vehicle, from the rewards P2 left in LDS - np.sum in NumPy's order
+    if (wave == 1) {
+      const LatePolArgs lq = (LatePolArgs)(late_kernarg_base() + kPolArgOffset);
+      void* const shaped_out = lq->shaped_out;
+      if (shaped_out) {
+        const int sflags = lq->shape_flags;
+        const out_t a = live ? (out_t)s_rew[lane] : (out_t)0;
+        const out_t sr = np_row_sum_wave(a, N, lane);
+        if (lane == 0) {
+          void* const so = lq->sum_r_out;
+          void* const co = lq->coll_out;
+          if (so) static_cast<out_t*>(so)[b] = sr;
+          if (co) static_cast<out_t*>(co)[b] = (out_t)A - sr;
+        }
+        if (live) {
+          out_t rr = a;
+          if (sflags & 4) {
+            int32_t* const pc = lq->pen_counter;
+            int32_t* const pp = lq->pen_prev;
+            const int ac = s_act[lane];
+            const bool stuck = (rr < (out_t)1) && (ac == pp[bN + lane]);
+            const int c = stuck ? pc[bN + lane] + 1 : 0;
+            pc[bN + lane] = c;
+            if (c > lq->pen_threshold) rr = (out_t)lq->pen_value;
+            pp[bN + lane] = ac;
+          }
+          if (sflags & 1) rr = rr + sr / (out_t)N;
+          static_cast<out_t*>(shaped_out)[bN + lane] = rr;
+        }
+      }
     }
   }
 

@@ -57,7 +57,7 @@ def shape_rewards(env: VecV2VEnv, reward: torch.Tensor, actions: torch.Tensor, o
 
 class GraphRollout:
     def __init__(self, env: VecV2VEnv, policy: SpsPolicy, K: int, global_reward_avg: bool = True, enable_channel: bool = False,
-                 clock: Optional[SlotClock] = None, capture: bool = True):
+                 clock: Optional[SlotClock] = None, capture: bool = True, fused: bool = False):
         cfg = env.cfg
         if cfg.mobility_vary or cfg.enable_fingerprint:
             raise ValueError("GraphRollout: configs whose episode ends act on the env from the host (mobility_vary, "
@@ -65,6 +65,7 @@ class GraphRollout:
         if K < 1 or K % env.io_ring or K % 2:
             raise ValueError("K must be a positive multiple of 2 and of the env's io_ring (%d)" % env.io_ring)
         self.env, self.pol, self.K = env, policy, int(K)
+        self.fused = bool(fused)       # the slot as ONE launch (diral_env_step_policy) instead of three
         self.global_reward_avg = bool(global_reward_avg)
         self.mode = STEP_MY_STEP_CH if enable_channel else STEP_MY_STEP
         dev = env.device
@@ -102,8 +103,12 @@ class GraphRollout:
     def _one_slot(self, k: int) -> None:
         env, pol = self.env, self.pol
         a, a_next = self.actions[k & 1], self.actions[(k + 1) & 1]
-        env._step(self.mode, a, k, want_chobs=True)                      # slot number = clock + k, on the device
         i = k & 1
+        if self.fused:
+            env.step_policy(a, k, pol, a_next, shaped_out=self.shaped[i], sum_r_out=self.sum_r[i], collision_out=self.coll[i],
+                            global_reward_avg=self.global_reward_avg, clock=self.clock, seed_offset=k, mode=self.mode)
+            return
+        env._step(self.mode, a, k, want_chobs=True)                      # slot number = clock + k, on the device
         shape_rewards(env, env._rew, a, self.shaped[i], self.sum_r[i], self.coll[i], self.global_reward_avg)
         pol.step_from_chobs_clocked(env._chobs, a, self.clock, k, out=a_next)
 

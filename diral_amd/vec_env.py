@@ -299,6 +299,50 @@ class VecV2VEnv:
         self._ok(st, "diral_env_step")
         return self._obs, self._rew, self._done
 
+    def step_policy(self, actions: torch.Tensor, t: int, policy, actions_out: torch.Tensor, shaped_out=None, sum_r_out=None,
+                    collision_out=None, global_reward_avg: bool = True, want_chobs: bool = False, clock=None,
+                    seed_offset: Optional[int] = None, mode: Optional[int] = None):
+        """One slot of a policy-only rollout as ONE launch (`diral_env_step_policy`): env step (state, reward, done,
+        optionally the channel observation) + the driver's reward shaping (main_test.py:171-206 without the
+        information-age terms) + the SPS agents' decisions for the next slot (algorithms/v2x_sps.py:76-104), the
+        channel observation handed over in LDS.  `policy`: a diral_amd.sps.SpsPolicy (its prev_action / counter are
+        updated in place); `actions_out` [B, N] int32: the next slot's actions.  Same results, bit for bit, as
+        `_step(want_chobs=True)` + `diral_driver_shape` + `SpsPolicy.step_from_chobs[_clocked]`; configurations the
+        fused kernel does not take run exactly those three launches (then the channel observation is materialised
+        whatever `want_chobs` says).  `clock`: a rollout.SlotClock / int64 device tensor added to the policy's seed
+        (`step_from_chobs_clocked` semantics, `seed_offset` as its `offset`); without it the policy's own step counter
+        advances as in `step_from_chobs`."""
+        from .config import DiralSlotPolicy
+        if self.io_ring > 1:
+            self._ri = (self._ri + 1) % self.io_ring
+        slot = self._ring[self._ri]
+        fusable = (self.N <= 64 and self.N >= 8 and self.A <= 64)
+        if (want_chobs or not fusable) and slot["chobs"] is None:
+            slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+        self._obs, self._rew, self._done, self._chobs = slot["obs"], slot["rew"], slot["done"], slot["chobs"]
+        self._spec = None
+        q = DiralSlotPolicy()
+        q.struct_bytes = ctypes.sizeof(DiralSlotPolicy)
+        q.shape_flags = 1 if global_reward_avg else 0
+        q.shaped_out = _ptr(shaped_out); q.sum_r_out = _ptr(sum_r_out); q.collision_out = _ptr(collision_out)
+        q.sps_prev_action = _ptr(policy.prev_action); q.sps_counter = _ptr(policy.counter)
+        q.rssi_threshold, q.inc_db, q.keep_prob = policy.threshold, policy.inc_db, policy.keep_prob
+        if clock is not None:
+            ct = clock.t if hasattr(clock, "t") else clock
+            q.seed = (int(policy.seed) * 1000003 + int(seed_offset or 0)) & (2**64 - 1)
+            q.seed_clock = _ptr(ct)
+        else:
+            policy._t += 1
+            q.seed = (int(policy.seed) * 1000003 + policy._t) & (2**64 - 1)
+        q.actions_out = _ptr(actions_out)
+        use_chobs = self._chobs if (want_chobs or not fusable) else None
+        st = self.lib.diral_env_step_policy(self._h, self.step_mode if mode is None else mode, _ptr(actions), int(t),
+                                            _ptr(self._obs) if self.S > 0 else None, _ptr(self._rew), _ptr(self._done),
+                                            _ptr(use_chobs), self._dt, ctypes.byref(q), self._stream())
+        self._ok(st, "diral_env_step_policy")
+        self._keep_policy = (q, actions, actions_out, shaped_out, sum_r_out, collision_out, clock)
+        return self._obs, self._rew, self._done
+
     def step(self, actions, t: Optional[int] = None, episode: float = 0.0, epsilon: float = 1.0
              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """``step(actions[B,N]) -> (obs[B,N,S], reward[B,N], done[B])``.

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 3
+#define DIRAL_ABI_VERSION 4
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -194,8 +194,9 @@ enum {
   DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
   DIRAL_KERNEL_CH      = 64,  /* my_step_ch */
   DIRAL_KERNEL_RING    = 128, /* the xpos ring (the per-entry xpos plane only for old entries) */
-  DIRAL_KERNEL_PACKED  = 256  /* the packed table form: thermometer codes + ages + own sequence numbers (N <= 64 always;
+  DIRAL_KERNEL_PACKED  = 256, /* the packed table form: thermometer codes + ages + own sequence numbers (N <= 64 always;
                                  128 < N <= 256 on dense topologies), else the (seq, age) plane */
+  DIRAL_KERNEL_POLICY  = 512  /* diral_env_step_policy ran as ONE launch (reward shaping + SPS decision in the step) */
 };
 int diral_env_last_kernel(const DiralEnv* env);
 
@@ -371,6 +372,43 @@ int diral_sps_step_chobs(int agents, int num_channels, const void* chobs, int ch
                          double rssi_threshold, double inc_db, double keep_prob,
                          const int32_t* draw_counter, const double* draw_keep,
                          const int32_t* draw_choice, uint64_t seed, int32_t* actions_out, void* stream);
+
+/* ---- the closed loop of a policy-only rollout as ONE launch per slot -----------------------------
+ * The reference's slot is env step -> reward shaping -> policy (main_test.py:127-206 with algorithms/v2x_sps.py as the
+ * policy); diral_env_step + diral_driver_shape + diral_sps_step_chobs are three dependent launches and the channel
+ * observation travels through HBM between the first and the third.  diral_env_step_policy runs the same slot as one
+ * launch where the configuration allows (N <= 64 on the one-lane highway, my_step, none of the run-time extras: the
+ * channel observation is staged in LDS by the step and the agents decide from there), and as the three launches
+ * otherwise (then `chobs_out` must be given) - same results either way, bit for bit:
+ *   shaped_out / sum_r_out / collision_out, pen_*: diral_driver_shape without the information-age terms
+ *     (shape_flags: bit 0 global_reward_avg, bit 2 stuck-action penalty); shaped_out NULL = no shaping;
+ *   sps_*, draws, seed: diral_sps_step_chobs (seed_clock != NULL: diral_sps_step_chobs_clocked, injected draws ignored
+ *     there too); actions_out [B][N]: the actions of the NEXT slot.
+ * `chobs_out` may be NULL when the slot runs fused: the observation then never leaves the chip. */
+typedef struct DiralSlotPolicy {
+  uint32_t struct_bytes;          /* = sizeof(DiralSlotPolicy) */
+  int32_t  shape_flags;
+  int32_t  pen_threshold;
+  int32_t  reserved0;
+  double   pen_value;
+  void*    shaped_out;            /* [B][N] out dtype or NULL */
+  void*    sum_r_out;             /* [B] or NULL */
+  void*    collision_out;         /* [B] or NULL */
+  int32_t* pen_counter;           /* [B][N] (shape_flags bit 2) */
+  int32_t* pen_prev_actions;      /* [B][N] */
+  int32_t* sps_prev_action;       /* [B][N] */
+  int32_t* sps_counter;           /* [B][N] */
+  double   rssi_threshold, inc_db, keep_prob;
+  const int32_t* draw_counter;    /* [B][N] or NULL */
+  const double*  draw_keep;
+  const int32_t* draw_choice;
+  uint64_t seed;
+  const int64_t* seed_clock;      /* NULL, or a device counter added to the seed */
+  int32_t* actions_out;           /* [B][N] */
+} DiralSlotPolicy;
+int diral_env_step_policy(DiralEnv* env, int mode, const int32_t* actions, int64_t t, void* state_out, void* rew_out,
+                          uint8_t* done_out, void* chobs_out, int out_dtype, const DiralSlotPolicy* policy,
+                          void* stream);
 
 /* ---- slot clock: rollouts captured into a hipGraph ---------------------------------------------
  * A captured sequence of K slots (env step, reward shaping, policy) bakes every by-value argument into its

@@ -1579,3 +1579,100 @@ def test_graph_rollout_equals_eager(N, A, B, ch):
     for e, _, r in runs:
         e.check()
         r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,A,B,dt,fused_expected", [
+    (64, 32, 96, torch.float32, True),       # the metric's shape: ONE launch per slot
+    (64, 32, 33, torch.float64, True),
+    (40, 20, 50, torch.float32, True),       # padded lanes, A not a multiple of 32
+    (9, 5, 40, torch.float32, True),         # np.sum's eight accumulators + a sequential tail of one
+    (6, 4, 40, torch.float32, False),        # N < 8: np.sum is sequential - the three launches
+    (96, 48, 12, torch.float32, False),      # N > 64: step_wide + the two policy launches
+])
+def test_fused_policy_slot_equals_three_launches(N, A, B, dt, fused_expected):
+    """diral_env_step_policy (env step + reward shaping + SPS decision as ONE launch, the channel observation handed
+    over in LDS) against the same closed loop as three launches (diral_env_step with the channel observation,
+    diral_driver_shape, diral_sps_step_chobs_clocked): 120 slots each, every per-slot output compared bit for bit -
+    state, raw and shaped rewards, sum / collision columns, done, the next actions - and at the end the env (tables,
+    positions), the policy state and the metrics."""
+    from diral_amd.config import KERNEL_POLICY
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2)
+    runs = []
+    for fused in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=dt, io_ring=2)
+        env.reset_topology(seed=11)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=4)
+        ro = GraphRollout(env, pol, K=2, capture=False, fused=fused)
+        runs.append((env, pol, ro))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    for step in range(60):
+        r1.run(1)
+        r2.run(1)
+        assert bool(e1.last_kernel() & KERNEL_POLICY) == fused_expected
+        assert not (e2.last_kernel() & KERNEL_POLICY)
+        for x, y in zip(r1.last(), r2.last()):
+            assert torch.equal(x, y), step
+        assert torch.equal(e1._rew, e2._rew) and torch.equal(e1._done, e2._done), step
+        for i in (0, 1):
+            assert torch.equal(r1.shaped[i], r2.shaped[i]) and torch.equal(r1.sum_r[i], r2.sum_r[i]), step
+            assert torch.equal(r1.coll[i], r2.coll[i]) and torch.equal(r1.actions[i], r2.actions[i]), step
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    m1, m2 = e1.metrics(), e2.metrics()
+    assert torch.equal(m1, m2)
+    for e, _, r in runs:
+        e.check()
+        r.close()
+
+
+@pytest.mark.gpu
+def test_fused_policy_slot_with_the_observation_written_and_captured():
+    """The fused slot also writes the channel observation when asked to (equal to the three-launch one), and a K-slot
+    hipGraph of fused slots replays like the eager loop."""
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = c2_config()
+    B, N, A = 64, cfg.num_users, cfg.num_channels
+    # (a) chobs_out given
+    e1 = VecV2VEnv(cfg, batch=B, device="cuda:0")
+    e2 = VecV2VEnv(cfg, batch=B, device="cuda:0")
+    p1, p2 = SpsPolicy(B, N, A, seed=9), SpsPolicy(B, N, A, seed=9)
+    for e in (e1, e2):
+        e.reset_topology(seed=2)
+    a1, a2 = p1.prev_action.clone(), p2.prev_action.clone()
+    n1, n2 = torch.empty_like(a1), torch.empty_like(a2)
+    sh1 = torch.empty((B, N), dtype=torch.float32, device="cuda:0")
+    for t in range(30):
+        e1.step_policy(a1, t, p1, n1, shaped_out=sh1, want_chobs=True)
+        e2._step(0, a2, t, want_chobs=True)
+        p2.step_from_chobs(e2._chobs, a2, out=n2)
+        assert torch.equal(e1._chobs, e2._chobs) and torch.equal(n1, n2) and torch.equal(e1._obs, e2._obs), t
+        a1, n1 = n1, a1
+        a2, n2 = n2, a2
+    # (b) captured
+    runs = []
+    for capture in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", io_ring=2)
+        env.reset_topology(seed=5)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=3)
+        ro = GraphRollout(env, pol, K=10, capture=capture, fused=True)
+        ro.run(6 if capture else 7)
+        torch.cuda.synchronize()
+        runs.append((env, pol, ro))
+    (g1, q1, r1), (g2, q2, r2) = runs
+    sa, sb = g1.export_state(), g2.export_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(q1.prev_action, q2.prev_action) and torch.equal(q1.counter, q2.counter)
+    for x, y in zip(r1.last(), r2.last()):
+        assert torch.equal(x, y)
+    for e, _, r in runs:
+        e.check()
+        r.close()
