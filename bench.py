@@ -196,6 +196,14 @@ def load_pmc(workload: str):
     return None
 
 
+def csrc_digest() -> str:
+    """Digest of the kernel sources the library is built from (diral_amd/csrc, include/diral_env.h): stamped into every
+    profile summary (profiles/run_profile.sh) and into profiles/pmc_counters.json, so that a bench line can say whether
+    the committed counters describe the kernels it ran (`roofline.pmc_current`) - the GPU boxes have no .git."""
+    from diral_amd.build import source_digest
+    return source_digest()
+
+
 def roofline_object(res, pmc):
     """The `roofline` object of a measurement: what bounds the kernel and how far it is from it.
 
@@ -230,11 +238,16 @@ def roofline_object(res, pmc):
         "kernel_ms": res["kernel_ms"],
         "traffic": traffic,
         "counter_frac": counter_frac,
+        "valu_frac": pmc.get("valu_busy") if pmc else None,      # the fraction of the pipe that bounds the kernel (= valu_busy)
         "valu_busy": pmc.get("valu_busy") if pmc else None,
         "lds_busy": pmc.get("lds_busy") if pmc else None,
         "cu_busy": pmc.get("cu_busy") if pmc else None,
         "clock_GHz": pmc.get("clock_GHz") if pmc else None,
         "pmc_source": pmc.get("source") if pmc else None,
+        "pmc_commit": pmc.get("commit") if pmc else None,
+        "pmc_csrc_sha": pmc.get("csrc_sha") if pmc else None,
+        "csrc_sha": csrc_digest(),
+        "pmc_current": (pmc.get("csrc_sha") == csrc_digest()) if pmc and pmc.get("csrc_sha") else None,
         "pmc_note": "traffic / valu_busy / clock_GHz come from the committed rocprofv3 --pmc passes of this command "
                     "(separate runs; counter_frac uses the kernel time of those passes), not from this run" if pmc else None,
         "model_bytes_per_launch": res["algorithmic_bytes_per_launch"],
@@ -562,7 +575,11 @@ def streamed_c2_sets(device, groups, sets=4):
     best = min(runs, key=lambda r: r["ms_per_step"])
     best = dict(best)
     best["ms_per_step_by_stream_set"] = [r["ms_per_step"] for r in runs]
-    best["note"] = "fastest of %d stream sets (a set whose streams share a hardware queue serialises: runtime bookkeeping, DESIGN.md 3.6)" % sets
+    med = sorted(r["ms_per_step"] for r in runs)
+    best["ms_per_step_median_of_sets"] = 0.5 * (med[(len(med) - 1) // 2] + med[len(med) // 2])
+    best["agent_steps_per_s_median_of_sets"] = best["agent_steps_per_s"] * best["ms_per_step"] / best["ms_per_step_median_of_sets"]
+    best["note"] = ("fastest of %d stream sets, the median of the sets beside it (a set whose streams share a hardware queue "
+                    "serialises: runtime bookkeeping, DESIGN.md 3.6)" % sets)
     return best
 
 
@@ -722,6 +739,13 @@ def main() -> int:
                 del e2
                 also["c2_sticky_0.9"] = short(r2)
                 also["c2_sticky_0.9"]["emit_chobs"] = emit
+                if args.out_dtype == "f32":
+                    # float64 outputs: the reference's own array dtype (state, reward, channel observation bit for bit)
+                    e2, r2 = run_workload("c2", device, 0, 1, 300, 10, 0, "f64", args.step_mode, emit, args.sticky, False)
+                    del e2
+                    also["c2_f64"] = short(r2)
+                    also["c2_f64"]["emit_chobs"] = emit
+                    also["c2_f64"]["out_dtype"] = "f64"
                 also["c2_streams2"] = streamed_c2_sets(device, 2)
                 also["c2_streams4"] = streamed_c2_sets(device, 4)
                 torch.cuda.empty_cache()

@@ -24,6 +24,19 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 OBJDIR = os.path.join(HERE, "build")
 
 
+def source_digest() -> str:
+    """sha256[:16] over the kernel sources and the C-ABI header, in a fixed order: identifies WHICH kernels a
+    library / a profile / a bench line is about on boxes without a .git (profiles/run_profile.sh, bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(HERE, "..", "include", "diral_env.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc_path() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--slots", type=int, default=500)
     ap.add_argument("--policy", choices=["sps", "random"], default="sps")
     ap.add_argument("--fused", action="store_true", help="one launch per slot (random policy only: SPS needs chobs)")
+    ap.add_argument("--one-launch", action="store_true",
+                    help="SPS policy: the whole slot (env step + reward shaping + SPS decision) as ONE launch, "
+                         "diral_env_step_policy - the channel observation never leaves the chip")
     args = ap.parse_args()
     rank, local_rank, world = rank_world()
     torch.cuda.set_device(local_rank)
@@ -44,7 +47,15 @@ def main():
     actions = pol.prev_action.clone()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(args.slots):
+    if args.one_launch and args.policy == "sps":
+        acts = [actions, torch.empty_like(actions)]
+        shaped = torch.empty((env.B, env.N), dtype=torch.float32, device=env.device)
+        for t in range(args.slots):
+            state, _, _ = env.step_policy(acts[t & 1], t, pol, acts[(t + 1) & 1], shaped_out=shaped, global_reward_avg=True)
+            if t == args.slots // 2:
+                env.metrics(clear=True)
+        args.slots_done = True
+    for t in range(0 if not getattr(args, "slots_done", False) else args.slots, args.slots):
         out = loop.slot(actions, t)                   # one fused env launch + reward shaping
         state = out["next_state"]                     # what a learning agent would consume
         if args.policy == "sps":

@@ -21,6 +21,22 @@ import sys
 MAX_CLOCK_GHZ = 2.4
 
 
+def traffic_factors():
+    """bytes really moved / (counter x 1024) for the access forms of the step kernels, measured on known byte counts by
+    profiles/micro/traffic_calib.hip (profiles/calibrate_traffic.sh -> profiles/traffic_calibration.json): FETCH_SIZE
+    x 2.000 for one dword, 8 B and 16 B per lane alike and for the table's read-modify-write row pattern; WRITE_SIZE
+    x 1.000 (non-temporal 16 B stores: 0.994).  Falls back to the guide's (2, 1) when the file is missing."""
+    import os
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_calibration.json")) as fh:
+            forms = json.load(fh)["forms"]
+        f = forms["rw_dword_rows"]["FETCH_SIZE_factor"]
+        w = forms["rw_dword_rows"]["WRITE_SIZE_factor"]
+        return f, w, "profiles/traffic_calibration.json (rw_dword_rows: the table's access form; dword / 8 B / 16 B reads all x %.3f)" % f
+    except Exception:
+        return 2.0, 1.0, "MI355X_MICROARCH.md (FETCH_SIZE reports half of a coalesced read); no calibration file"
+
+
 def parse(path):
     txt = open(path).read()
     g = {}
@@ -37,13 +53,18 @@ def record(summary, head):
         return g[k][0] if k in g else None
     def ns(k):
         return dur.get(g[k][1]) if k in g else None
+    stamp = re.search(r"^CSRC_SHA (\w+)\s+COMMIT (\S+)", open(summary).read(), re.M)
+    csrc_sha, commit = (stamp.group(1), stamp.group(2)) if stamp else (None, head)
     out = {"source": "%s (rocprofv3 --pmc passes of `python bench.py --lean ...`, separate runs, mean over the last 40 launches "
-                     "after bench.py's pre-roll; kernels of commit %s)" % (summary, head),
+                     "after bench.py's pre-roll; kernel sources %s, commit %s)" % (summary, csrc_sha, commit),
+           "csrc_sha": csrc_sha, "commit": commit,
            "kernel_ms_profiled": steady / 1e6 if steady else None}
     f, w = val("FETCH_SIZE"), val("WRITE_SIZE")
     if f is not None and w is not None:
-        out.update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes_per_launch=(2 * f + w) * 1024.0,
-                   hbm_rule="(2*FETCH_SIZE + WRITE_SIZE)*1024; gfx950 FETCH_SIZE reports half of a coalesced read (MI355X_MICROARCH.md)")
+        ff, wf, src = traffic_factors()
+        out.update(FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w, hbm_bytes_per_launch=(ff * f + wf * w) * 1024.0,
+                   hbm_read_bytes_per_launch=ff * f * 1024.0, hbm_write_bytes_per_launch=wf * w * 1024.0,
+                   hbm_rule="(%.4f*FETCH_SIZE + %.4f*WRITE_SIZE)*1024; factors from %s" % (ff, wf, src))
         tns = [x for x in (ns("FETCH_SIZE"), ns("WRITE_SIZE")) if x]
         if tns:
             out["kernel_ms_traffic_passes"] = sum(tns) / len(tns) / 1e6

@@ -31,7 +31,8 @@ pmc pmc_fetch FETCH_SIZE
 pmc pmc_write WRITE_SIZE
 pmc pmc_grbm GRBM_GUI_ACTIVE
 cd $R
-LAST=40 python profiles/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+echo "CSRC_SHA $(python -c 'from diral_amd.build import source_digest; print(source_digest())')  COMMIT ${PMC_COMMIT:-unknown}" > $OUT/summary.txt
+LAST=40 python profiles/summarize_profile.py $OUT >> $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # the raw per-dispatch tables have done their job (summary.txt; trace/*kernel_stats.csv is kept): gpurun merges at most 64 MiB back
 [ "${KEEP_RAW:-0}" = 1 ] || find $OUT -name "*_kernel_trace.csv" -o -name "*_counter_collection.csv" | xargs rm -f

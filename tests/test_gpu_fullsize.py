@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 GLOBAL_SEED = 1234      # bench.py's
 
 
-def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None):
+def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32, env_offset=0):
     from diral_amd.vec_env import VecV2VEnv
     from oracle.oracle import Oracle, SQ_IEEE
     cfg = bench_config(N, A, L, mobility_vary=vary)
     K = cfg.State.num_bins
-    env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=dtype, env_offset=env_offset)
     env.reset_topology(seed=GLOBAL_SEED)                    # the device draws bench.py uses
     st0 = env.export_state(tables=False)
     rng = np.random.default_rng(N * 1000 + A)
@@ -45,7 +46,7 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None):
         cnt = torch.zeros((B, A), dtype=torch.long, device="cuda:0").scatter_add_(1, al, torch.ones_like(al))
         c = cnt.gather(1, al)
         assert torch.all(rew[c == 1] == 1)
-        assert torch.all(rew[c > 2] == -c[c > 2].float())
+        assert torch.all(rew[c > 2] == -c[c > 2].to(dtype))
         assert torch.all((rew[c == 2] == 0) | (rew[c == 2] == -2))
         # (4) channel observation: 0 on the own resource and on unused ones, else a distance < Rc or the 100000 sentinel
         own = torch.gather(chobs, 2, al.unsqueeze(-1))
@@ -60,9 +61,9 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None):
         acts_s = a_t[sample_t].cpu().numpy()
         o_rew, o_chobs = orc.step(STEP_MY_STEP, acts_s, t)
         o_state = orc.obtain_state(acts_s, o_chobs, o_rew)
-        assert np.array_equal(obs[sample_t].cpu().numpy(), o_state.astype(np.float32)), t
-        assert np.array_equal(rew[sample_t].cpu().numpy(), o_rew.astype(np.float32)), t
-        assert np.array_equal(chobs[sample_t].cpu().numpy(), o_chobs.astype(np.float32)), t
+        assert np.array_equal(obs[sample_t].cpu().numpy(), o_state.astype(npdt)), t
+        assert np.array_equal(rew[sample_t].cpu().numpy(), o_rew.astype(npdt)), t
+        assert np.array_equal(chobs[sample_t].cpu().numpy(), o_chobs.astype(npdt)), t
         if vel_slot is not None and t == vel_slot:
             draws = torch.randint(1, 4, (B, N), device="cuda:0", dtype=torch.uint8, generator=g)
             env.update_velocity(draws)
@@ -92,3 +93,42 @@ def test_c3_benchmarked_instantiation_full_size():
 def test_c5_benchmarked_instantiation_full_size():
     """configs[4]: 128 UE / 64 res, mobility_vary, B = 16384 - step_wide_kernel<2,...>; one update_velocity."""
     _run(128, 64, 4000.0, 16384, True, n_sample=10, T=32, fam=KERNEL_WIDE, vel_slot=24)
+
+
+def test_c4_shard_benchmarked_instantiation_full_size():
+    """configs[3]: one GPU's share of the 262144-env job, B = 32768 at the env offset of rank 5 - the RICH instantiation
+    `also_measured.c4shard` times (state + reward + channel observation in one launch), 24 envs sampled across the shard
+    against the oracle."""
+    _run(64, 32, 2000.0, 32768, False, n_sample=24, T=16, fam=KERNEL_FAST64, env_offset=5 * 32768)
+
+
+@pytest.mark.parametrize("N,A,L,B,vary,ns,T", [(64, 32, 2000.0, 4096, False, 16, 14), (256, 64, 4000.0, 8192, False, 4, 8),
+                                               (128, 64, 4000.0, 16384, True, 6, 10)])
+def test_float64_outputs_full_size(N, A, L, B, vary, ns, T):
+    """The float64-output instantiations (the reference's own array dtype, `also_measured.c2_f64`) at the bench's batch
+    sizes: state, reward and channel observation of the sampled envs equal the oracle's float64 values bit for bit."""
+    _run(N, A, L, B, vary, n_sample=ns, T=T, fam=KERNEL_FAST64 if N <= 64 else KERNEL_WIDE, dtype=torch.float64)
+
+
+def test_specialised_kernel_is_well_ahead_of_the_general_one_at_c2():
+    """A loose wall-clock check the driver's `-m gpu` run sees (the tight ones live under `-m perf`): at C2 shapes the
+    dispatch's kernel is at least 1.2 x as fast as the general kernel forced onto the same handle (measured: > 4 x)."""
+    import time
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = bench_config(64, 32, 2000.0)
+    times = {}
+    for general in (False, True):
+        env = VecV2VEnv(cfg, batch=2048, device="cuda:0", out_dtype=torch.float32)
+        env.reset_topology(seed=3)
+        env.force_general_kernel(general)
+        acts = [env.sample(seed=i) for i in range(4)]
+        for t in range(30):
+            env.step(acts[t % 4], t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(30, 110):
+            env.step(acts[t % 4], t)
+        torch.cuda.synchronize()
+        times[general] = time.perf_counter() - t0
+        env.check()
+    assert times[True] >= 1.2 * times[False], times
