@@ -358,16 +358,20 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     f.slow_cnt_r = nullptr; f.slow_list_r = nullptr; f.slow_flag_r = nullptr;
     f.slow_cnt_w = nullptr; f.slow_list_w = nullptr; f.slow_flag_w = nullptr; f.slow_cnt_z = nullptr;
     bool slow_first = false;
-    if (use_fast64 && e->slow && e->slow_first && !stream_is_capturing(s)) {
-      // (a captured launch keeps dispatch order and leaves the sets alone: a replayed graph would not rotate them)
+    if (use_fast64 && e->slow && e->slow_first) {
       const size_t w = slow_set_words(e);
       uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
       uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
       uint32_t* const set_z = e->slow + ((e->slow_launches + 2) % 3) * w;
       f.slow_cnt_r = set_r; f.slow_list_r = set_r + 16; f.slow_flag_r = set_r + 16 + fast_slow_max(e->B);
-      f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + fast_slow_max(e->B);
-      f.slow_cnt_z = set_z;
-      ++e->slow_launches;
+      if (!stream_is_capturing(s)) {
+        f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + fast_slow_max(e->B);
+        f.slow_cnt_z = set_z;
+        ++e->slow_launches;
+      }
+      // (a CAPTURED launch reads the set the last eager launch left - complete, never written by a replay - and builds
+      // none: a replayed graph could not rotate the sets.  The list ages with the replays - slow envs stay slow for
+      // hundreds of slots, profiles/launch_timeline.py - but stays a partition: every env runs exactly once.)
       slow_first = true;
     }
     RichParams r = rich_for(e, p);

@@ -381,7 +381,7 @@ __device__ DIRAL_OUTLINE void fast_sps_decide(const T* stage, int SA, int A, int
 }
 
 #ifdef DIRAL_TIMING
-#define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg) { p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+#define DIRAL_FSTAMP(i) do { if (lane == 0 && p.dbg && !listed) { p.dbg[((size_t)b * 4 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     if ((i) == 7) { __builtin_amdgcn_s_waitcnt(0); atomicMax(&p.dbg[(size_t)p.B * 40 + (((size_t)(p.t & 1) * gridDim.x + b) * 2) + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } } while (0)
 #else
 #define DIRAL_FSTAMP(i) do {} while (0)
