@@ -144,7 +144,7 @@ class StateConfig:
     add_index: bool = False
     add_velocity: bool = False
     action_index: str = "binary"        # "binary" | "real"  (test_env.py:32)
-    piggybacking: bool = False          # must stay False
+    piggybacking: bool = False          # must stay False (permanent divergence)
     add_position: bool = False
     add_positional_dist: bool = False
     add_positional_dist_piggy: bool = False
@@ -282,8 +282,10 @@ class EnvConfig:
         if self.num_users < 1 or self.num_channels < 1:
             raise ConfigError("num_users and num_channels must be >= 1")
         if st.piggybacking:
-            raise ConfigError("State.piggybacking=True (obs-insertion mode, "
-                              "test_env.py:71-79,241-254) is out of scope")
+            raise ConfigError("State.piggybacking=True (obs-insertion mode, test_env.py:71-79, 241-254) is a permanent "
+                              "divergence of this build: the reference's own branch builds observation vectors whose "
+                              "length depends on the slot's traffic and indexes prev_obs[None] when no transmitter is in "
+                              "range (DESIGN.md 6)")
         if st.action_index not in ("binary", "real"):
             raise ConfigError("action_index must be 'binary' or 'real' (test_env.py:50-55)")
         if st.type not in (1, 2):

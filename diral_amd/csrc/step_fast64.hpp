@@ -110,8 +110,11 @@ struct FastParams {
   uint32_t* slow_flag_w;
   uint32_t* slow_cnt_z;           // the count the launch after the next will build on: zeroed here
 };
-// listed envs per launch (an env beyond that keeps its place in dispatch order): an eighth of the batch, 16 ... 2048
-__host__ __device__ inline int fast_slow_max(int B) { const int m = B >> 3; return m < 16 ? 16 : (m > 2048 ? 2048 : m); }
+// listed envs per launch (an env beyond that keeps its place in dispatch order): a quarter of the batch, 16 ... 4096
+#ifndef DIRAL_SLOW_SHIFT
+#define DIRAL_SLOW_SHIFT 2             // a quarter of the batch (an eighth: sticky policies overflow the list, c2_sticky_0.9 58 -> 52 us; half: no better)
+#endif
+__host__ __device__ inline int fast_slow_max(int B) { const int m = B >> DIRAL_SLOW_SHIFT; return m < 16 ? 16 : (m > 4096 ? 4096 : m); }
 
 // Late-bound kernel arguments.  The compiler hoists the scalar loads of EVERY by-value kernel
 // argument to the kernel entry and then keeps (or spills, through v_writelane / v_readlane - VALU

@@ -47,16 +47,36 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, env=None, port: Op
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on these hosts (RCCL across processes)
     e.setdefault("OMP_NUM_THREADS", "1")
     cmd = torchrun_command(script, argv, nproc, port)
-    proc = subprocess.Popen(cmd, env=e, stdout=stdout, stderr=stderr)
+    # a session of its own: the launcher AND its rank processes form one process group that a timeout can take down as
+    # a whole (the elastic agent cannot tear its workers down when it is SIGKILLed itself - they would keep the GPUs
+    # and the rendezvous port)
+    proc = subprocess.Popen(cmd, env=e, stdout=stdout, stderr=stderr, start_new_session=True)
+
+    def stop(first_signal):
+        import signal
+        try:
+            os.killpg(proc.pid, first_signal)              # the launcher forwards it and joins its workers
+        except ProcessLookupError:
+            return
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)            # whoever is left of the group
+        except ProcessLookupError:
+            pass
+        proc.wait()
+
     try:
         return int(proc.wait(timeout=timeout))
     except subprocess.TimeoutExpired:
-        proc.kill()
-        proc.wait()
+        import signal
+        stop(signal.SIGTERM)
         return 124
     except KeyboardInterrupt:
-        proc.terminate()
-        proc.wait()
+        import signal
+        stop(signal.SIGINT)
         raise
 
 

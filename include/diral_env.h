@@ -117,7 +117,10 @@ typedef enum DiralStepMode {
  * The arithmetic is always float64, like the reference; F32 is a final cast. */
 typedef enum DiralDType { DIRAL_F32 = 0, DIRAL_F64 = 1 } DiralDType;
 
-/* limits of this build */
+/* limits of this build.  Beyond num_users = 256 diral_env_create returns DIRAL_ERR_UNSUPPORTED.  The specialised
+ * kernels (csrc/step_fast64.hpp, step_wide.hpp: every number bench.py reports) serve num_channels <= 64; a config
+ * with 64 < num_channels <= 256 is stepped by the general kernel (csrc/step_kernel.hpp: same results, bit for bit,
+ * 2.5-4 x the time - diral_env_last_kernel() says which one ran). */
 #define DIRAL_MAX_USERS    256
 #define DIRAL_MAX_CHANNELS 256
 #define DIRAL_MAX_BINS     64

@@ -32,7 +32,9 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names, "diral_amd/_lib.py and include/diral_env.h disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.diral_env_abi_version() == 3
+    from diral_amd.config import ABI_VERSION
+    src = open(os.path.join(ROOT, "include", "diral_env.h")).read()
+    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 4
 
 
 def test_cfg_struct_layout_matches_header():
@@ -44,6 +46,29 @@ def test_cfg_struct_layout_matches_header():
     assert (c.num_users, c.num_channels, c.reward_design) == (3, 3, 1)
     assert (c.highway_length, c.communication_range, c.bin_range) == (200.0, 1.0, 500.0)
     assert c.info_age_limit == 20 and c.episode_interval == 25 and c.pf_threshold == 10 and c.pf_penalty == -10.0
+
+
+def test_slot_policy_struct_layout_and_argument_checks():
+    """`DiralSlotPolicy` (diral_env_step_policy): the ctypes image has the header's size (a gcc-compiled probe of the
+    header), and the entry point rejects null handles / wrong struct sizes without touching a device."""
+    import subprocess
+    import tempfile
+    from diral_amd.config import DiralSlotPolicy
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "p.c")
+        with open(c, "w") as fh:
+            fh.write('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu %%zu\\n", '
+                     'sizeof(DiralSlotPolicy), offsetof(DiralSlotPolicy, shaped_out), offsetof(DiralSlotPolicy, rssi_threshold), '
+                     'offsetof(DiralSlotPolicy, actions_out)); return 0; }\n' % os.path.join(ROOT, "include", "diral_env.h"))
+        exe = os.path.join(d, "p")
+        subprocess.check_call(["gcc", c, "-o", exe])
+        size, o1, o2, o3 = (int(x) for x in subprocess.check_output([exe]).split())
+    assert size == ctypes.sizeof(DiralSlotPolicy)
+    assert (o1, o2, o3) == (DiralSlotPolicy.shaped_out.offset, DiralSlotPolicy.rssi_threshold.offset, DiralSlotPolicy.actions_out.offset)
+    lib = _lib.load()
+    q = DiralSlotPolicy()
+    q.struct_bytes = ctypes.sizeof(DiralSlotPolicy)
+    assert lib.diral_env_step_policy(None, 0, None, 0, None, None, None, None, 0, ctypes.byref(q), None) == -1
 
 
 def test_host_validation_and_state_space():
