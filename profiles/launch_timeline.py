@@ -22,6 +22,11 @@ B = int(os.environ.get("B", 4096))
 env = VecV2VEnv(c2_config(), batch=B, out_dtype=torch.float32)
 env.reset_topology(seed=1)
 acts = [env.sample(seed=i) for i in range(64)]
+STICKY = float(os.environ.get("STICKY", "0"))            # probability an agent keeps its resource (converged policy)
+if STICKY > 0:
+    for i in range(1, 64):
+        keep = torch.rand(acts[i].shape, device=acts[i].device) < STICKY
+        acts[i] = torch.where(keep, acts[i - 1], acts[i])
 for t in range(64):
     env._step(0, acts[t], t, want_chobs=True)
 torch.cuda.synchronize()
