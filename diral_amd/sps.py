@@ -110,30 +110,26 @@ class SpsPolicy:
         self._keep = (c, a, dc, dk, dch)
         return out
 
-
-def _clocked(self, chobs: torch.Tensor, actions: torch.Tensor, clock, offset: int = 0,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`step_from_chobs` with device draws seeded by (seed, offset) + the value of a device slot counter
-    (`diral_sps_step_chobs_clocked`): the by-value arguments of a captured launch stay fixed while the draws move on
-    with the counter (diral_amd/rollout.py).  `clock`: a rollout.SlotClock or an int64 device tensor."""
-    if chobs.dtype not in (torch.float32, torch.float64) or tuple(chobs.shape) != (self.B, self.N, self.A):
-        raise ValueError("chobs must be float32/float64 [B, N, A]")
-    c = chobs.contiguous()
-    a = actions.to(device=self.device, dtype=torch.int32).contiguous()
-    if out is None:
-        out = torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
-    ct = clock.t if hasattr(clock, "t") else clock
-    st = self.lib.diral_sps_step_chobs_clocked(self.B * self.N, self.A, _ptr(c), 1 if c.dtype == torch.float64 else 0, _ptr(a),
-                                               _ptr(self.prev_action), _ptr(self.counter), self.threshold, self.inc_db,
-                                               self.keep_prob, (int(self.seed) * 1000003 + int(offset)) & (2**64 - 1),
-                                               _ptr(ct), _ptr(out), self._stream())
-    if st != 0:
-        raise DiralError(st, "diral_sps_step_chobs_clocked")
-    self._keep = (c, a, ct)
-    return out
-
-
-SpsPolicy.step_from_chobs_clocked = _clocked
+    def step_from_chobs_clocked(self, chobs: torch.Tensor, actions: torch.Tensor, clock, offset: int = 0,
+                                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`step_from_chobs` with device draws seeded by (seed, offset) + the value of a device slot counter
+        (`diral_sps_step_chobs_clocked`): the by-value arguments of a captured launch stay fixed while the draws move on
+        with the counter (diral_amd/rollout.py).  `clock`: a rollout.SlotClock or an int64 device tensor."""
+        if chobs.dtype not in (torch.float32, torch.float64) or tuple(chobs.shape) != (self.B, self.N, self.A):
+            raise ValueError("chobs must be float32/float64 [B, N, A]")
+        c = chobs.contiguous()
+        a = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
+        ct = clock.t if hasattr(clock, "t") else clock
+        st = self.lib.diral_sps_step_chobs_clocked(self.B * self.N, self.A, _ptr(c), 1 if c.dtype == torch.float64 else 0, _ptr(a),
+                                                   _ptr(self.prev_action), _ptr(self.counter), self.threshold, self.inc_db,
+                                                   self.keep_prob, (int(self.seed) * 1000003 + int(offset)) & (2**64 - 1),
+                                                   _ptr(ct), _ptr(out), self._stream())
+        if st != 0:
+            raise DiralError(st, "diral_sps_step_chobs_clocked")
+        self._keep = (c, a, ct)
+        return out
 
 
 def rssi_from_channel_obs(chobs: torch.Tensor, actions: torch.Tensor) -> torch.Tensor:
