@@ -310,6 +310,18 @@ hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
   return hipMemsetAsync(e->slow, 0, 3 * slow_set_words(e) * 4, s);
 }
 
+// Will this step run on the POL instantiation of step_fast64 (the policy epilogue inside the launch)?  The conditions of
+// launch_step_any below, evaluated up front: diral_env_step_policy must know BEFORE it launches anything whether it needs
+// the caller's channel-observation buffer for the three-launch form.
+bool policy_fusable(const DiralEnv* e, const StepParams& p) {
+  const bool spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
+  if (!(spec && e->vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && e->flat_y && p.N >= 8)) return false;
+  if (p.mode != DIRAL_STEP_MY_STEP) return false;                       // (my_step_ch: CH instantiation; design: EXTRA)
+  const bool extra = ((p.flags & DIRAL_F_TRACK_ARRIVAL) && p.la) || ((p.flags & DIRAL_F_MOBILITY) && p.trace) ||
+                     (p.flags & DIRAL_F_TRACK_PRR) || !(p.flags & DIRAL_F_ADD_POSDIST_PIGGY) || !(p.flags & DIRAL_F_MOBILITY);
+  return !extra;
+}
+
 // `pol` / `fused`: diral_env_step_policy - when the configuration runs on the POL instantiation of step_fast64 the policy
 // epilogue is part of this launch and *fused is set; otherwise the plain step is launched and the caller adds the two
 // policy launches
@@ -795,12 +807,15 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   q.threshold = pol->rssi_threshold; q.inc_db = pol->inc_db; q.keep_prob = pol->keep_prob;
   q.draw_counter = pol->draw_counter; q.draw_keep = pol->draw_keep; q.draw_choice = pol->draw_choice;
   q.seed = pol->seed; q.clock = (const long long*)pol->seed_clock; q.actions_out = pol->actions_out;
+  // (decided before anything is launched: a caller without a channel-observation buffer can retry with one)
+  const bool will_fuse = policy_fusable(e, p);
+  if (!will_fuse && !chobs_out) return DIRAL_ERR_UNSUPPORTED;
   bool fused = false;
-  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, &q, &fused));
+  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, will_fuse ? &q : nullptr, &fused));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   if (fused) return DIRAL_OK;
   // the same slot as three launches (configurations the POL instantiation does not take)
-  if (!chobs_out) return DIRAL_ERR_UNSUPPORTED;
+  if (!chobs_out) return DIRAL_ERR_HIP;                                      // (cannot happen: policy_fusable mirrors the dispatch)
   if (pol->shaped_out) {
     const int st = diral_driver_shape(e->B, e->N, e->A, rew_out, out_dtype, actions, nullptr, nullptr, pol->pen_counter,
                                       pol->pen_prev_actions, pol->shape_flags, pol->pen_threshold, pol->pen_value,

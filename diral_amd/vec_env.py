@@ -316,7 +316,10 @@ class VecV2VEnv:
         if self.io_ring > 1:
             self._ri = (self._ri + 1) % self.io_ring
         slot = self._ring[self._ri]
-        fusable = (self.N <= 64 and self.N >= 8 and self.A <= 64)
+        # (whether the slot runs fused is the library's decision - kernel family, step mode, run-time extras; a call
+        # without a channel-observation buffer that cannot run fused comes back DIRAL_ERR_UNSUPPORTED before anything
+        # is launched, and is repeated with the buffer from then on)
+        fusable = (self.N <= 64 and self.N >= 8 and self.A <= 64) and not getattr(self, "_policy_needs_chobs", False)
         if (want_chobs or not fusable) and slot["chobs"] is None:
             slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
         self._obs, self._rew, self._done, self._chobs = slot["obs"], slot["rew"], slot["done"], slot["chobs"]
@@ -336,9 +339,18 @@ class VecV2VEnv:
             q.seed = (int(policy.seed) * 1000003 + policy._t) & (2**64 - 1)
         q.actions_out = _ptr(actions_out)
         use_chobs = self._chobs if (want_chobs or not fusable) else None
-        st = self.lib.diral_env_step_policy(self._h, self.step_mode if mode is None else mode, _ptr(actions), int(t),
-                                            _ptr(self._obs) if self.S > 0 else None, _ptr(self._rew), _ptr(self._done),
-                                            _ptr(use_chobs), self._dt, ctypes.byref(q), self._stream())
+
+        def call(chobs):
+            return self.lib.diral_env_step_policy(self._h, self.step_mode if mode is None else mode, _ptr(actions), int(t),
+                                                  _ptr(self._obs) if self.S > 0 else None, _ptr(self._rew), _ptr(self._done),
+                                                  _ptr(chobs), self._dt, ctypes.byref(q), self._stream())
+        st = call(use_chobs)
+        if st == -3 and use_chobs is None:               # DIRAL_ERR_UNSUPPORTED: not a fused configuration, nothing launched
+            self._policy_needs_chobs = True
+            if slot["chobs"] is None:
+                slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+            self._chobs = slot["chobs"]
+            st = call(self._chobs)
         self._ok(st, "diral_env_step_policy")
         self._keep_policy = (q, actions, actions_out, shaped_out, sum_r_out, collision_out, clock)
         return self._obs, self._rew, self._done

@@ -1632,6 +1632,40 @@ def test_fused_policy_slot_equals_three_launches(N, A, B, dt, fused_expected):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,ch", [(dict(track_arrival=True), False), (dict(), True), (dict(track_prr=True), False)])
+def test_policy_slot_falls_back_to_three_launches_outside_the_fused_instantiation(kw, ch):
+    """`step_policy` on configurations the POL instantiation does not take (arrival stamps, my_step_ch, PRR metrics): the
+    library says so before it launches anything, the call is repeated with a channel-observation buffer, and the slot
+    equals the explicit three launches."""
+    from diral_amd.config import KERNEL_POLICY
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = bench_config(64, 32, 2000.0, reward_design=2, **kw)
+    B, N, A = 24, 64, 32
+    runs = []
+    for fused in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", io_ring=2)
+        env.reset_topology(seed=8)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=6)
+        runs.append((env, pol, GraphRollout(env, pol, K=2, capture=False, fused=fused, enable_channel=ch)))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    for step in range(25):
+        r1.run(1)
+        r2.run(1)
+        assert not (e1.last_kernel() & KERNEL_POLICY)
+        for x, y in zip(r1.last(), r2.last()):
+            assert torch.equal(x, y), step
+        assert torch.equal(e1._rew, e2._rew) and torch.equal(e1._chobs, e2._chobs)
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for e, _, r in runs:
+        e.check()
+        r.close()
+
+
 def test_fused_policy_slot_with_the_observation_written_and_captured():
     """The fused slot also writes the channel observation when asked to (equal to the three-launch one), and a K-slot
     hipGraph of fused slots replays like the eager loop."""
