@@ -38,7 +38,9 @@ rt = full[B * 40:B * 44].astype(np.float64).reshape(2, B, 2) * 10e-3     # us; s
 prev, last = rt[0], rt[1]
 ok = (last[:, 0] > 0) & (last[:, 1] > 0) & (prev[:, 0] > 0) & (prev[:, 1] > 0)
 if not ok.all():
-    print("  (%d workgroups without a complete pair of stamps are left out)" % int((~ok).sum()))
+    bad = np.nonzero(~ok)[0]
+    print("  (%d workgroups without a complete pair of stamps are left out: envs %s ...; zero fields last start %d end %d prev start %d end %d)" % (
+        len(bad), bad[:8].tolist(), int((last[:, 0] <= 0).sum()), int((last[:, 1] <= 0).sum()), int((prev[:, 0] <= 0).sum()), int((prev[:, 1] <= 0).sum())))
     keep = np.nonzero(ok)[0]
     last, prev = last[keep], prev[keep]
     B = len(keep)
@@ -81,3 +83,20 @@ for lo, hi in ((0, 0), (1, 4), (5, 12), (13, 16)):
 sel = (keyed == 0) & (gen > 0)
 if sel.any():
     print("  no keyed quad, general-loop quads: %d workgroups, lifetime mean %.2f us  max %.2f" % (sel.sum(), life[sel].mean(), life[sel].max()))
+# the slow-first sets as the last launch left them (timing builds export them)
+try:
+    fs = env.lib.diral_env_debug_slow
+    fs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    sbuf = np.zeros((2 * (env.B + env.B // 4 + 64 + 32),), np.uint32)
+    w = fs(env._h, sbuf.ctypes.data_as(ctypes.c_void_p))
+    if w > 0:
+        smax = max(16, min(4096, env.B >> 2))
+        for i in range(2):
+            st = sbuf[i * w:(i + 1) * w]
+            tag = int(st[0]) | (int(st[1]) << 32)
+            cnt = int(st[2]) | (int(st[3]) << 32)
+            place = st[16 + smax:16 + smax + env.B]
+            print("  set %d: clock %d writer id %d; count clock %d entries %d; places != 0: %d (first %s)" % (
+                i, tag >> 32, tag & 0xffffffff, cnt >> 32, cnt & 0xffffffff, int((place != 0).sum()), place[:6].tolist()))
+except AttributeError:
+    pass
