@@ -89,6 +89,9 @@ def record(summary, head):
         out["per_wave"] = {k.replace("SQ_INSTS_", "").lower(): val(k) / wv for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if val(k)}
         if val("SQ_WAVE_CYCLES"):
             out["per_wave"]["lifetime_cycles"] = 4.0 * val("SQ_WAVE_CYCLES") / wv
+        out["per_wave"]["waves"] = wv
+        out["per_wave"]["note"] = ("divided by SQ_WAVES; step_fast64 launches B + B/4 workgroups (slow-first dispatch, DESIGN.md 3.2 item 5), "
+                                   "the B/4 first ones mostly exit at once: per wave that runs an env multiply by 1.25")
     return out
 
 
