@@ -1710,3 +1710,11 @@ def test_fused_policy_slot_with_the_observation_written_and_captured():
     for e, _, r in runs:
         e.check()
         r.close()
+
+
+@pytest.mark.parametrize("N,A,K", [(256, 64, 48), (200, 48, 40)])
+def test_stand_alone_obtain_state_with_more_than_64_kb_of_lds(N, A, K):
+    """observe_kernel's dynamic LDS grows with N x K (ring rows + histogram rows): ~66 KB at N = 256 / K = 48 (more bins do not fit the general kernel at that size),
+    ~66 KB at N = 200 / K = 40 - past the 64 KB a kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize
+    (set per handle at create).  `random_rollout` calls obtain_state with foreign arguments every six slots."""
+    random_rollout(bench_config(N, A, 16.0 * N, State=dict(num_bins=K)), B=3, T=14, seed=300 + N)
