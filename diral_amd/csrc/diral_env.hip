@@ -51,6 +51,8 @@ struct DiralEnv {
   uint32_t* slow = nullptr;
   uint64_t slow_launches = 0;   // launches that rotated the sets
   bool slow_first = true;       // DIRAL_NO_SLOW_FIRST=1 at create: blocks = envs in order (A/B timing, tests)
+  int f32_margin = -1;          // DIRAL_F32_MARGIN=<n> at create: 0 = no float32 screening of the bin, n > 0 = a band of at
+                                //   least n / 65536 bin widths (tests: a wide band sends many entries to float64); -1 = the bound
   int32_t* la = nullptr;
   int32_t* pf = nullptr;
   double* metrics = nullptr;
@@ -367,6 +369,18 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
     f.B = p.B;
+    {
+      // float32 screening of the histogram bin (step_fast64.hpp, fast quads): everything float32 can lose, in bin widths,
+      // for positions in [0, L] - two conversions of a position, the subtraction of an in-range difference, the
+      // constant and the fma at t <= K - with a factor of two on top; as 1 / 65536ths, rounded up, + 1
+      const double w = (p.Rb - (-p.Rb)) / (double)p.K;
+      const double xmax = p.L;
+      const double lost = 2.0 * (((2.0 * xmax + p.Rb) * 0x1p-24) / w + 2.0 * (double)p.K * 0x1p-23);
+      const double m = std::ceil(lost * 65536.0) + 1.0;
+      const bool on = use_fast64 && m <= 64.0 && xmax < 1e6 && e->f32_margin != 0;
+      f.f32_m16 = on ? std::max((int)m, std::min(e->f32_margin, 16384)) : 0;
+      f.f32_xmax = (float)xmax;
+    }
     f.slow_cnt_r = nullptr; f.slow_list_r = nullptr; f.slow_flag_r = nullptr;
     f.slow_cnt_w = nullptr; f.slow_list_w = nullptr; f.slow_flag_w = nullptr; f.slow_cnt_z = nullptr;
     bool slow_first = false;
@@ -612,6 +626,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
       CREATE_TRY(hipMemset(e->slow, 0, 3 * slow_set_words(e) * 4));
       const char* off = std::getenv("DIRAL_NO_SLOW_FIRST");
       e->slow_first = !(off && off[0] == '1');
+      if (const char* fm = std::getenv("DIRAL_F32_MARGIN")) e->f32_margin = std::max(0, std::atoi(fm));
     }
     e->ring_valid = true;                                       // all tables zero: never heard, age 0, xpos 0
   }

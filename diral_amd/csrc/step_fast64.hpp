@@ -95,6 +95,12 @@ struct FastParams {
   uint8_t* done_out;
   unsigned long long* dbg;
   int B;                          // envs of the handle (the grid may be larger: slow-first blocks below)
+  // float32 screening of the histogram bin in the fast quads (P3b): the bin of v = xpos - own position computed from
+  // float32 copies, exact whenever its fraction is further than `f32_m16` / 65536 bin widths from an integer (the
+  // host's bound on everything float32 can lose for positions up to `f32_xmax`); lanes inside the band take the
+  // float64 statement.  f32_m16 = 0: off (a highway too long for float32 to be worth it).
+  int f32_m16;
+  float f32_xmax;
   // Slow envs first (step_fast64 only).  An env whose tables hold entries beyond the codes runs its
   // quads on the keyed path and takes two to three times as long as the others; a launch ends when its last workgroup
   // does, so such a workgroup must not be among the last to START.  Every launch leaves, for the next one, the list of
@@ -255,6 +261,11 @@ __device__ inline int ffbl_byte(unsigned int w) {
   return r;
 }
 // double -> int32, truncating, SATURATING, NaN -> 0 (the hardware conversion; a C cast is undefined out of range)
+__device__ inline int cvt_i32_f32_sat(float x) {                   // truncating, saturating, NaN -> 0
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ inline int cvt_i32_f64_sat(double x) {
   int r;
   asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
@@ -897,6 +908,15 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // inv_w * 2^20 (exact: the exponent field + 20) and K * 2^20: the fixed-point bin of the fast quads
   const double inv_w20 = __hiloint2double(__double2hiint(inv_w) + (20 << 20), __double2loint(inv_w));
   const unsigned int k20 = (unsigned int)K << 20;
+  // float32 screening (FastParams::f32_m16): float32 copies of the lag-ordered ring rows and of the own position; off for
+  // this wave when a stamp or a position lies outside the range the host's error bound was made for
+  const int m16 = p.f32_m16;
+  const float ringf0 = (float)ringv0, ringf1 = (float)ringv1, npxf = (float)mynpx;
+  const bool f32_ok = FLAT && m16 > 0 &&
+                      __ballot(!(__builtin_fabs(ringv0) <= (double)p.f32_xmax && __builtin_fabs(ringv1) <= (double)p.f32_xmax &&
+                                 __builtin_fabs(mynpx) <= (double)p.f32_xmax)) == 0ull;
+  const float invw16f = (float)(inv_w * 65536.0), halfk16f = (float)(p.Rb * inv_w * 65536.0);
+  const unsigned int k16m = ((unsigned int)K << 16) + 2u * (unsigned int)m16;   // -m16 <= t16 < K * 2^16 + m16
   unsigned int* const hrow = s_hist + lane * KP;
   // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513) of one entry:
   // d = dist(entry, own post-move position), kept if d < Rb, value d * sign(x1 - x2)
@@ -979,6 +999,15 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
 #endif
         if (__ballot(rare) == 0ull) {
           const unsigned int agt = live ? (agq | ((own_col >> 2) == q ? own_byte : 0u)) : 0xffffffffu;
+          // (float32 screening, below) which of this lane's entries the float64 body counts: all of them when the
+          // screening is off, else those whose float32 fraction fell into the band - recomputed here, the pass is rare
+          auto band32 = [&](int cc) -> bool {
+            if (!f32_ok) return true;
+            const int src = ((int)((__builtin_ctz((cnq >> (8 * cc)) | 0x100u)) & 7) << 2) + (((4 * q + cc) & 7) << 5);
+            const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(q >= 2 ? ringf1 : ringf0)));
+            const int t16 = cvt_i32_f32_sat(__builtin_fmaf(xf - npxf, invw16f, halfk16f));
+            return (unsigned int)(t16 + m16) < k16m && (((unsigned int)(t16 - m16)) & 0xffffu) >= 65536u - 2u * (unsigned int)m16;
+          };
           auto column = [&](auto cc_tag) {
             constexpr int cc = decltype(cc_tag)::value;
             const int c = 4 * q + cc;
@@ -987,7 +1016,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
                                                __builtin_amdgcn_ds_bpermute(src, __double2loint(rv)));
             const double v = xg - mynpx;
             const int ti = cvt_i32_f64_sat((v + p.Rb) * inv_w20);
-            const bool agev = ((agt >> (8 * cc)) & 255u) < (unsigned int)p.age_limit;
+            const bool agev = band32(cc) && ((agt >> (8 * cc)) & 255u) < (unsigned int)p.age_limit;
             const bool in = (unsigned int)ti <= k20;
             const bool edge = ((unsigned int)(ti + 1) & 0xfffffu) <= 1u;
             const bool m = agev && in;
@@ -1015,6 +1044,32 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
             atomicAdd(&hrow[cnt ? bin : K], 1u);
             mycnt += cnt ? 1u : 0u;
           };
+          // float32 first (FastParams::f32_m16): ONE gather and three float32 operations per entry; t16 = (v + Rb) *
+          // inv_w * 2^16 truncated - its integer part is the bin, and |v| < Rb is 0 <= t16 < K * 2^16, unless the 16 fraction bits
+          // are within m16 of an integer (everything float32 lost is below m16 / 65536 bin widths).  Lanes inside that
+          // band are left for the float64 body, which then runs once more for the quad (a uniform test: rare)
+          bool redo = false;                                        // an entry of this lane is left for float64
+          auto column32 = [&](auto cc_tag) {
+            constexpr int cc = decltype(cc_tag)::value;
+            const int c = 4 * q + cc;
+            const int src = (ffbl_byte<cc>(cnq) << 2) + ((c & 7) << 5);
+            const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(q >= 2 ? ringf1 : ringf0)));
+            const int t16 = cvt_i32_f32_sat(__builtin_fmaf(xf - npxf, invw16f, halfk16f));
+            const bool agev = ((agt >> (8 * cc)) & 255u) < (unsigned int)p.age_limit;
+            const bool mm = agev && (unsigned int)(t16 + m16) < k16m;
+            const bool band = (((unsigned int)(t16 - m16)) & 0xffffu) >= 65536u - 2u * (unsigned int)m16;
+            const bool cnt = mm && !band;
+            redo = redo || (mm && band);
+            atomicAdd(&hrow[cnt ? (t16 >> 16) : K], 1u);
+            mycnt += cnt ? 1u : 0u;
+          };
+          if (f32_ok) {                                             // (uniform)
+            column32(std::integral_constant<int, 0>{});
+            column32(std::integral_constant<int, 1>{});
+            column32(std::integral_constant<int, 2>{});
+            column32(std::integral_constant<int, 3>{});
+            if (__ballot(redo) == 0ull) continue;
+          }
           column(std::integral_constant<int, 0>{});
           column(std::integral_constant<int, 1>{});
           column(std::integral_constant<int, 2>{});

@@ -480,6 +480,48 @@ def test_fast64_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
     gen.check()
 
 
+@pytest.mark.parametrize("margin", ["0", "2500", "16384"])
+@pytest.mark.parametrize("N,A,K,grid", [(64, 32, 20, False), (64, 32, 20, True), (61, 16, 33, False)])
+def test_fast64_float32_screening_of_the_bin_is_exact(N, A, K, grid, margin, monkeypatch):
+    """The fast quads of csrc/step_fast64.hpp take the histogram bin from float32
+    copies unless its fraction lies in a band around an integer, and from float64
+    inside it.  DIRAL_F32_MARGIN (read at create) switches the screening off (0) or
+    widens the band (2500 / 65536 of a bin: 8 % of the entries redone in float64;
+    16384: half of them), so that both bodies and their hand-over run on every step;
+    `grid`: positions and speeds on the grid of bin edges - every difference an exact
+    edge hit.  States, rewards and tables against the oracle, bit for bit."""
+    from oracle.oracle import Oracle, SQ_IEEE
+
+    L = 30.0 * N + 100
+    cfg = bench_config(N, A, L, State=dict(num_bins=K))
+    rng = np.random.default_rng(77 + N + K + int(margin))
+    B = 24
+    if grid:
+        x0 = 25.0 * rng.integers(0, int(L) // 25, size=(B, N)).astype(np.float64)
+        v0 = 25.0 * rng.integers(0, 3, size=(B, N)).astype(np.float64)
+    else:
+        x0 = rng.uniform(0, L, size=(B, N))
+        v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    y0 = np.zeros((B, N))
+    monkeypatch.setenv("DIRAL_F32_MARGIN", margin)
+    env = make_env(cfg, B, dtype=torch.float64)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    env.reset_topology(x0, y0, v0)
+    orc.reset(x0, y0, v0)
+    for t in range(30):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        o, r, d = env.step(a, t)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        o_state = orc.obtain_state(a, o_chobs, o_rew)
+        assert np.array_equal(o.cpu().numpy(), o_state), t
+        assert np.array_equal(r.cpu().numpy(), o_rew), t
+    assert (env.last_kernel() & 15) == _fam(N)
+    se, oe = env.export_state(), orc.export()
+    for k in ("seq", "x", "pos_x"):
+        assert np.array_equal(se[k].cpu().numpy(), oe[k]), k
+    env.check()
+
+
 @pytest.mark.parametrize("name", ["g1_step_rd2", "g1_ch_rd2", "g1_design", "g1_flags_all"])
 def test_testenv_shim_on_gpu_reads_like_the_reference(name):
     """`from diral_amd import TestEnv` driven with the reference's own call
