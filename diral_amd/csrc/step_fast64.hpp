@@ -154,7 +154,7 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
 }
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, slow, mtab, rtx, inr, px, py, npx, rew, stage, total;
+  uint32_t rv, edges, mask, act, hist, cnt, slow, inv, mtab, rtx, inr, px, py, npx, rew, stage, total;
 };
 // row stride (elements) of the channel-observation staging array [vehicle][resource] of the RICH
 // instantiations: a multiple of 4 elements, so that the write-out reads a 16-byte piece of a row
@@ -180,6 +180,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
   l.hist = o;  o += 4u * fast_hist_stride(K) * 64;
   l.cnt = o;   o += 4u * 64;
   l.slow = o;  o += 16u;                     // the workgroup holds a quad flagged for the keyed path of the next slot
+  l.inv = o;   o += out64 ? 0u : 8u * 64;   // float32 outputs: 1.0 / n for the 64 possible neighbour counts (P4), staged in P0
   l.mtab = o;  o += 64u * fast_mtab_stride(A);      // [vehicle][resource] gather source lane * 4 (bpermute address), bytes
   // (CH and EXTRA instantiations only - `ratios`: without them the RICH workgroup of A <= 32 stays at 20 KB, eight per CU)
   l.rtx = o;   o += ratios ? 8u * 64 : 0u;  // my_step_ch: reception ratio R per transmitter
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // retires in order, so P1 must not sit behind the 16 table words)
   const size_t vi = bN + (live ? lane : 0);
   const double my_edge = p.edges[tid < K ? tid : K];        // oldest load: must not sit behind the table
+  const double my_inv = OUT64 ? 0.0 : p.inv_tab[lane];      // (every wave: a branch around a load makes the others wait)
   int myact = p.actions[vi];
   double mypx = p.pos_x[vi];
   double mypy = FLAT ? 0.0 : p.pos_y[vi];
@@ -506,6 +508,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   // lane c (and c + 16, ...): the own sequence number of column c's subject
   unsigned int* const tsq = p.tseq + (size_t)b * p.NR + (has_cols ? wave * 16 : 0);
   const unsigned int ts_own = tsq[lane & 15];
+  // lanes 0..3: the flags of this wave's four quads (`told`, left by the previous slot) - loaded here, one word a lane,
+  // and turned into `badq` in front of the merge, which would otherwise wait there for a round trip to L2
+  const unsigned int told_l = ((LateFastArgs)late_kernarg_base())->told[qbase + (lane & 3)];
   __builtin_amdgcn_sched_barrier(0);
   if (listed) return;                        // (uniform; nothing has been stored yet)
   if (live && (myact < 0 || myact >= A)) { atomicOr(p.err, kErrAction); myact = -1; }
@@ -543,6 +548,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
   }
   for (int j = tid; j < KP * 64; j += 256) s_hist[j] = 0u;
+  if constexpr (!OUT64) {
+    // 1.0 / n, n = 0 .. 63 (a vehicle counts at most the other 63): the table P4 multiplies by, read HERE from memory,
+    // where the wave waits for its loads anyway, and from LDS behind the last barrier - there a global load was a round
+    // trip to L2 on the tail of every workgroup
+    if (wave == 2) reinterpret_cast<double*>(smem + lay.inv)[lane] = my_inv;
+  }
   if (tid <= K + 1) s_edges[tid] = my_edge;                 // K <= 64 < 256 threads
   DIRAL_FSTAMP(1);
 
@@ -794,13 +805,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   double ringv0 = ringp[lane], ringv1 = ringp[64 + lane];
   // quads with an entry older than the codes reach (a straggler is usually ONE subject; sticky policies produce
   // them: profiles/lag_distribution*.py): bit q of `badq`, from the flags the previous slot left
-  unsigned int badq = 0u;
-  {
-    const unsigned int* const toldp = lpr->told + qbase;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) badq |= (toldp[q] != 0u ? 1u : 0u) << q;
-    badq = has_cols ? (unsigned int)__builtin_amdgcn_readfirstlane((int)badq) : 0u;
-  }
+  const unsigned int badq = has_cols ? (unsigned int)__ballot(told_l != 0u) & 15u : 0u;
   const int own_col = live ? lane - wave * 16 : -1;            // column of this lane's own entry, if in this wave
   const bool own_here = has_cols && (unsigned int)own_col < 16u;
   // fresh sequence numbers of the 16 subjects: lane c holds column c's (lanes >= 16 repeat them)
@@ -808,6 +813,8 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (has_cols && lane < 16) tsq[lane] = tkov;
   // sequence-number overflow (24 bits: the keyed path packs (seq << 8) | lane)
   if (tkov >= (1u << 24) - 1u) atomicOr(lpr->err, kErrSeq);
+  double st_px0, st_px1;                                        // this slot's stamps and their sequence numbers, ring layout
+  unsigned int st_tk0, st_tk1;
   unsigned int cold[4];                                         // the codes after the stamp, before the merge
   const unsigned int own_byte = own_here ? (0xffu << (8 * (own_col & 3))) : 0u;   // this lane's own entry in its quad's words
   {
@@ -835,22 +842,27 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     const double px1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(a1, __double2hiint(mypx)),
                                         __builtin_amdgcn_ds_bpermute(a1, __double2loint(mypx)));
     const bool h0 = (unsigned int)(lane & 7) == (tk0 & 7u), h1 = (unsigned int)(lane & 7) == (tk1 & 7u);
-    ringv0 = h0 ? px0 : ringv0;
-    ringv1 = h1 ? px1 : ringv1;
     if (has_cols) {
       if (h0) ringp[lane] = px0;
       if (h1) ringp[64 + lane] = px1;
     }
+    // (into the ring rows in registers: BEHIND the merge - `ring_stamp` - so that the merge does not wait for the rows)
+    st_px0 = px0; st_px1 = px1; st_tk0 = tk0; st_tk1 = tk1;
+  }
+  auto ring_stamp = [&]() {
+    const bool h0 = (unsigned int)(lane & 7) == (st_tk0 & 7u), h1 = (unsigned int)(lane & 7) == (st_tk1 & 7u);
+    ringv0 = h0 ? st_px0 : ringv0;
+    ringv1 = h1 ? st_px1 : ringv1;
     // ... and re-arranged by LAG for the lookups of P3b: lane l takes the stamp (l & 7) numbers behind the fresh
     // one of its subject, ring[k][(t_k - (l & 7)) & 7].  An entry's xpos is then the value of lane 8 (c & 7) + lag -
     // the lag straight from the code (count of trailing zeros), no sequence number, no per-column v_readlane
-    const int r0 = (int)(((unsigned int)lane & 56u) | ((tk0 - (unsigned int)lane) & 7u)) << 2;
-    const int r1 = (int)(((unsigned int)lane & 56u) | ((tk1 - (unsigned int)lane) & 7u)) << 2;
+    const int r0 = (int)(((unsigned int)lane & 56u) | ((st_tk0 - (unsigned int)lane) & 7u)) << 2;
+    const int r1 = (int)(((unsigned int)lane & 56u) | ((st_tk1 - (unsigned int)lane) & 7u)) << 2;
     ringv0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(r0, __double2hiint(ringv0)),
                               __builtin_amdgcn_ds_bpermute(r0, __double2loint(ringv0)));
     ringv1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(r1, __double2hiint(ringv1)),
                               __builtin_amdgcn_ds_bpermute(r1, __double2loint(ringv1)));
-  }
+  };
   // Vehicle.received_update for the resources in ascending order: w[j] = comb(w[j], w[j] of lane
   // m_i / 4) for the resources i in use and the wave's four words j.  The gather sources of FOUR consecutive resources
   // arrive with one ds_read_b32 of this vehicle's table row (the next word a group ahead); a resource nobody transmits on
@@ -897,6 +909,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     // quad of the wave is keyed: a sparse topology)
     if (actw != 0ull) merge_walk(cw, [](unsigned int a, unsigned int b) { return a | b; });
   }
+  ring_stamp();
   DIRAL_FSTAMP(4);
 
   // ---- P3b: the entry's xpos, the table words, the histogram -----------------------
@@ -1321,7 +1334,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
   } else {
   float* out = static_cast<float*>(state_out) + bN * S;
-  const double* const inv_tab = ((LateFastArgs)late)->inv_tab;
+  const double* const inv_tab = reinterpret_cast<const double*>(smem + lay.inv);
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
     // (row, quad) advance incrementally: one integer division per thread instead of one per store
