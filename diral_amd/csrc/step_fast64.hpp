@@ -186,6 +186,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
   l.rtx = o;   o += ratios ? 8u * 64 : 0u;  // my_step_ch: reception ratio R per transmitter
   l.inr = o;   o += ratios ? 4u * 64 : 0u;  // my_step_ch: receivers in range per transmitter
   l.px = l.py = l.npx = l.rew = l.stage = o;
+  if (!rich) { l.px = o; o += 8u * 64; }     // the pre-move positions, for P2 behind the last barrier (RICH: part of the tail below)
   if (rich) {                               // RICH output tail (rich_out.hpp): per-vehicle values by index
     l.px = o;  o += 8u * 64;
     l.py = o;  o += flat ? 0u : 8u * 64;    // every pos_y == 0: not staged (keeps 8 workgroups per CU at A <= 32)
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   out_t* s_stage = reinterpret_cast<out_t*>(smem + lay.stage);   // RICH only
   double* s_rtx = reinterpret_cast<double*>(smem + lay.rtx);
   int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
-  double* s_px = reinterpret_cast<double*>(smem + lay.px);       // RICH only
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);       // (s_py, s_npx, s_rew: RICH only)
   double* s_py = reinterpret_cast<double*>(smem + lay.py);
   double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
   double* s_rew = reinterpret_cast<double*>(smem + lay.rew);
@@ -542,8 +543,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (wave == 0) {
     if (lane == 0) s_slow[0] = 0u;
     s_act[lane] = myact; s_cnt[lane] = 0u;
+    s_px[lane] = mypx;
     if constexpr (RICH) {
-      s_px[lane] = mypx; s_npx[lane] = mynpx; s_rew[lane] = 0.0;
+      s_npx[lane] = mynpx; s_rew[lane] = 0.0;
       if constexpr (!FLAT) s_py[lane] = mypy;
     }
   }
@@ -656,7 +658,12 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   __syncthreads();
 
   // ---- P2 (wave 0): reward per transmitter, metrics -------------------------------
-  if (wave == 0) {
+  // Nothing of it is needed before the state vectors are written unless they carry the rewards (the RICH tail) or the
+  // policy epilogue shapes them: otherwise (`late_p2`) wave 0 runs P2 BEHIND the last barrier, next to the other three
+  // waves' P4, instead of in front of its P3 - where the other waves then waited for it at that barrier.
+  bool late_p2 = !POL;
+  if constexpr (RICH) late_p2 = late_p2 && ((LateRichArgs)(late_kernarg_base() + kRichArgOffset))->plain_state != 0;
+  auto p2_body = [&](const double px_own, const int act_own) {
     const LateFastArgs lp = (LateFastArgs)late_kernarg_base();     // rew_out, metrics, done_out: used here only
     if (rd2_lanes) {
       // lane i: resource i.  A pair is rewarded 2 * [dist > Rc] - 2 (the mean distance of ONE pair is the distance:
@@ -665,11 +672,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       const int cl = __popcll(mkl);
       const unsigned long long mk2 = mkl & (mkl - 1ull);
       const int la = cl > 0 ? __builtin_ctzll(mkl) : 0, lb = cl > 1 ? __builtin_ctzll(mk2) : 0;
-      const double xa = __hiloint2double(__builtin_amdgcn_ds_bpermute(la << 2, __double2hiint(mypx)),
-                                         __builtin_amdgcn_ds_bpermute(la << 2, __double2loint(mypx)));
-      const double xb = __hiloint2double(__builtin_amdgcn_ds_bpermute(lb << 2, __double2hiint(mypx)),
-                                         __builtin_amdgcn_ds_bpermute(lb << 2, __double2loint(mypx)));
-      const double dab = p1_fast ? __builtin_fabs(xb - xa) : fast_dist<true>(xa, 0.0, xb, 0.0);
+      const double xa = __hiloint2double(__builtin_amdgcn_ds_bpermute(la << 2, __double2hiint(px_own)),
+                                         __builtin_amdgcn_ds_bpermute(la << 2, __double2loint(px_own)));
+      const double xb = __hiloint2double(__builtin_amdgcn_ds_bpermute(lb << 2, __double2hiint(px_own)),
+                                         __builtin_amdgcn_ds_bpermute(lb << 2, __double2loint(px_own)));
+      // (`p1_fast`, decided again from the positions at hand rather than kept across P3)
+      const unsigned int xh2 = (unsigned int)__double2hiint(px_own) & 0x7fffffffu;
+      const bool absd = __ballot(!(xh2 >= 0x24000000u || (xh2 | (unsigned int)__double2loint(px_own)) == 0u)) == 0ull;
+      const double dab = absd ? __builtin_fabs(xb - xa) : fast_dist<true>(xa, 0.0, xb, 0.0);
       const double rwl = cl == 2 ? 2.0 * (double)(dab > p.Rc) - 2.0 : 0.0 - (double)cl;
       if (cl > 1) s_rv[lane] = rwl;
       wave_lds_order();
@@ -677,14 +687,14 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     double rw = 0.0;
     int sole = 0, coll = 0;
     double prr = 0.0;
-    if (live && myact >= 0) {
-      const int c = __popcll(s_mask[myact]);
+    if (live && act_own >= 0) {
+      const int c = __popcll(s_mask[act_own]);
       if (CH) {
         const double R = (c > 1) ? s_rtx[lane] : 1.0;         // test_env.py:411-429
         const bool plain = (p.reward_design == 2);
         rw = plain ? ((c > 1) ? -1.0 * (1.0 - R) : 1.0) : fast_ch_reward(p.reward_design, c > 1, R);
         coll = c > 1; sole = !(c > 1); prr = R;
-      } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[myact]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
+      } else if (c > 1) { rw = (EXTRA && p.design) ? s_rtx[lane] : s_rv[act_own]; coll = 1; } else { rw = 1.0; sole = 1; }   // test_env.py:211-222, 297-301
       if (!CH && EXTRA && p.prr) prr = (c > 1) ? s_rtx[lane] : 1.0;   // the metric only: the reward stays my_step's
       if constexpr (RICH && !CH) {
         // proportional fairness (test_env.py:215-222, my_step only): a transmitter that collided more than
@@ -734,6 +744,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         done_out[b] = (uint8_t)dn;
       }
     }
+  };
+  if (wave == 0) {
+    if (!late_p2) p2_body(mypx, myact);
     if (live) p.pos_x[bN + lane] = mynpx;
   }
   if constexpr (RICH) {
@@ -1266,9 +1279,16 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     }
   }
 
+  if (late_p2 && wave == 0) {                // (uniform) P2, while the other waves write the state vectors
+    p2_body(s_px[lane], s_act[lane]);
+    DIRAL_FSTAMP(7);
+    return;
+  }
   // ---- P4: state = [one-hot(action) (A) | histogram (K)] ---------------------------
   // float64 (the reference's dtype, h/n as one IEEE division - np.histogram counts
   // divided by the neighbour count) or float32 (= the float32 cast of that value).
+  // (by the waves P2 leaves free: all four, or waves 1-3 with `late_p2`)
+  const int T4 = late_p2 ? 192 : 256, t4 = late_p2 ? tid - 64 : tid;
   const unsigned long long late = late_kernarg_base();             // state_out and the RICH section layout: from here on
   void* const state_out = ((LateFastArgs)late)->state_out;
   if constexpr (RICH) {
@@ -1302,9 +1322,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
     double* out = static_cast<double*>(state_out) + bN * S;
     if (((A | K) & 1) == 0) {
       const int q_per_row = S >> 1, total = N * q_per_row;
-      const int du = 256 / q_per_row, dq = 256 - du * q_per_row;
-      int u = tid / q_per_row, qr = tid - u * q_per_row;
-      for (int q = tid; q < total; q += 256) {
+      const int du = T4 / q_per_row, dq = T4 - du * q_per_row;
+      int u = t4 / q_per_row, qr = t4 - u * q_per_row;
+      for (int q = t4; q < total; q += T4) {
         const int s0 = qr << 1;
         double2 v;
         if (s0 < A) {
@@ -1321,7 +1341,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
       }
     } else {
-      for (int e = tid; e < N * S; e += 256) {
+      for (int e = t4; e < N * S; e += T4) {
         const int u = e / S, s = e - u * S;
         double val;
         if (s < A) val = (s_act[u] == s) ? 1.0 : 0.0;
@@ -1338,9 +1358,9 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
   if (((A | K) & 3) == 0) {
     const int q_per_row = S >> 2, total = N * q_per_row;
     // (row, quad) advance incrementally: one integer division per thread instead of one per store
-    const int du = 256 / q_per_row, dq = 256 - du * q_per_row;
-    int u = tid / q_per_row, qr = tid - u * q_per_row;
-    for (int q = tid; q < total; q += 256) {
+    const int du = T4 / q_per_row, dq = T4 - du * q_per_row;
+    int u = t4 / q_per_row, qr = t4 - u * q_per_row;
+    for (int q = t4; q < total; q += T4) {
       const int s0 = qr << 2;
       float4 v;
       if (s0 < A) {
@@ -1361,7 +1381,7 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
       if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
     }
   } else {
-    for (int e = tid; e < N * S; e += 256) {
+    for (int e = t4; e < N * S; e += T4) {
       const int u = e / S, s = e - u * S;
       float val;
       if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
