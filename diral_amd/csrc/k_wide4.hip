@@ -25,15 +25,26 @@ struct AttrWide {
 
 hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
   const LaunchWide l{f, r, dim3(B), wide_lds_layout(V, f.A, f.K).total, s};
+#ifdef DIRAL_WIDE_BENCH_ONLY
+  // tuning builds (profiles/build_variant.sh): only the instantiations the C3 bench line runs - seconds to compile
+  if (k.out64 || !k.full || k.ch || k.extra) return hipErrorInvalidValue;
+  bool_dispatch(l, std::integer_sequence<bool, false, true, false, false>{}, k.rich, k.packed);
+#else
   bool_dispatch(l, std::integer_sequence<bool>{}, k.out64, k.full, k.ch, k.extra, k.rich, k.packed);
+#endif
   return hipGetLastError();
 }
 
 hipError_t set_attr_wide4(int A, int K) {
   hipError_t st = hipSuccess;
   const AttrWide a{(int)wide_lds_layout(V, A, K).total, &st};
+#ifdef DIRAL_WIDE_BENCH_ONLY
+  for (int m = 0; m < 4; ++m)
+    bool_dispatch(a, std::integer_sequence<bool, false, true, false, false>{}, (m & 1) != 0, (m & 2) != 0);
+#else
   for (int m = 0; m < 64; ++m)
     bool_dispatch(a, std::integer_sequence<bool>{}, (m & 1) != 0, (m & 2) != 0, (m & 4) != 0, (m & 8) != 0, (m & 16) != 0, (m & 32) != 0);
+#endif
   return st;
 }
 }  // namespace diral

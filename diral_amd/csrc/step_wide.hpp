@@ -575,6 +575,12 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     }
     actw = __ballot(any != 0ull);
   }
+  // ... and per viewer slot j the resources with a transmitter IN that slot: a vehicle's merge words are gathered by
+  // others only in the step of the resource it transmits on, so the merge loop writes a slot's words back to LDS right
+  // before step i only when the slot holds a transmitter of i (a store costs three times a gather: MI355X_MICROARCH LDS)
+  unsigned long long txs[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) txs[j] = __ballot(lane < A && s_mask[(lane < A ? lane : 0) * VPL + j] != 0ull);
 
   // viewer-side tail of one entry: stores, then its histogram contribution
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
@@ -729,16 +735,14 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       // wider pass halves the number of chains a wave walks per column.
       typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
       uvec* const sv = reinterpret_cast<uvec*>(sw);
-      auto put = [&]() {
+      auto put_slot = [&](int j) {
+        uvec t;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          uvec t;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
-          sv[lane + 64 * j] = t;
-        }
+        for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
+        sv[lane + 64 * j] = t;
       };
-      put();
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) put_slot(j);
       wave_lds_order();
       auto merge_loop = [&](auto wtag, auto ttag) {
         constexpr int W = decltype(wtag)::value;
@@ -747,9 +751,17 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         unsigned long long rem = actw;
         unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
         while (rem) {
-          rem &= rem - 1;
+          const unsigned long long low = rem & (0ull - rem);     // this step's resource, as its bit
+          rem ^= low;
           const unsigned int mw = m_next;
           if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
+          // the words of this step's transmitters, as the earlier steps left them (a receiver that is no transmitter
+          // of i reads its OWN possibly stale words where it has no source: a subset of what it holds, a no-op)
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            if (VPL == 2 || (txs[j] & low)) put_slot(j);    // (N <= 128, two slots: the tests cost more than the stores they save)
+          }
+          wave_lds_order();
           unsigned int v[NK], sa[VPL];
           unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
 #pragma unroll
@@ -765,8 +777,6 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           } else {
             max_u8_words<NK>(kp, v);
           }
-          put();
-          wave_lds_order();
         }
       };
       auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
