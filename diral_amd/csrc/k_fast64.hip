@@ -16,7 +16,13 @@ struct LaunchFast64 {
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
   static const PolParams no_policy{};
   const LaunchFast64 l{f, r, no_policy, dim3(B), fast_lds_layout(f.K, f.A, k.rich, k.out64, k.flat, k.ch || k.extra).total, s};
+#ifdef DIRAL_FAST_BENCH_ONLY
+  // tuning builds (profiles/build_variant.sh): only the instantiations the C2 / C4 bench lines run - seconds to compile
+  if (!k.flat || k.out64 || k.ch || k.extra) return hipErrorInvalidValue;
+  bool_dispatch(l, std::integer_sequence<bool, true, false, false, false>{}, k.rich);
+#else
   bool_dispatch(l, std::integer_sequence<bool>{}, k.flat, k.out64, k.ch, k.extra, k.rich);
+#endif
   return hipGetLastError();
 }
 

@@ -25,15 +25,25 @@ struct AttrWide {
 
 hipError_t launch_wide2(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
   const LaunchWide l{f, r, dim3(B), wide_lds_layout(V, f.A, f.K).total, s};
+#ifdef DIRAL_WIDE_BENCH_ONLY
+  // tuning builds (profiles/build_variant.sh): only the instantiations the C5 bench line runs - seconds to compile
+  if (k.out64 || !k.full || k.ch || k.extra) return hipErrorInvalidValue;
+  bool_dispatch(l, std::integer_sequence<bool, false, true, false, false>{}, k.rich);
+#else
   bool_dispatch(l, std::integer_sequence<bool>{}, k.out64, k.full, k.ch, k.extra, k.rich);
+#endif
   return hipGetLastError();
 }
 
 hipError_t set_attr_wide2(int A, int K) {
   hipError_t st = hipSuccess;
   const AttrWide a{(int)wide_lds_layout(V, A, K).total, &st};
+#ifdef DIRAL_WIDE_BENCH_ONLY
+  for (int m = 0; m < 2; ++m) bool_dispatch(a, std::integer_sequence<bool, false, true, false, false>{}, (m & 1) != 0);
+#else
   for (int m = 0; m < 32; ++m)
     bool_dispatch(a, std::integer_sequence<bool>{}, (m & 1) != 0, (m & 2) != 0, (m & 4) != 0, (m & 8) != 0, (m & 16) != 0);
+#endif
   return st;
 }
 }  // namespace diral

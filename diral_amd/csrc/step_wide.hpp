@@ -649,6 +649,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // costs more than it saves (C5 + 13 %, a sparse 256-vehicle highway + 60 %).
   if constexpr (PACKED) {
   unsigned int passbits = 0u;                      // bit pch: a quad of pass pch was flagged when the slot began
+#ifndef DIRAL_WIDE_NO_PREFETCH
+  unsigned int pf_sink = 0u;
+#endif
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
     const int kbase = wave * CPW + pch * PC;
@@ -722,6 +725,22 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
     }
     DIRAL_WCLOCK(tc1);
+#ifndef DIRAL_WIDE_NO_PREFETCH
+    // the NEXT pass's code and age words towards the caches while this pass merges (the result register is never read:
+    // it only has to stay allocated until the loads have landed - `pf_sink` lives to the end of the loop)
+    if (pch + 1 < CPW / PC && kbase + PC < NRows) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const unsigned long long bc = (unsigned long long)tcrow + 4ull * (unsigned int)((NW + w) * NV);
+        const unsigned long long ba = (unsigned long long)tarow + 4ull * (unsigned int)((NW + w) * NV);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(bc), "n"(256 * j));
+          asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(ba), "n"(256 * j));
+        }
+      }
+    }
+#endif
     {
       constexpr bool thermo = true;
       unsigned int kp0[NK];                      // the codes before the merge
@@ -861,6 +880,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
 #endif
   }
+#ifndef DIRAL_WIDE_NO_PREFETCH
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
+#endif
   // ---- flagged passes (a quad with an entry beyond the codes): through the planes, in a loop of their own so that
   //      the coded pass above carries none of this path's registers
 #pragma unroll 1
