@@ -689,8 +689,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     for (int w = 0; w < NW; ++w)
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
-        kp[w * VPL + j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
-        agew[w * VPL + j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
+        // (non-temporal, like the stores below: a word is read once and written once per slot, and whatever it would push out of
+        // L2 - the next pass's words on their way in, see the finalize loop - is worth more there: C3 reads 1.93 -> 1.70 GB)
+        kp[w * VPL + j] = __builtin_nontemporal_load(&tcrow[(unsigned int)(w * NV) + ul + 64u * j]);
+        agew[w * VPL + j] = __builtin_nontemporal_load(&tarow[(unsigned int)(w * NV) + ul + 64u * j]);
       }
     {
       const unsigned int ts = tsrow[ul < (unsigned int)PC ? ul : 0u];
@@ -725,22 +727,6 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
       }
     }
     DIRAL_WCLOCK(tc1);
-#ifndef DIRAL_WIDE_NO_PREFETCH
-    // the NEXT pass's code and age words towards the caches while this pass merges (the result register is never read:
-    // it only has to stay allocated until the loads have landed - `pf_sink` lives to the end of the loop)
-    if (pch + 1 < CPW / PC && kbase + PC < NRows) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const unsigned long long bc = (unsigned long long)tcrow + 4ull * (unsigned int)((NW + w) * NV);
-        const unsigned long long ba = (unsigned long long)tarow + 4ull * (unsigned int)((NW + w) * NV);
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(bc), "n"(256 * j));
-          asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(ba), "n"(256 * j));
-        }
-      }
-    }
-#endif
     {
       constexpr bool thermo = true;
       unsigned int kp0[NK];                      // the codes before the merge
@@ -825,15 +811,35 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           if (FULL || lane + 64 * j < N) {
-            tcrow[(unsigned int)(w * NV) + ul + 64u * j] = kp[w * VPL + j];
-            tarow[(unsigned int)(w * NV) + ul + 64u * j] = agew[w * VPL + j];
+            __builtin_nontemporal_store(kp[w * VPL + j], &tcrow[(unsigned int)(w * NV) + ul + 64u * j]);
+            __builtin_nontemporal_store(agew[w * VPL + j], &tarow[(unsigned int)(w * NV) + ul + 64u * j]);
           }
         }
       bool handw[NW];                              // a lane handed an entry of the quad over (now 7 behind)
 #pragma unroll
       for (int w = 0; w < NW; ++w) handw[w] = false;
 #pragma unroll
-      for (int w = 0; w < NW; ++w)
+      for (int w = 0; w < NW; ++w) {
+#ifndef DIRAL_WIDE_NO_PREFETCH
+      // The NEXT pass's code and age words requested towards L2 in front of this pass's last four columns (16 loads into a
+      // register that is never read: `pf_sink` only stays allocated until they have landed): the next pass then starts
+      // on an L2 hit instead of an HBM round trip.  Placement matters: L2 turns over in ~10 us at this kernel's rate, and
+      // words requested before the merge (15 us earlier) were fetched TWICE (reads +1.0 GB; the second time from the
+      // Infinity Cache); here +0.09 GB.  Only with the channel observation (RICH): without it the launch is 2 % faster
+      // without the prefetch.
+      if (RICH && w == NW - 1 && pch + 1 < CPW / PC && kbase + PC < NRows) {
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+          const unsigned long long bc = (unsigned long long)tcrow + 4ull * (unsigned int)((NW + w2) * NV);
+          const unsigned long long ba = (unsigned long long)tarow + 4ull * (unsigned int)((NW + w2) * NV);
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(bc), "n"(256 * j));
+            asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(ba), "n"(256 * j));
+          }
+        }
+      }
+#endif
 #pragma unroll FIN_UNROLL
       for (int cc = 0; cc < 4; ++cc) {
         const int c = 4 * w + cc;
@@ -869,6 +875,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           emit(k, kvalid, j, false, age, xg, tkrow, txrow, std::integral_constant<int, 3>{});
         }
         wave_lds_order();
+      }
       }
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
