@@ -607,9 +607,33 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         }
       } while (m);
     };
+    // my_step without the EXTRA switches: nothing needs "in range" per transmitter, and the closest IN-RANGE transmitter
+    // (strict '<', first of equals) is the closest of all if that one is in range, else none - so the loop keeps a plain
+    // running minimum (v_min_f64 on the magnitude: one instruction where the select of a float64 takes two, and no range
+    // compare per transmitter) and the range test runs once per resource.  7 -> 4 vector instructions per transmitter.
+    auto search_min = [&](auto fast_tag) {
+      constexpr bool ABS = decltype(fast_tag)::value;
+      unsigned long long m = mk;
+      do {
+        const int w = __builtin_ctzll(m);
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(w));
+        double d;
+        if constexpr (ABS) d = mypx - readlane_f64(mypx, w);                     // signed: the magnitude through source modifiers
+        else d = fast_dist<FLAT>(readlane_f64(mypx, w), FLAT ? 0.0 : readlane_f64(mypy, w), mypx, mypy);
+        const bool bt = __builtin_fabs(d) < best;
+        bid = bt ? w : bid;
+        asm("v_min_f64 %0, %0, |%1|" : "+v"(best) : "v"(d));
+      } while (m);
+      if (!(best < p.Rc)) { best = 100000.0; bid = lane; }                       // network.py:385-386: none in range
+    };
     if (mk != 0ull) {
-      if (FLAT && p1_fast) search(std::true_type{});
-      else search(std::false_type{});
+      if constexpr (!CH && !EXTRA) {
+        if (FLAT && p1_fast) search_min(std::true_type{});
+        else search_min(std::false_type{});
+      } else {
+        if (FLAT && p1_fast) search(std::true_type{});
+        else search(std::false_type{});
+      }
     }
     best = __builtin_fabs(best);
     const bool self = !live || myact == i;                  // padded lanes and the transmitters of i gather from themselves
