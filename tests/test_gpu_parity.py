@@ -1760,3 +1760,54 @@ def test_stand_alone_obtain_state_with_more_than_64_kb_of_lds(N, A, K):
     ~66 KB at N = 200 / K = 40 - past the 64 KB a kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize
     (set per handle at create).  `random_rollout` calls obtain_state with foreign arguments every six slots."""
     random_rollout(bench_config(N, A, 16.0 * N, State=dict(num_bins=K)), B=3, T=14, seed=300 + N)
+
+
+@pytest.mark.parametrize("N,A", [(64, 32), (48, 6), (128, 64), (256, 64)])
+def test_closest_transmitter_on_ties_and_at_the_range_boundary(N, A):
+    """Network.find_closest_tx (network.py:378-398) on the plain my_step instantiations - no arrival stamps, no PRR
+    tracking: step_fast64's search keeps a running minimum over ALL transmitters and tests the range once per resource
+    (csrc/step_fast64.hpp, P1).  A standing topology on a 50 m grid with Rc = 250 m makes the cases it must not get
+    wrong permanent: transmitters exactly Rc away (out of range: strict '<'), two transmitters at the same distance on
+    either side or at the same spot (the lower id wins), a vehicle on top of its transmitter (distance 0).  State, reward
+    and the channel observation (the distance to the chosen transmitter, 100000 when none is in range) against the
+    oracle, bit for bit, and the tables at the end."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(N, A, 50.0 * 40, communication_range=250.0)
+    rng = np.random.default_rng(77 + N)
+    B = 12
+    x0 = (50.0 * rng.integers(0, 40, size=(B, N))).astype(np.float64)
+    y0 = np.zeros((B, N))
+    v0 = np.zeros((B, N))                                  # nobody moves: the grid stays a grid
+    env = make_env(cfg, B)
+    env.reset_topology(x0, y0, v0)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    orc.reset(x0, y0, v0)
+    seen_boundary = seen_tie = False
+    for t in range(12):
+        acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, acts, t)
+        assert (env.last_kernel() & 15) == _fam(N)
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, t)
+        o_state = orc.obtain_state(acts, o_chobs, o_rew)
+        assert np.array_equal(rew, o_rew), t
+        assert np.array_equal(chobs, o_chobs), (t, np.argwhere(chobs != o_chobs)[:5])
+        assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:5])
+        # the slot really held the cases: a (viewer, transmitter) pair exactly Rc apart, and a viewer with two
+        # equidistant nearest transmitters on one resource
+        for b in range(2):
+            for i in range(A):
+                tx = np.flatnonzero(acts[b] == i)
+                if len(tx) == 0:
+                    continue
+                d = np.abs(x0[b][:, None] - x0[b][tx][None, :])
+                seen_boundary |= bool(np.any(d == 250.0))
+                if len(tx) > 1:
+                    ds = np.sort(d, axis=1)
+                    seen_tie |= bool(np.any((ds[:, 0] == ds[:, 1]) & (ds[:, 0] < 250.0)))
+    assert seen_boundary and seen_tie
+    st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    oe = orc.export()
+    for k in ("pos_x", "seq", "x"):
+        assert np.array_equal(st[k], oe[k]), k
+    assert np.array_equal(st["age"], np.minimum(oe["age"], 255))
+    env.check()
