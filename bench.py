@@ -387,9 +387,10 @@ def rollout_sps(device, envs=4096, slots=400, warm=80):
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
-def rollout_sps_graph(device, envs=4096, K=50, replays=8):
+def rollout_sps_graph(device, envs=4096, K=48, replays=8):
     """The same closed loop (env step -> reward shaping -> SPS policy) as `rollout_sps`, K slots captured into ONE
-    hipGraph and replayed (diral_amd/rollout.py: slot number, policy draws and actions live in device memory)."""
+    hipGraph and replayed (diral_amd/rollout.py: slot number, policy draws and actions live in device memory; K a
+    multiple of 3: the captured step launches keep the slow-env list live, diral_env_set_capture_rotation)."""
     from diral_amd import c2_config
     from diral_amd.rollout import GraphRollout
     from diral_amd.sps import SpsPolicy
@@ -452,7 +453,7 @@ def rollout_sps_fused(device, envs=4096, slots=400, warm=80, write_chobs=False):
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
-def c2_graph(device, envs=4096, K=20, replays=50):
+def c2_graph(device, envs=4096, K=24, replays=42):
     """The headline step (c2: state + reward + channel observation, iid-uniform actions from a ring of K action tensors)
     with K slots captured into ONE hipGraph (slot number on the device: diral_env_set_clock) and replayed: what is left of
     the gap between `ms_per_step` and the kernel time when no launch goes through Python.  Outputs of a replay equal K
@@ -480,9 +481,12 @@ def c2_graph(device, envs=4096, K=20, replays=50):
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=device)
     side.wait_stream(torch.cuda.current_stream(device))
+    assert K % 3 == 0                           # the captured launches rotate the slow-env sets: VecV2VEnv.set_capture_rotation
+    env.set_capture_rotation(True)
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             k_slots()
+    env.set_capture_rotation(False)
     torch.cuda.current_stream(device).wait_stream(side)
     for _ in range(3):
         graph.replay()

@@ -25,6 +25,7 @@ SYMBOLS = [
     "diral_sps_window_from_chobs", "diral_sps_step_chobs", "diral_driver_shape",
     "diral_env_export_entries", "diral_env_import_entries",
     "diral_env_set_clock", "diral_clock_add", "diral_sps_step_chobs_clocked", "diral_env_step_policy",
+    "diral_env_set_capture_rotation", "diral_env_align_phase",
 ]
 
 _lib = None
@@ -87,6 +88,8 @@ def load() -> ctypes.CDLL:
         "diral_clock_add": (I, [P, I64, P]),
         "diral_sps_step_chobs_clocked": (I, [I, I, P, I, P, P, P, D, D, D, U64, P, P, P]),
         "diral_env_step_policy": (I, [P, I, P, I64, P, P, P, P, I, P, P]),
+        "diral_env_set_capture_rotation": (I, [P, I, P]),
+        "diral_env_align_phase": (I, [P, I, P]),
     }
     for name in SYMBOLS:
         try:

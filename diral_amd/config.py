@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1

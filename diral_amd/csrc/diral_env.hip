@@ -51,6 +51,7 @@ struct DiralEnv {
   uint32_t* slow = nullptr;
   uint64_t slow_launches = 0;   // launches that rotated the sets
   bool slow_first = true;       // DIRAL_NO_SLOW_FIRST=1 at create: blocks = envs in order (A/B timing, tests)
+  bool capture_rotates = false; // diral_env_set_capture_rotation: captured launches rotate the sets too (graphs of 3 k launches)
   int f32_margin = -1;          // DIRAL_F32_MARGIN=<n> at create: 0 = no float32 screening of the bin, n > 0 = a band of at
                                 //   least n / 65536 bin widths (tests: a wide band sends many entries to float64); -1 = the bound
   int32_t* la = nullptr;
@@ -390,13 +391,14 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
       uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
       uint32_t* const set_z = e->slow + ((e->slow_launches + 2) % 3) * w;
       f.slow_cnt_r = set_r; f.slow_list_r = set_r + 16; f.slow_flag_r = set_r + 16 + fast_slow_max(e->B);
-      if (!stream_is_capturing(s)) {
+      if (e->capture_rotates || !stream_is_capturing(s)) {
         f.slow_cnt_w = set_w; f.slow_list_w = set_w + 16; f.slow_flag_w = set_w + 16 + fast_slow_max(e->B);
         f.slow_cnt_z = set_z;
         ++e->slow_launches;
       }
       // (a CAPTURED launch reads the set the last eager launch left - complete, never written by a replay - and builds
-      // none: a replayed graph could not rotate the sets.  The list ages with the replays - slow envs stay slow for
+      // none: a replayed graph could not rotate the sets - unless the caller keeps every graph at a multiple of three
+      // launches and its phase aligned: diral_env_set_capture_rotation.  The list ages with the replays - slow envs stay slow for
       // hundreds of slots, profiles/launch_timeline.py - but stays a partition: every env runs exactly once.)
       slow_first = true;
     }
@@ -1155,6 +1157,27 @@ int diral_clock_add(int64_t* clock, int64_t inc, void* stream) {
 int diral_env_set_clock(DiralEnv* e, const int64_t* t_dev) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   e->base.t_dev = (const long long*)t_dev;
+  return DIRAL_OK;
+}
+
+int diral_env_set_capture_rotation(DiralEnv* e, int on, int* phase) {
+  if (!e) return DIRAL_ERR_BAD_ARG;
+  e->capture_rotates = on != 0;
+  if (phase) *phase = (int)(e->slow_launches % 3);
+  return DIRAL_OK;
+}
+
+int diral_env_align_phase(DiralEnv* e, int phase, void* stream) {
+  if (!e || phase < 0 || phase > 2) return DIRAL_ERR_BAD_ARG;
+  if (!e->slow || (int)(e->slow_launches % 3) == phase) return DIRAL_OK;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  if (stream_is_capturing(s)) { e->capture_violation = true; return DIRAL_ERR_CAPTURE; }
+  // the sets a launch of the new phase reads, builds and clears must not hold what launches of another phase left half
+  // done (a cleared count under flags that still stand): all three empty = every env runs in dispatch order once
+  if (hipMemsetAsync(e->slow, 0, 3 * slow_set_words(e) * 4, s) != hipSuccess) return DIRAL_ERR_HIP;
+  while ((int)(e->slow_launches % 3) != phase) ++e->slow_launches;
   return DIRAL_OK;
 }
 

@@ -77,6 +77,7 @@ class GraphRollout:
         self.sum_r = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
         self.coll = [torch.empty((B,), dtype=dt, device=dev) for _ in range(2)]
         self.graph = None
+        self._phase = None
         self._slots_run = 0
         self._closed = False
         env.set_clock(self.clock.t)            # the env holds the tensor from here on (VecV2VEnv.set_clock)
@@ -89,9 +90,17 @@ class GraphRollout:
                 self.graph = torch.cuda.CUDAGraph()
                 self._stream = torch.cuda.Stream(device=dev)
                 self._stream.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(self._stream):
-                    with torch.cuda.graph(self.graph, stream=self._stream):
-                        self._run_slots(eager=False)
+                # K a multiple of 3: the captured launches rotate the slow-env sets like eager ones (the list of the
+                # envs to dispatch first stays live from replay to replay instead of ageing: VecV2VEnv.set_capture_rotation;
+                # run() keeps the phase aligned)
+                self._phase = env.set_capture_rotation(True) if self.K % 3 == 0 else None
+                try:
+                    with torch.cuda.stream(self._stream):
+                        with torch.cuda.graph(self.graph, stream=self._stream):
+                            self._run_slots(eager=False)
+                finally:
+                    if self._phase is not None:
+                        env.set_capture_rotation(False)
                 torch.cuda.current_stream(dev).wait_stream(self._stream)
         except BaseException:
             # (DIRAL_ERR_CAPTURE, an unsupported reward design for my_step_ch, ...): the env must not keep
@@ -123,6 +132,8 @@ class GraphRollout:
 
     def run(self, replays: int = 1) -> None:
         """`replays` x K slots (enqueued on the current stream; no host sync)."""
+        if self.graph is not None and getattr(self, "_phase", None) is not None and replays > 0:
+            self.env.align_phase(self._phase)        # (eager steps since the last replay may have moved it)
         for _ in range(replays):
             if self.graph is not None:
                 self.graph.replay()

@@ -218,6 +218,21 @@ class VecV2VEnv:
                  "diral_env_set_clock")
         self._clock = clock
 
+    def set_capture_rotation(self, on: bool) -> int:
+        """Let captured step launches rotate the slow-env sets like eager ones (`diral_env_set_capture_rotation`; N <= 64).
+        The caller's side of the contract: every graph captured while this is on holds a multiple of 3 step launches of
+        this env, is replayed whole, and `align_phase(phase)` runs before a replay that follows anything but another
+        replay of the same graph.  Returns the env's phase at the call (= the phase of the first launch captured next)."""
+        phase = ctypes.c_int(0)
+        self._ok(self.lib.diral_env_set_capture_rotation(self._h, 1 if on else 0, ctypes.byref(phase)),
+                 "diral_env_set_capture_rotation")
+        return int(phase.value)
+
+    def align_phase(self, phase: int) -> None:
+        """Bring the env's launch phase to `phase` on the current stream (`diral_env_align_phase`): a no-op when it is
+        there already, otherwise the slow-env sets are emptied first."""
+        self._ok(self.lib.diral_env_align_phase(self._h, int(phase), self._stream()), "diral_env_align_phase")
+
     def last_kernel(self) -> int:
         """config.KERNEL_* code of the kernel the last step / observe call launched."""
         return int(self.lib.diral_env_last_kernel(self._h))

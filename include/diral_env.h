@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 4
+#define DIRAL_ABI_VERSION 5
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -423,6 +423,19 @@ int diral_env_step_policy(DiralEnv* env, int mode, const int32_t* actions, int64
  *   diral_clock_add(clock, inc, stream): *clock += inc as a one-thread launch (the last node of the graph).
  *   diral_sps_step_chobs_clocked: diral_sps_step_chobs with device draws seeded by seed + *clock. */
 int diral_env_set_clock(DiralEnv* env, const int64_t* t_dev);
+/* Slow-first dispatch inside captured graphs (N <= 64).  A step launch leaves the list of the envs
+ * it found slow for the NEXT launch in one of three rotating sets; the host counts launches to know which set a launch
+ * reads, builds and clears.  A captured launch is baked with its sets, so by default it only READS the set of the last
+ * eager launch and builds none - correct, but the list ages with the replays.
+ *   diral_env_set_capture_rotation(env, 1, &phase): from now on captured step launches rotate the sets like eager ones.
+ *     The caller promises: every graph captured while this is on holds a MULTIPLE OF 3 step launches of this env, is
+ *     replayed whole, and diral_env_align_phase(env, phase, stream) is called (on the replay's stream) before a replay
+ *     that follows anything but another replay of the same graph.  *phase (may be NULL) = the env's phase (launch count
+ *     mod 3) at the call: the phase of the first launch captured next.  (…, 0, …): back to the default.
+ *   diral_env_align_phase(env, phase, stream): make the env's phase `phase`; if it has to move, the three sets are
+ *     emptied first (an empty list is always a valid one: the next launch runs every env in dispatch order). */
+int diral_env_set_capture_rotation(DiralEnv* env, int on, int* phase);
+int diral_env_align_phase(DiralEnv* env, int phase, void* stream);
 int diral_clock_add(int64_t* clock, int64_t inc, void* stream);
 int diral_sps_step_chobs_clocked(int agents, int num_channels, const void* chobs, int chobs_dtype,
                                  const int32_t* actions, int32_t* prev_action, int32_t* counter,

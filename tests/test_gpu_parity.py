@@ -1585,12 +1585,14 @@ def test_streamed_sub_batches_equal_one_handle(N, A, G, B):
     one.check()
 
 
+@pytest.mark.parametrize("K", [10, 12])
 @pytest.mark.parametrize("N,A,B,ch", [(64, 32, 64, False), (64, 32, 16, True), (128, 64, 8, False), (256, 64, 4, False)])
-def test_graph_rollout_equals_eager(N, A, B, ch):
+def test_graph_rollout_equals_eager(N, A, B, ch, K):
     """diral_amd/rollout.py: K slots of [env step -> reward shaping -> SPS policy] captured into one hipGraph and replayed
-    20 times against the same 210 slots run eagerly: slot number (done flag, arrival stamps), policy draws and actions come
+    20 times against the same 21 K slots run eagerly: slot number (done flag, arrival stamps), policy draws and actions come
     from device memory, so the replays move on exactly like the eager loop - env state, tables, policy state, metrics and the
-    last outputs equal bit for bit."""
+    last outputs equal bit for bit.  K = 12 (a multiple of 3): the captured launches of step_fast64 rotate the slow-env
+    sets (diral_env_set_capture_rotation) instead of reading a frozen list - every env still runs exactly once per slot."""
     from diral_amd.rollout import GraphRollout
     from diral_amd.sps import SpsPolicy
     from diral_amd.vec_env import VecV2VEnv
@@ -1600,10 +1602,11 @@ def test_graph_rollout_equals_eager(N, A, B, ch):
         env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32, io_ring=2)
         env.reset_topology(seed=5)
         pol = SpsPolicy(B, N, A, device="cuda:0", seed=3)
-        ro = GraphRollout(env, pol, K=10, enable_channel=ch, capture=capture)
+        ro = GraphRollout(env, pol, K=K, enable_channel=ch, capture=capture)
+        assert (ro._phase is not None) == (capture and K % 3 == 0)
         ro.run(20 if capture else 21)
         torch.cuda.synchronize()
-        assert ro.slots == 210 and ro.clock.value() == 210
+        assert ro.slots == 21 * K and ro.clock.value() == 21 * K
         runs.append((env, pol, ro))
     (e1, p1, r1), (e2, p2, r2) = runs
     a, b = e1.export_state(), e2.export_state()
@@ -1615,9 +1618,9 @@ def test_graph_rollout_equals_eager(N, A, B, ch):
     assert torch.equal(e1._done, e2._done) and torch.equal(e1._chobs, e2._chobs)
     m1, m2 = e1.metrics(), e2.metrics()
     assert torch.equal(m1[:, [0, 2, 3]], m2[:, [0, 2, 3]]) and torch.allclose(m1, m2, rtol=1e-12, atol=1e-9)
-    assert float(m1[:, 0].min()) == 210.0
+    assert float(m1[:, 0].min()) == 21.0 * K
     if ch:
-        assert torch.equal(e1.info_age(209), e2.info_age(209))
+        assert torch.equal(e1.info_age(21 * K - 1), e2.info_age(21 * K - 1))
     for e, _, r in runs:
         e.check()
         r.close()
@@ -1811,3 +1814,46 @@ def test_closest_transmitter_on_ties_and_at_the_range_boundary(N, A):
         assert np.array_equal(st[k], oe[k]), k
     assert np.array_equal(st["age"], np.minimum(oe["age"], 255))
     env.check()
+
+
+def test_graph_replays_with_rotating_slow_sets_survive_eager_steps_in_between():
+    """A captured rollout whose step launches rotate the slow-env sets (K = 6: diral_env_set_capture_rotation), with
+    plain eager steps of the same env between the replays - one, then two, so that the launch phase is off by one and by
+    two when the next replay starts: `GraphRollout.run` realigns it (diral_env_align_phase empties the sets), and every
+    env still runs exactly once in every launch.  Against the same sequence without a graph, bit for bit.  Sticky
+    actions make a third of the envs slow, so the lists are long and change from slot to slot."""
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    N, A, B, K = 64, 32, 256, 6
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2)
+    runs = []
+    for capture in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32, io_ring=2)
+        env.reset_topology(seed=9)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=4)
+        pol.keep_prob = 0.95
+        ro = GraphRollout(env, pol, K=K, capture=capture)
+        assert (ro._phase is not None) == capture
+        extra = [env.sample(seed=50 + i) for i in range(3)]
+        ro.run(15 if capture else 16)                                    # (the capture ran its K slots once eagerly)
+        env._step(ro.mode, extra[0], 0, want_chobs=True)                 # one eager launch: phase + 1
+        ro.run(5)
+        env._step(ro.mode, extra[1], 1, want_chobs=True)                 # two: phase + 2
+        env._step(ro.mode, extra[2], 2, want_chobs=True)
+        ro.run(5)
+        env._step(ro.mode, extra[0], 3, want_chobs=True)                 # a last eager step: its outputs are compared
+        torch.cuda.synchronize()
+        runs.append((env, pol, ro))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    assert torch.equal(e1._obs, e2._obs) and torch.equal(e1._rew, e2._rew) and torch.equal(e1._chobs, e2._chobs)
+    m1, m2 = e1.metrics(), e2.metrics()
+    assert torch.equal(m1[:, [0, 2, 3]], m2[:, [0, 2, 3]])
+    assert float(m1[:, 0].min()) == float(m1[:, 0].max()) == 26.0 * K + 4          # (the eager pass of the capture, 25 runs, 4 steps)
+    for e, _, r in runs:
+        e.check()
+        r.close()
