@@ -650,10 +650,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   if constexpr (PACKED) {
   unsigned int passbits = 0u;                      // bit pch: a quad of pass pch was flagged when the slot began
 #ifndef DIRAL_WIDE_NO_PREFETCH
-  unsigned int pf_sink = 0u;
+  unsigned int pf_touch = 0u;
 #endif
 #pragma unroll 1
   for (int pch = 0; pch < CPW / PC; ++pch) {
+#ifndef DIRAL_WIDE_NO_PREFETCH
+    asm volatile("" :: "v"(pf_touch));          // (the prefetch of the pass before, if any: see the finalize loop)
+#endif
     const int kbase = wave * CPW + pch * PC;
     if (kbase >= NRows) break;
     if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
@@ -821,23 +824,17 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
 #ifndef DIRAL_WIDE_NO_PREFETCH
-      // The NEXT pass's code and age words requested towards L2 in front of this pass's last four columns (16 loads into a
-      // register that is never read: `pf_sink` only stays allocated until they have landed): the next pass then starts
-      // on an L2 hit instead of an HBM round trip.  Placement matters: L2 turns over in ~10 us at this kernel's rate, and
-      // words requested before the merge (15 us earlier) were fetched TWICE (reads +1.0 GB; the second time from the
-      // Infinity Cache); here +0.09 GB.  Only with the channel observation (RICH): without it the launch is 2 % faster
-      // without the prefetch.
+      // The NEXT pass's code and age words requested towards L2 in front of this pass's last four columns: ONE load, every
+      // lane a dword of another 64-byte piece of the next pass's rows (lanes 0-31: the code words, 32-63: the age words;
+      // 2 KB each at N = 256), so that the next pass starts on L2 hits instead of an HBM round trip.  An ordinary load
+      // into `pf_touch`, "used" by an empty asm at the top of the next pass: the compiler keeps one register for it and
+      // knows what is in flight.  Placement matters: L2 turns over in ~10 us at this kernel's rate, and words requested
+      // before the merge (15 us earlier) were fetched TWICE (reads +1.0 GB, the second time from the Infinity Cache).
+      // Only with the channel observation (RICH): without it the launch is 2 % faster without the prefetch.
       if (RICH && w == NW - 1 && pch + 1 < CPW / PC && kbase + PC < NRows) {
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) {
-          const unsigned long long bc = (unsigned long long)tcrow + 4ull * (unsigned int)((NW + w2) * NV);
-          const unsigned long long ba = (unsigned long long)tarow + 4ull * (unsigned int)((NW + w2) * NV);
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(bc), "n"(256 * j));
-            asm volatile("global_load_dword %0, %1, %2 offset:%c3" : "+v"(pf_sink) : "v"(4u * ul), "s"(ba), "n"(256 * j));
-          }
-        }
+        const unsigned int piece = 16u * (ul & 31u);                           // dword index: 64-byte pieces
+        const unsigned int* const nb = (ul < 32u ? (const unsigned int*)tcrow : (const unsigned int*)tarow) + (unsigned int)(NW * NV);
+        if (piece < (unsigned int)(NW * NV)) pf_touch = nb[piece];
       }
 #endif
 #pragma unroll FIN_UNROLL
@@ -888,7 +885,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #endif
   }
 #ifndef DIRAL_WIDE_NO_PREFETCH
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
+  asm volatile("" :: "v"(pf_touch));
 #endif
   // ---- flagged passes (a quad with an entry beyond the codes): through the planes, in a loop of their own so that
   //      the coded pass above carries none of this path's registers
