@@ -313,16 +313,35 @@ hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
   return hipMemsetAsync(e->slow, 0, 3 * slow_set_words(e) * 4, s);
 }
 
-// Will this step run on the POL instantiation of step_fast64 (the policy epilogue inside the launch)?  The conditions of
-// launch_step_any below, evaluated up front: diral_env_step_policy must know BEFORE it launches anything whether it needs
-// the caller's channel-observation buffer for the three-launch form.
-bool policy_fusable(const DiralEnv* e, const StepParams& p) {
-  const bool spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
-  if (!(spec && e->vpl == 1 && p.A <= kFastMaxA && p.NV == 64 && e->flat_y && p.N >= 8)) return false;
-  if (p.mode != DIRAL_STEP_MY_STEP) return false;                       // (my_step_ch: CH instantiation; design: EXTRA)
-  const bool extra = ((p.flags & DIRAL_F_TRACK_ARRIVAL) && p.la) || ((p.flags & DIRAL_F_MOBILITY) && p.trace) ||
-                     (p.flags & DIRAL_F_TRACK_PRR) || !(p.flags & DIRAL_F_ADD_POSDIST_PIGGY) || !(p.flags & DIRAL_F_MOBILITY);
-  return !extra;
+// Which kernel family and instantiation a step call runs on: decided in ONE place, for the launch itself
+// (launch_step_any) and for everyone who must know the outcome before anything is launched (diral_env_step_policy).
+struct StepDispatch {
+  bool spec, plain, ch, use_fast64, use_wide;
+  // the run-time switches of the EXTRA instantiations, host-folded (FastParams::design ... nomove)
+  bool design, prr, notab, nomove;
+  int32_t* la;
+  const double* trace;
+  bool extra;
+  bool pol_ok;          // the POL instantiation of step_fast64 (policy epilogue inside the launch) takes this call
+};
+StepDispatch step_dispatch(const DiralEnv* e, const StepParams& p) {
+  StepDispatch d;
+  d.spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
+  d.plain = d.spec && is_plain_cfg(p);
+  d.ch = p.mode == DIRAL_STEP_MY_STEP_CH;
+  // the wide kernels read the reward column of a RICH state back from rew_out
+  const bool wide_rich_ok = d.plain || !(p.flags & DIRAL_F_ADD_REWARD) || p.state_out == nullptr || p.rew_out != nullptr;
+  d.use_fast64 = d.spec && e->vpl == 1 && p.A <= kFastMaxA && p.NV == 64;
+  d.use_wide = d.spec && e->vpl > 1 && p.A <= kWideMaxA && e->flat_y && wide_rich_ok;
+  d.design = p.mode == DIRAL_STEP_DESIGN;
+  d.prr = (p.flags & DIRAL_F_TRACK_PRR) && p.mode == DIRAL_STEP_MY_STEP;
+  d.notab = !(p.flags & DIRAL_F_ADD_POSDIST_PIGGY);          // no piggybacked tables: test_env.py:138-139, 231-238
+  d.nomove = !(p.flags & DIRAL_F_MOBILITY);                  // static (design) topology: network.py:302-305
+  d.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
+  d.trace = d.nomove ? nullptr : p.trace;
+  d.extra = d.design || d.la != nullptr || d.trace != nullptr || d.prr || d.notab || d.nomove;
+  d.pol_ok = d.use_fast64 && e->flat_y && !d.ch && !d.extra && p.N >= 8;
+  return d;
 }
 
 // `pol` / `fused`: diral_env_step_policy - when the configuration runs on the POL instantiation of step_fast64 the policy
@@ -331,13 +350,8 @@ bool policy_fusable(const DiralEnv* e, const StepParams& p) {
 hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, const PolParams* pol = nullptr, bool* fused = nullptr) {
   const int vpl = e->vpl;
   const bool flat_y = e->flat_y;
-  const bool spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
-  const bool plain = spec && is_plain_cfg(p);
-  const bool ch = p.mode == DIRAL_STEP_MY_STEP_CH;
-  // the wide kernels read the reward column of a RICH state back from rew_out
-  const bool wide_rich_ok = plain || !(p.flags & DIRAL_F_ADD_REWARD) || p.state_out == nullptr || p.rew_out != nullptr;
-  const bool use_fast64 = spec && vpl == 1 && p.A <= kFastMaxA && p.NV == 64;
-  const bool use_wide = spec && vpl > 1 && p.A <= kWideMaxA && flat_y && wide_rich_ok;
+  const StepDispatch d = step_dispatch(e, p);
+  const bool plain = d.plain, ch = d.ch, use_fast64 = d.use_fast64, use_wide = d.use_wide;
   // xpos ring (step_fast64.hpp): the N <= 64 kernel keeps the plane only for entries older than the ring reaches
   const bool use_ring = (use_fast64 || use_wide) && e->ring != nullptr;
   if (use_ring) {
@@ -352,12 +366,12 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     FastParams f;
     f.N = p.N; f.A = p.A; f.K = p.K; f.NR = p.NR; f.NV = p.NV; f.flags = p.flags;
     f.reward_design = p.reward_design; f.age_limit = p.age_limit; f.episode_interval = p.episode_interval;
-    f.design = (p.mode == DIRAL_STEP_DESIGN) ? 1 : 0;
+    f.design = d.design ? 1 : 0;
     f.done_now = (!p.t_dev && (p.t % p.episode_interval) == p.episode_interval - 1) ? 1 : 0;   // main_test.py:226 (with a slot clock: on the device)
-    f.prr = ((p.flags & DIRAL_F_TRACK_PRR) && p.mode == DIRAL_STEP_MY_STEP) ? 1 : 0;
-    f.notab = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) ? 0 : 1;     // no piggybacked tables: test_env.py:138-139, 231-238
-    f.nomove = (p.flags & DIRAL_F_MOBILITY) ? 0 : 1;             // static (design) topology: network.py:302-305
-    f.trace = f.nomove ? nullptr : p.trace;
+    f.prr = d.prr ? 1 : 0;
+    f.notab = d.notab ? 1 : 0;
+    f.nomove = d.nomove ? 1 : 0;
+    f.trace = d.trace;
     f.chobs_mode = (p.chobs_out ? 1 : 0) | ((p.mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ? 2 : 0);
     f.L = p.L; f.Rc = p.Rc; f.Rb = p.Rb; f.inv_w = p.hist_inv_width; f.t = p.t; f.t_dev = p.t_dev;
     f.actions = p.actions; f.pos_x = p.pos_x; f.pos_y = p.pos_y; f.vel = p.vel; f.tkey = p.tkey; f.tx = p.tx;
@@ -365,7 +379,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     f.ring = use_ring ? e->ring : nullptr;
     f.tcode = e->tcode; f.tage = e->tage; f.tseq = e->tseq; f.told = e->told;
     if (use_ring) e->plane_valid = false;
-    f.la = (p.flags & DIRAL_F_TRACK_ARRIVAL) ? p.la : nullptr;
+    f.la = d.la;
     f.trace_len = p.trace_len; f.trace_per_env = p.trace_per_env;
     f.state_out = p.state_out; f.rew_out = p.rew_out;
     f.done_out = p.done_out; f.dbg = p.dbg;
@@ -396,10 +410,12 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
         f.slow_cnt_z = set_z;
         ++e->slow_launches;
       }
-      // (a CAPTURED launch reads the set the last eager launch left - complete, never written by a replay - and builds
-      // none: a replayed graph could not rotate the sets - unless the caller keeps every graph at a multiple of three
-      // launches and its phase aligned: diral_env_set_capture_rotation.  The list ages with the replays - slow envs stay slow for
-      // hundreds of slots, profiles/launch_timeline.py - but stays a partition: every env runs exactly once.)
+      // (a CAPTURED launch reads the set it was baked with and builds none: a replayed graph could not rotate the sets -
+      // unless the caller keeps every graph at a multiple of three launches and its phase aligned:
+      // diral_env_set_capture_rotation.  Eager launches between two replays keep rotating through that set: they leave it
+      // either rebuilt or EMPTY - count and flags, step_fast64.hpp - never half cleared, so the replay runs every env
+      // exactly once whatever happened in between; the list it reads ages - slow envs stay slow for hundreds of slots,
+      // profiles/launch_timeline.py - or is empty, which costs time, not correctness.)
       slow_first = true;
     }
     RichParams r = rich_for(e, p);
@@ -408,7 +424,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     r.pf_threshold = p.pf_threshold; r.pf_penalty = p.pf_penalty;
     KernelSel k;
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
-    k.extra = f.design != 0 || f.la != nullptr || f.trace != nullptr || f.prr != 0 || f.notab != 0 || f.nomove != 0;   // EXTRA instantiation: the run-time switches compiled in
+    k.extra = d.extra;                                          // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
     k.packed = use_wide && vpl == 4 && e->tcode != nullptr;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
@@ -416,7 +432,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
     const int grid = p.B + (slow_first ? fast_slow_max(p.B) : 0);
-    if (pol && k.flat && !k.ch && !k.extra && p.N >= 8) {
+    if (pol && d.pol_ok) {
       // the policy epilogue: RICH instantiation (the channel observation is staged in LDS whether or not it is written out)
       if (!k.rich) { r.plain_state = 1; }
       e->last_kernel |= DIRAL_KERNEL_RICH | DIRAL_KERNEL_POLICY;
@@ -743,6 +759,7 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
                     void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   const size_t tab = (size_t)e->B * e->NR * e->NV;
@@ -781,6 +798,7 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   if (mode == DIRAL_STEP_MY_STEP_CH && (e->cfg.reward_design < 2 || e->cfg.reward_design > 4))
     return DIRAL_ERR_BAD_CONFIG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   StepParams p = e->base;
   p.mode = mode; p.t = t; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
   p.actions = actions;
@@ -810,6 +828,7 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   if (pol->shaped_out && (pol->shape_flags & 4) && (!pol->pen_counter || !pol->pen_prev_actions)) return DIRAL_ERR_BAD_ARG;
   if (e->A > kSpsWaveMaxA) return DIRAL_ERR_UNSUPPORTED;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   StepParams p = e->base;
   p.mode = mode; p.t = t; p.episode = 0.0; p.eps = 1.0; p.out_f64 = (out_dtype == DIRAL_F64);
   p.actions = actions;
@@ -825,14 +844,14 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   q.draw_counter = pol->draw_counter; q.draw_keep = pol->draw_keep; q.draw_choice = pol->draw_choice;
   q.seed = pol->seed; q.clock = (const long long*)pol->seed_clock; q.actions_out = pol->actions_out;
   // (decided before anything is launched: a caller without a channel-observation buffer can retry with one)
-  const bool will_fuse = policy_fusable(e, p);
+  const bool will_fuse = step_dispatch(e, p).pol_ok;
   if (!will_fuse && !chobs_out) return DIRAL_ERR_UNSUPPORTED;
   bool fused = false;
   HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, will_fuse ? &q : nullptr, &fused));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   if (fused) return DIRAL_OK;
   // the same slot as three launches (configurations the POL instantiation does not take)
-  if (!chobs_out) return DIRAL_ERR_HIP;                                      // (cannot happen: policy_fusable mirrors the dispatch)
+  if (!chobs_out) return DIRAL_ERR_HIP;                                      // (cannot happen: one step_dispatch decides both)
   if (pol->shaped_out) {
     const int st = diral_driver_shape(e->B, e->N, e->A, rew_out, out_dtype, actions, nullptr, nullptr, pol->pen_counter,
                                       pol->pen_prev_actions, pol->shape_flags, pol->pen_threshold, pol->pen_value,
@@ -850,6 +869,7 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
   if (e->S == 0) return DIRAL_OK;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   StepParams p = e->base;
   p.mode = kModeObserve; p.t = 0; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
   p.actions = actions; p.state_out = state_out;
@@ -865,6 +885,7 @@ int diral_env_update_velocity(DiralEnv* e, const uint8_t* draws, uint64_t seed, 
   if (!e) return DIRAL_ERR_BAD_ARG;
   if (!has(&e->cfg, DIRAL_F_MOBILITY_VARY)) return DIRAL_OK;   // test_env.py:503
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const size_t bn = (size_t)e->B * e->N;
   hipLaunchKernelGGL(velocity_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, draws,
                      seed, (uint64_t)e->env_offset * (uint64_t)e->N, e->vel);
@@ -875,6 +896,7 @@ int diral_env_update_velocity(DiralEnv* e, const uint8_t* draws, uint64_t seed, 
 int diral_env_sample(DiralEnv* e, int32_t* actions_out, uint64_t seed, void* stream) {
   if (!e || !actions_out) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const size_t bn = (size_t)e->B * e->N;
   hipLaunchKernelGGL(sample_kernel, dim3(blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, (int)bn, e->A, seed,
                      (uint64_t)e->env_offset * (uint64_t)e->N, actions_out);
@@ -886,6 +908,7 @@ int diral_env_info_age(DiralEnv* e, int64_t t, int32_t* out, void* stream) {
   if (!e || !out) return DIRAL_ERR_BAD_ARG;
   if (!e->la) return DIRAL_ERR_BAD_CONFIG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipLaunchKernelGGL(info_age_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, e->N, (long long)t, e->la, out);
   HIP_TRY(e, hipGetLastError());
   return DIRAL_OK;
@@ -895,6 +918,7 @@ int diral_env_export_state(DiralEnv* e, double* pos_x, double* pos_y, double* ve
                            int32_t* tab_age, double* tab_x, double* tab_y, int32_t* last_arrival, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   if (pos_x) HIP_TRY(e, hipMemcpyAsync(pos_x, e->pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
@@ -919,6 +943,7 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
                            const int32_t* last_arrival, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   const size_t bn = (size_t)e->B * e->N;
   if (pos_x) HIP_TRY(e, hipMemcpyAsync(e->pos_x, pos_x, bn * 8, hipMemcpyDeviceToDevice, s));
@@ -948,6 +973,7 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
 int diral_env_export_entries(DiralEnv* e, DiralNeighborEntry* entries, void* stream) {
   if (!e || !entries) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)e->B * e->N * e->N;
   HIP_TRY(e, ensure_plane(e, s));
@@ -960,6 +986,7 @@ int diral_env_export_entries(DiralEnv* e, DiralNeighborEntry* entries, void* str
 int diral_env_import_entries(DiralEnv* e, const DiralNeighborEntry* entries, void* stream) {
   if (!e || !entries) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)e->B * e->N * e->N;
   e->plane_valid = true;                                        // every entry of the plane is rewritten
@@ -974,6 +1001,7 @@ int diral_env_import_entries(DiralEnv* e, const DiralNeighborEntry* entries, voi
 int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_env, void* stream) {
   if (!e || T < 0) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(e, hipStreamSynchronize(s));               // no launch may still read the old copy
   if (e->trace) { (void)hipFree(e->trace); e->trace = nullptr; }
@@ -997,6 +1025,7 @@ int diral_env_set_trace(DiralEnv* e, const double* x_positions, int T, int per_e
 int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   const int total = e->B * DIRAL_M_COLUMNS;
   hipLaunchKernelGGL(metrics_kernel, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, total, e->metrics,
                      out, clear);
@@ -1011,6 +1040,7 @@ int diral_env_metrics(DiralEnv* e, double* out, int clear, void* stream) {
 int diral_env_debug_timing(DiralEnv* e, unsigned long long* host_out, int waves) {
   if (!e || !e->dbg || !host_out) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   if (hipDeviceSynchronize() != hipSuccess) return DIRAL_ERR_HIP;
   if (hipMemcpy(host_out, e->dbg, (size_t)e->B * waves * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return DIRAL_ERR_HIP;
   return DIRAL_OK;
@@ -1194,6 +1224,7 @@ int diral_sps_init(int agents, int selection_window, int32_t* prev_action, int32
 int diral_env_check(DiralEnv* e, void* stream) {
   if (!e) return DIRAL_ERR_BAD_ARG;
   DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   uint32_t flags = 0;
   HIP_TRY(e, hipMemcpyAsync(&flags, e->err, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));

@@ -106,15 +106,19 @@ struct FastParams {
   // does, so such a workgroup must not be among the last to START.  Every launch leaves, for the next one, the list of
   // the envs it found slow (`told` flags set for the next slot) and a flag per env; the next launch runs the listed envs
   // in its first fast_slow_max(B) blocks - dispatched first - and the block that would have taken such an env in dispatch
-  // order exits at once.  Three rotating sets (the host counts launches): read set r, build set r + 1, clear the count of
-  // set r + 2.  Null: blocks = envs in order (captured launches: a replayed graph does not rotate).
+  // order exits at once.  Three rotating sets (the host counts launches): read set r, build set r + 1, EMPTY set r + 2
+  // (its count and every env's flag: at every launch boundary each set is either a complete list or empty, so a launch
+  // that reads any of them - a captured launch replays against the set it was baked with, whatever the eager launches in
+  // between did to it - steps every env exactly once).  A captured launch gets the read set only (slow_*_w / _z null: a
+  // replayed graph cannot rotate), unless the graph rotates as a whole (diral_env_set_capture_rotation).
+  // slow_cnt_r null: blocks = envs in order (DIRAL_NO_SLOW_FIRST).
   const uint32_t* slow_cnt_r;     // [1] number of listed envs
   const uint32_t* slow_list_r;    // [fast_slow_max(B)]
   const uint32_t* slow_flag_r;    // [B] != 0: listed
   uint32_t* slow_cnt_w;
   uint32_t* slow_list_w;
   uint32_t* slow_flag_w;
-  uint32_t* slow_cnt_z;           // the count the launch after the next will build on: zeroed here
+  uint32_t* slow_cnt_z;           // the set [count | list | flags] the launch after the next will build: emptied here
 };
 // listed envs per launch (an env beyond that keeps its place in dispatch order): a quarter of the batch, 16 ... 4096
 #ifndef DIRAL_SLOW_SHIFT
@@ -1264,7 +1268,11 @@ __global__ __launch_bounds__(256, DIRAL_FAST_MINWAVES) void step_fast64_kernel(c
         if (pos < (unsigned int)fast_slow_max(ls->B)) { ls->slow_list_w[pos] = (unsigned int)b; fl = 1u; }
       }
       flag_w[b] = fl;
-      if (b == 0) *ls->slow_cnt_z = 0u;
+      // the set the launch after the next builds: count AND flags (a cleared count under standing flags would make a
+      // launch that still reads this set - a graph captured two launches ago - skip the flagged envs)
+      uint32_t* const set_z = ls->slow_cnt_z;
+      set_z[16 + fast_slow_max(ls->B) + b] = 0u;
+      if (b == 0) *set_z = 0u;
     }
   }
 

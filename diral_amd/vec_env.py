@@ -327,7 +327,23 @@ class VecV2VEnv:
         whatever `want_chobs` says).  `clock`: a rollout.SlotClock / int64 device tensor added to the policy's seed
         (`step_from_chobs_clocked` semantics, `seed_offset` as its `offset`); without it the policy's own step counter
         advances as in `step_from_chobs`."""
-        from .config import DiralSlotPolicy
+        from .config import DiralSlotPolicy, ERR_UNSUPPORTED
+        # raw pointers cross the C-ABI: what they point at is checked here (an int64 or strided tensor would be read as
+        # garbage; `actions_out` aliasing `actions` lets the fused kernel's policy wave overwrite actions the
+        # three-launch form still reads)
+        for name, a in (("actions", actions), ("actions_out", actions_out)):
+            if not isinstance(a, torch.Tensor) or a.dtype != torch.int32 or tuple(a.shape) != (self.B, self.N) \
+                    or not a.is_contiguous() or a.device != self.device:
+                raise ValueError("step_policy: %s must be a contiguous int32 tensor [%d, %d] on %s" %
+                                 (name, self.B, self.N, self.device))
+        if actions_out.data_ptr() == actions.data_ptr():
+            raise ValueError("step_policy: actions_out must not alias actions")
+        for name, a, shape in (("shaped_out", shaped_out, (self.B, self.N)), ("sum_r_out", sum_r_out, (self.B,)),
+                               ("collision_out", collision_out, (self.B,))):
+            if a is not None and (a.dtype != self.out_dtype or tuple(a.shape) != shape or not a.is_contiguous()
+                                  or a.device != self.device):
+                raise ValueError("step_policy: %s must be a contiguous %s tensor %s on %s" %
+                                 (name, self.out_dtype, shape, self.device))
         if self.io_ring > 1:
             self._ri = (self._ri + 1) % self.io_ring
         slot = self._ring[self._ri]
@@ -360,7 +376,7 @@ class VecV2VEnv:
                                                   _ptr(self._obs) if self.S > 0 else None, _ptr(self._rew), _ptr(self._done),
                                                   _ptr(chobs), self._dt, ctypes.byref(q), self._stream())
         st = call(use_chobs)
-        if st == -3 and use_chobs is None:               # DIRAL_ERR_UNSUPPORTED: not a fused configuration, nothing launched
+        if st == ERR_UNSUPPORTED and use_chobs is None:  # not a fused configuration, nothing launched
             self._policy_needs_chobs = True
             if slot["chobs"] is None:
                 slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)

@@ -1857,3 +1857,82 @@ def test_graph_replays_with_rotating_slow_sets_survive_eager_steps_in_between():
     for e, _, r in runs:
         e.check()
         r.close()
+
+
+@pytest.mark.parametrize("K", [10, 4])
+def test_graph_replays_on_a_frozen_slow_set_survive_eager_steps_in_between(K):
+    """A captured rollout whose launch count is NOT a multiple of three cannot rotate the slow-env sets: every captured
+    launch is baked with the set the last eager launch before the capture read.  Eager steps between two replays keep
+    rotating through that set - one of them clears it, the next rebuilds it.  A set must be either a complete list or
+    EMPTY at every launch boundary (count and flags: step_fast64.hpp), else a replay issued two eager steps after the
+    capture finds a zero count under standing flags and steps the flagged envs not at all.  One, two
+    and three eager steps between replays; against the same sequence without a graph, bit for bit; every env's slot
+    counter advanced by every launch.  Sticky actions keep a third of the envs on the list."""
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    N, A, B = 64, 32, 256
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2)
+    runs = []
+    for capture in (True, False):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32, io_ring=2)
+        env.reset_topology(seed=9)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=4)
+        pol.keep_prob = 0.95
+        # (eager warm-up first: the tables age, the lists fill - the capture then bakes a set with standing flags)
+        warm = [env.sample(seed=70 + i) for i in range(2)]
+        for i in range(40):
+            env._step(0, warm[i & 1], i, want_chobs=True)
+        ro = GraphRollout(env, pol, K=K, capture=capture)
+        assert ro._phase is None                                         # no rotation inside this graph
+        extra = [env.sample(seed=50 + i) for i in range(3)]
+        slots = 40 + K
+        ro.run(3 if capture else 4)                                      # (the capture ran its K slots once eagerly)
+        slots += 3 * K
+        for n_eager in (1, 2, 3, 2, 1):
+            for j in range(n_eager):
+                env._step(ro.mode, extra[j], j, want_chobs=True)
+            ro.run(2)
+            slots += n_eager + 2 * K
+            m = env.metrics()
+            assert float(m[:, 0].min()) == float(m[:, 0].max()) == float(slots), (capture, n_eager, m[:, 0].min(), slots)
+        env._step(ro.mode, extra[0], 3, want_chobs=True)                 # a last eager step: its outputs are compared
+        torch.cuda.synchronize()
+        runs.append((env, pol, ro))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    assert torch.equal(e1._obs, e2._obs) and torch.equal(e1._rew, e2._rew) and torch.equal(e1._chobs, e2._chobs)
+    m1, m2 = e1.metrics(), e2.metrics()
+    assert torch.equal(m1[:, [0, 2, 3]], m2[:, [0, 2, 3]])
+    for e, _, r in runs:
+        e.check()
+        r.close()
+
+
+def test_step_policy_rejects_tensors_the_c_abi_would_misread():
+    """`VecV2VEnv.step_policy` hands raw pointers to diral_env_step_policy: dtype, shape, contiguity, device and
+    aliasing of the action tensors are checked in Python."""
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    cfg = c2_config()
+    B, N, A = 8, cfg.num_users, cfg.num_channels
+    env = VecV2VEnv(cfg, batch=B, device="cuda:0")
+    env.reset_topology(seed=1)
+    pol = SpsPolicy(B, N, A, seed=2)
+    a = pol.prev_action.clone()
+    out = torch.empty_like(a)
+    with pytest.raises(ValueError):
+        env.step_policy(a.long(), 0, pol, out)
+    with pytest.raises(ValueError):
+        env.step_policy(a, 0, pol, a)
+    with pytest.raises(ValueError):
+        env.step_policy(a.t().contiguous().t(), 0, pol, out)
+    with pytest.raises(ValueError):
+        env.step_policy(a, 0, pol, out[:, : N - 1])
+    with pytest.raises(ValueError):
+        env.step_policy(a, 0, pol, out, shaped_out=torch.empty((B, N), dtype=torch.float64, device="cuda:0"))
+    env.step_policy(a, 0, pol, out)
+    env.check()
