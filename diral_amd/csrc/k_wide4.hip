@@ -13,18 +13,18 @@ struct LaunchWide {
   }
 };
 struct AttrWide {
-  int lds; hipError_t* st;
+  int lds, lds_packed; hipError_t* st;
   template <bool O, bool F, bool C, bool X, bool R, bool P>
   void operator()(std::integer_sequence<bool, O, F, C, X, R, P>) const {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(step_wide_kernel<V, O, F, C, X, R, P>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, P ? lds_packed : lds);
     if (e != hipSuccess) *st = e;
   }
 };
 }  // namespace
 
 hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s) {
-  const LaunchWide l{f, r, dim3(B), wide_lds_layout(V, f.A, f.K).total, s};
+  const LaunchWide l{f, r, dim3(B), wide_lds_layout(V, f.A, f.K, k.packed).total, s};
 #ifdef DIRAL_WIDE_BENCH_ONLY
   // tuning builds (profiles/build_variant.sh): only the instantiations the C3 bench line runs - seconds to compile
   if (k.out64 || !k.full || k.ch || k.extra) return hipErrorInvalidValue;
@@ -37,7 +37,7 @@ hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSe
 
 hipError_t set_attr_wide4(int A, int K) {
   hipError_t st = hipSuccess;
-  const AttrWide a{(int)wide_lds_layout(V, A, K).total, &st};
+  const AttrWide a{(int)wide_lds_layout(V, A, K, false).total, (int)wide_lds_layout(V, A, K, true).total, &st};
 #ifdef DIRAL_WIDE_BENCH_ONLY
   for (int m = 0; m < 4; ++m)
     bool_dispatch(a, std::integer_sequence<bool, false, true, false, false>{}, (m & 1) != 0, (m & 2) != 0);

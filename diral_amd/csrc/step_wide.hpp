@@ -36,7 +36,7 @@ namespace diral {
 constexpr int kWideMaxA = 64;
 
 struct WideLds {
-  uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, total;
+  uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, pbytes, lut, total;
 };
 #ifndef DIRAL_WIDE_WAVES4
 #define DIRAL_WIDE_WAVES4 8              // waves per workgroup at N <= 256 (each owns 256 / waves subject columns)
@@ -51,9 +51,11 @@ __host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DI
 #endif
 // merge scratch per wave: a pass's rank words (one byte per column and viewer), then the
 // rank -> xpos table (256 doubles)
+// (N <= 256: + 64 bytes in front of the lag -> xpos table of the packed form's finalize phase, whose lookup of a
+// never-heard entry - lag "-1" - lands 8 bytes below its column's row: csrc/step_wide_closure.inc)
 __host__ __device__ constexpr uint32_t wide_scratch(int vpl) {
   const uint32_t words = 64u * vpl * (vpl == 2 ? DIRAL_WIDE_PC2 : DIRAL_WIDE_PC4);
-  return words > 2048u ? words : 2048u;
+  return (words > 2048u ? words : 2048u) + (vpl == 4 ? 64u : 0u);
 }
 // histogram row stride in 32-bit words: two 16-bit bins per word (counts <= 255), odd stride
 __host__ __device__ constexpr int wide_hist_stride(int K) { return ((K + 1) / 2) | 1; }
@@ -63,7 +65,7 @@ __host__ __device__ constexpr int wide_hist_stride(int K) { return ((K + 1) / 2)
 // conflict-free at any stride
 __host__ __device__ constexpr int wide_mtab_stride(int vpl) { return vpl == 4 ? 65 : 66; }
 
-__host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
+__host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K, bool packed = false) {
   const uint32_t npad = 64u * vpl;
   WideLds l;
   // The per-wave merge scratch sits at LDS offset 0: wave W's words start at the COMPILE-TIME
@@ -71,6 +73,11 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K) {
   // offset of its gathers instead of adding a base register to every gather address.
   l.scratch = 0;
   uint32_t o = wide_scratch(vpl) * wide_waves(vpl);        // 2 KB per wave (4 KB at 16 columns per pass)
+  // the packed form's merge (step_wide_closure.inc), at compile-time addresses as well (DS immediate offsets): the
+  // reachability matrix P of the slot as bytes [viewer][lane half][K step] (8 KB at N = 256) and the 256-entry
+  // bits -> 8 x bf16 table of the product's B operand
+  l.pbytes = l.lut = o;
+  if (packed) { l.pbytes = o; o += 32u * npad; l.lut = o; o += 4096u; o += 32u * npad; }   // (+ the closure's own rows of P, 8 bytes x 4 waves per viewer)
   l.px = o;    o += 8u * npad;
   l.npx = o;   o += 8u * npad;
   l.rv = o;    o += 8u * A;
@@ -193,6 +200,19 @@ __device__ inline void unpack_src(unsigned int mw, unsigned int (&a)[VPL]) {
   }
 }
 
+// byte BYTE of a word of table indices, times 16: the LDS byte offset of that row of the bits -> 8 x bf16 table
+// (step_wide_closure.inc), shift and byte extraction in one SDWA instruction
+template <int BYTE>
+__device__ inline unsigned int lut_row(unsigned int w) {
+  unsigned int r;
+  static_assert(BYTE >= 0 && BYTE < 4, "byte select");
+  if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(4u), "v"(w));
+  if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(4u), "v"(w));
+  if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(4u), "v"(w));
+  if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(4u), "v"(w));
+  return r;
+}
+
 // Reward of a colliding resource (test_env.py:163-199) for N > 64, positions in
 // LDS, all y == 0.  Out of line: runs ~once per colliding resource.
 template <int VPL>
@@ -256,6 +276,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_MINWAVES4
 #define DIRAL_WIDE_MINWAVES4 6           // N <= 256: 84 VGPRs, three 512-thread workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_MINWAVES4P
+#define DIRAL_WIDE_MINWAVES4P 4          // ... the packed form: 128 VGPRs (the product's A operand alone takes 64), two workgroups per CU
+#endif
 
 // FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
@@ -268,7 +291,7 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 // by more than 7 stamps (sparse topologies, and configs[4] at N <= 128) every pass of the packed form would detour
 // through the planes - those handles keep the plane form.
 template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH, bool PACKED>
-__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : DIRAL_WIDE_MINWAVES4) void step_wide_kernel(const FastParams p, const RichParams r) {
+__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : (PACKED ? DIRAL_WIDE_MINWAVES4P : DIRAL_WIDE_MINWAVES4)) void step_wide_kernel(const FastParams p, const RichParams r) {
   static_assert(!PACKED || VPL == 4, "the packed pass exists for N > 128");
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   constexpr int NK = NW * VPL;                 // ... per lane
   // merge words in LDS: one NW-word vector per viewer, gathered with ONE 8-byte read per slot and step (the plane layout
   // [word][viewer] with 4-byte gathers was dropped: C5 +2 %)
-  static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= wide_scratch(VPL), "a pass's rank words fill at most the wave's scratch");
+  static_assert(PC % 4 == 0 && CPW % PC == 0 && NPAD * NW * 4 <= wide_scratch(VPL) && wide_scratch(VPL) % 16 == 0, "a pass's rank words fill at most the wave's scratch");
   constexpr uint32_t SCR = wide_scratch(VPL);
   static_assert(WAVES >= VPL && WAVES <= 8, "P2 runs on the first VPL waves; the merge loop has 8 per-wave copies");
   static_assert(8 * PC <= 64, "xpos ring: one lane per (column, lag) of a pass");
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     return *(const __attribute__((address_space(4))) double*)(late_kernarg_base() + off);
   };
   const double pL = late_f64(offsetof(FastParams, L)), pRc = late_f64(offsetof(FastParams, Rc)), pRb = late_f64(offsetof(FastParams, Rb));
-  const WideLds lay = wide_lds_layout(VPL, A, K);
+  const WideLds lay = wide_lds_layout(VPL, A, K, PACKED);
   double* s_px = reinterpret_cast<double*>(smem + lay.px);
   double* s_npx = reinterpret_cast<double*>(smem + lay.npx);
   double* s_rv = reinterpret_cast<double*>(smem + lay.rv);
@@ -648,245 +671,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // entries do; the 8-level codes cannot carry them, and the packed form's detour through the planes for such passes
   // costs more than it saves (C5 + 13 %, a sparse 256-vehicle highway + 60 %).
   if constexpr (PACKED) {
-  unsigned int passbits = 0u;                      // bit pch: a quad of pass pch was flagged when the slot began
-#ifndef DIRAL_WIDE_NO_PREFETCH
-  unsigned int pf_touch = 0u;
-#endif
-#pragma unroll 1
-  for (int pch = 0; pch < CPW / PC; ++pch) {
-#ifndef DIRAL_WIDE_NO_PREFETCH
-    asm volatile("" :: "v"(pf_touch));          // (the prefetch of the pass before, if any: see the finalize loop)
-#endif
-    const int kbase = wave * CPW + pch * PC;
-    if (kbase >= NRows) break;
-    if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
-    // The table is stored the way the merge wants it (round 3, as in step_fast64.hpp): per row-quad and viewer one word
-    // of four thermometer codes of the entries' lags (0 = never heard, or older than 7: then `tkey` holds its
-    // sequence number) and one word of four ages; `tseq` holds the subjects' own sequence numbers, `told` flags the
-    // quads with an entry beyond the codes.  A pass of PC columns = NW quads:
-    //  * clean quads: the stamp (vehicle.py:56-70) is a shift of the code words + a packed age increment, the merge
-    //    ORs the words, and what goes back to HBM are the merged code words and the age words - the planes `tkey` /
-    //    `tx` are neither read nor written, except where an entry reaches lag 7 (hand-over: sequence number to
-    //    `tkey`, xpos to `tx`, quad flagged);
-    //  * a flagged quad: the pass goes through the planes - its entries are written to `tkey` as (seq, age) words
-    //    (unstamped), the byte-rank / 32-bit pass of round 2 runs on them unchanged, and the packed words are
-    //    rebuilt from the words it leaves.  Rare, and kept apart so that the coded pass owns its registers.
-    const size_t qrow = (size_t)b * (NRows >> 2) + (kbase >> 2);
-    const global_ptr<unsigned int> tcrow = uniform_ptr(g_tcode, qrow * NV);
-    const global_ptr<unsigned int> tarow = uniform_ptr(g_tage, qrow * NV);
-    const global_ptr<unsigned int> tsrow = uniform_ptr(g_tseq, bR + kbase);
-    bool clean;
-    {
-      const global_ptr<const unsigned int> tof = uniform_ptr<const unsigned int>(g_told, qrow);
-      unsigned int anyold = 0u;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) anyold |= tof[w];
-      clean = __builtin_amdgcn_readfirstlane((int)anyold) == 0;
-    }
-    passbits |= (clean ? 0u : 1u) << pch;
-    if (!clean) continue;                        // (flagged passes: the second loop below)
-    unsigned int kp[NK], agew[NK];               // [word * VPL + slot]: 4 codes each; ages, same packing
-    unsigned int tkov;                           // lane c: column c's fresh sequence number of its subject
-    DIRAL_WCLOCK(tc0);
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        // (non-temporal, like the stores below: a word is read once and written once per slot, and whatever it would push out of
-        // L2 - the next pass's words on their way in, see the finalize loop - is worth more there: C3 reads 1.93 -> 1.70 GB)
-        kp[w * VPL + j] = __builtin_nontemporal_load(&tcrow[(unsigned int)(w * NV) + ul + 64u * j]);
-        agew[w * VPL + j] = __builtin_nontemporal_load(&tarow[(unsigned int)(w * NV) + ul + 64u * j]);
-      }
-    {
-      const unsigned int ts = tsrow[ul < (unsigned int)PC ? ul : 0u];
-      tkov = ul < (unsigned int)PC ? ts + 1u : 0u;
-      if (ul < (unsigned int)PC) tsrow[ul] = tkov;
-      ovf = ovf || (tkov >= (1u << 24) - 1u);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // Vehicle.periodic_update (vehicle.py:56-70): every lag + 1 (a shift), every age + 1 (saturating, packed), the
-    // own entry: lag 0 / age 0.  Padded viewer slots (u >= N) read whatever lies behind the row: masked to 0.
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        const bool uval = FULL || (lane + 64 * j < N);
-        const unsigned int c0 = uval ? kp[w * VPL + j] : 0u, a = uval ? agew[w * VPL + j] : 0u;
-        kp[w * VPL + j] = (c0 << 1) & 0xfefefefeu;
-        const unsigned int hi = a & 0x80808080u, lo = (a & 0x7f7f7f7fu) + 0x01010101u, sat = lo & hi;
-        agew[w * VPL + j] = (lo ^ hi) | sat | (sat - (sat >> 7));
-      }
-#pragma unroll
-    for (int c = 0; c < PC; ++c) {
-      const int k = kbase + c;
-      const bool own = (FULL || k < N) && (lane == (k & 63));
-      const unsigned int ob = own ? (0xffu << (8 * (c & 3))) : 0u;
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) {
-        if (j == (k >> 6)) {                       // wave-uniform: the slot that holds the subject's own entry
-          kp[(c >> 2) * VPL + j] |= ob;
-          agew[(c >> 2) * VPL + j] &= ~ob;
-        }
-      }
-    }
-    DIRAL_WCLOCK(tc1);
-    {
-      constexpr bool thermo = true;
-      unsigned int kp0[NK];                      // the codes before the merge
-#pragma unroll
-      for (int q = 0; q < NK; ++q) kp0[q] = kp[q];
-      // -- Vehicle.received_update for every (resource, rx), resources ascending:
-      //    rank[u] = max(rank[u], rank[m_i(u)]), 4 columns per word, byte-wise (SDWA)
-      {
-      // vector layout sv[viewer] = its NW words: ONE 8/16-byte gather per slot and step.  A step is a
-      // dependent chain (gather -> max -> write-back -> next gather, in-order LDS queue), so the
-      // wider pass halves the number of chains a wave walks per column.
-      typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
-      uvec* const sv = reinterpret_cast<uvec*>(sw);
-      auto put_slot = [&](int j) {
-        uvec t;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t[w] = kp[w * VPL + j];
-        sv[lane + 64 * j] = t;
-      };
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) put_slot(j);
-      wave_lds_order();
-      auto merge_loop = [&](auto wtag, auto ttag) {
-        constexpr int W = decltype(wtag)::value;
-        constexpr bool THERMO = decltype(ttag)::value;
-        const unsigned char* const swb = reinterpret_cast<const unsigned char*>(sw);
-        unsigned long long rem = actw;
-        unsigned int m_next = rem ? (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane] : 0u;
-        while (rem) {
-          const unsigned long long low = rem & (0ull - rem);     // this step's resource, as its bit
-          rem ^= low;
-          const unsigned int mw = m_next;
-          if (rem) m_next = (unsigned int)s_mtab[__builtin_ctzll(rem) * MT + lane];
-          // the words of this step's transmitters, as the earlier steps left them (a receiver that is no transmitter
-          // of i reads its OWN possibly stale words where it has no source: a subset of what it holds, a no-op)
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            if (VPL == 2 || (txs[j] & low)) put_slot(j);    // (N <= 128, two slots: the tests cost more than the stores they save)
-          }
-          wave_lds_order();
-          unsigned int v[NK], sa[VPL];
-          unpack_src<VPL, (NW == 2 ? 3u : 4u)>(mw, sa);
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const uvec g = W >= 0 ? *lds_at<uvec>(SCR * (W >= 0 ? W : 0) + sa[j]) : *reinterpret_cast<const uvec*>(swb + sa[j]);
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v[w * VPL + j] = g[w];
-          }
-          wave_lds_order();
-          if constexpr (THERMO) {
-#pragma unroll
-            for (int q = 0; q < NK; ++q) kp[q] |= v[q];
-          } else {
-            max_u8_words<NK>(kp, v);
-          }
-        }
-      };
-      auto merge_codes = [&](auto wtag) { merge_loop(wtag, std::true_type{}); };
-      DIRAL_WIDE_DISPATCH_WAVE(merge_codes);
-      }
-      DIRAL_WCLOCK(tc2);
-
-      // -- xpos by (subject, sequence number); histogram.  One column at a time (rolled: uniform byte
-      //    extraction).  The code -> xpos table of the column: the subject's 8 latest stamps from its ring row
-      //    (lane l < 8 * PC holds lag l & 7 of column l >> 3, loaded once per pass); EVERY coded entry reads its
-      //    xpos by its final code, a never-heard one (code 0) its ghost xpos from the plane.
-      double rg = 0.0;
-      {
-        const unsigned int rc = ul >> 3, rl = ul & 7u;
-        const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(rc << 2), (int)tkov);
-        if (rc < (unsigned int)PC) rg = ringp[(size_t)(bR + kbase + rc) * 8 + ((tkc - rl) & 7u)];
-      }
-      // ages of updated entries cleared with a byte mask of the code bytes that changed; the two words go back
-#pragma unroll
-      for (int q = 0; q < NK; ++q) {
-        const unsigned int x = kp[q] ^ kp0[q];
-        const unsigned int nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-        agew[q] &= ~(nz | (nz - (nz >> 7)));
-      }
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          if (FULL || lane + 64 * j < N) {
-            __builtin_nontemporal_store(kp[w * VPL + j], &tcrow[(unsigned int)(w * NV) + ul + 64u * j]);
-            __builtin_nontemporal_store(agew[w * VPL + j], &tarow[(unsigned int)(w * NV) + ul + 64u * j]);
-          }
-        }
-      bool handw[NW];                              // a lane handed an entry of the quad over (now 7 behind)
-#pragma unroll
-      for (int w = 0; w < NW; ++w) handw[w] = false;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-#ifndef DIRAL_WIDE_NO_PREFETCH
-      // The NEXT pass's code and age words requested towards L2 in front of this pass's last four columns: ONE load, every
-      // lane a dword of another 64-byte piece of the next pass's rows (lanes 0-31: the code words, 32-63: the age words;
-      // 2 KB each at N = 256), so that the next pass starts on L2 hits instead of an HBM round trip.  An ordinary load
-      // into `pf_touch`, "used" by an empty asm at the top of the next pass: the compiler keeps one register for it and
-      // knows what is in flight.  Placement matters: L2 turns over in ~10 us at this kernel's rate, and words requested
-      // before the merge (15 us earlier) were fetched TWICE (reads +1.0 GB, the second time from the Infinity Cache).
-      // Only with the channel observation (RICH): without it the launch is 2 % faster without the prefetch.
-      if (RICH && w == NW - 1 && pch + 1 < CPW / PC && kbase + PC < NRows) {
-        const unsigned int piece = 16u * (ul & 31u);                           // dword index: 64-byte pieces
-        const unsigned int* const nb = (ul < 32u ? (const unsigned int*)tcrow : (const unsigned int*)tarow) + (unsigned int)(NW * NV);
-        if (piece < (unsigned int)(NW * NV)) pf_touch = nb[piece];
-      }
-#endif
-#pragma unroll FIN_UNROLL
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = 4 * w + cc;
-        const int k = kbase + c;
-        const bool kvalid = FULL || k < N;
-        const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-        const global_ptr<double> txrow = uniform_ptr(p.tx, (bR + k) * NV);
-        const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-        const double pxk = s_px[kvalid ? k : 0];
-        if ((ul >> 3) == (unsigned int)c) {
-          // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
-          const unsigned int l = ul & 7u;
-          xt[(0xffu << l) & 0xffu] = (l == 0u) ? pxk : rg;
-          if (l == 0u && kvalid) ringp[(size_t)(bR + k) * 8 + (tk_own & 7u)] = pxk;
-        }
-        wave_lds_order();
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          const unsigned int rf = pick(kp, j, w, cc);
-          double xg = xt[rf];
-          const unsigned int age = pick(agew, j, w, cc);
-          if ((rf & 0x7fu) == 0u) {                                     // 0: never heard; 0x80: lag 7 - both rare, one test
-            if (rf == 0u) {                                             // never heard: the ghost xpos lives in the plane
-              xg = txrow[ul + 64u * j];
-              asm volatile("" : "+v"(xg));                                // (consumed inside the branch: see step_fast64.hpp)
-            } else if (FULL || (lane + 64 * j < N && kvalid)) {
-              // from the next slot on beyond the codes: hand over - sequence number (lag 7) and xpos go to the planes
-              tkrow[ul + 64u * j] = ((tk_own - 7u) << 8) | age;
-              txrow[ul + 64u * j] = xg;
-              handw[w] = true;
-            }
-          }
-          emit(k, kvalid, j, false, age, xg, tkrow, txrow, std::integral_constant<int, 3>{});
-        }
-        wave_lds_order();
-      }
-      }
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        if (__ballot(handw[w]) != 0ull && lane == 0) g_told[qrow + w] = 1u;
-      }
-    }
-#ifdef DIRAL_TIMING
-    DIRAL_WCLOCK(tc3);
-    acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
-#endif
-  }
-#ifndef DIRAL_WIDE_NO_PREFETCH
-  asm volatile("" :: "v"(pf_touch));
-#endif
+  // the coded merge + finalize of the clean passes: reachability closure + one bf16 product on the matrix pipe
+  // (leaves `passbits`: bit pch = a quad of pass pch was flagged when the slot began -> the loop below)
+#include "step_wide_closure.inc"
   // ---- flagged passes (a quad with an entry beyond the codes): through the planes, in a loop of their own so that
   //      the coded pass above carries none of this path's registers
 #pragma unroll 1

@@ -1,0 +1,816 @@
+// closure_merge.hip - go / no-go micro-benchmark: the gossip merge of one slot as
+// "reachability closure + ONE (max, x) product on the matrix pipe" against today's chain of gathers.
+//
+//   hipcc --offload-arch=gfx950 -O3 profiles/micro/closure_merge.hip -o /tmp/closure_merge && /tmp/closure_merge
+//
+// What is being compared.  Vehicle.received_update for every (resource, receiver), resources ascending (vehicle.py:35-47,
+// test_env.py:204-240), on the packed table of step_wide<4> / step_fast64 (one thermometer-code byte per
+// entry, subject-major words of four subjects): rows obey R_i = (I + E_i) R_{i-1} over (OR, AND), E_i having at most one
+// source per receiver (its closest in-range transmitter of resource i) and no row for the transmitters of i.  Hence
+//     final = P . stamped,   P = (I + E_A) ... (I + E_1),
+// an N x N BIT matrix that depends on actions and positions only.
+//   * today (`chain_*`): every wave walks the chain of active resources once per PASS of 8 subject columns (C3: 4 passes
+//     x 64 steps x [store the transmitters' words, gather 4 x 8 B, OR 8 words]).
+//   * closure (`closure_*`): the chain runs ONCE per env on bits - wave W carries the 32 source bits [32 W, 32 W + 32) of
+//     every viewer (one dword per viewer: a quarter of a pass step's bytes) -, then the apply step
+//         final[k][u] = max over w of P[u][w] * stamped[w][k]
+//     is one bf16 product per 16 subject columns on the idle matrix pipe: a code (0xff << lag) & 0xff travels as the
+//     power of two 2^(16 popcount - 127) (bf16 bits: popcount << 11), P as 0.0 / 1.0; a sum of at most 256 such terms has
+//     the exponent field 16 p ... 16 p + 8 of its largest term, so the merged code is (0xff00 >> (bits >> 27)) & 0xff -
+//     the (max, x) semiring read off the exponent of an ordinary f32 accumulation, exact whatever the rounding.
+//     A operand (subjects x sources): each lane loads the 8 consecutive source words of its subject's quad straight from
+//     the table (2 x 16 B per K step) and turns its byte into a bf16; B operand (sources x viewers): the lane's byte of
+//     P picks a 16-byte row of a 256-entry bits -> 8 x bf16 table in LDS (one ds_read_u8 + one ds_read_b128 per MFMA).
+//     The K index (source) is laid out identically in A and B, so the product does not depend on the hardware's K order.
+// Reported: bit equality of both kernels with a host restatement, cycles per wave of (chain) against (closure, A operand,
+// product + epilogue), and kernel time at the occupancy of step_wide<4> (512 threads, 52 KB of LDS, <= 84 VGPRs).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#define CHECK(call)                                                                                  \
+  do {                                                                                               \
+    hipError_t st__ = (call);                                                                        \
+    if (st__ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(st__)); std::exit(1); } \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct Args {
+  const unsigned int* mtab;            // [envs][A][64]: byte j = gather source of viewer lane + 64 j (itself: none)
+  const unsigned long long* actw;      // [envs] resources with a transmitter
+  const unsigned long long* txs;       // [envs][4] ... with a transmitter in viewer slot j
+  const unsigned int* codes;           // [envs][N / 4][N] stamped code words, subject-major
+  unsigned int* out;                   // [blocks][N / 4][N] merged code words
+  unsigned long long* dbg;             // [blocks][waves][4] s_memtime stamps
+  int envs;
+};
+
+__device__ inline void lds_order() { asm volatile("" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// C3 shapes: N = 256 vehicles, A = 64 resources, 8 waves x 32 subject columns, 4 viewers per lane
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int N3 = 256, A3 = 64, NQ3 = N3 / 4, MT3 = 65;
+constexpr unsigned int kScr3 = 16384u;     // per-wave scratch 8 x 2 KB (chain) / P bits 8 x 1 KB + bf16 table 4 KB (closure)
+constexpr unsigned int kLds3 = 52u * 1024u;   // what step_wide<4> occupies: three workgroups per CU
+
+__device__ inline void load_mtab3(const Args& p, int e, unsigned int* s_mtab, int tid) {
+  for (int i = tid; i < A3 * 64; i += 512) s_mtab[(i >> 6) * MT3 + (i & 63)] = p.mtab[(size_t)e * A3 * 64 + i];
+}
+
+// today's merge of step_wide<4, PACKED> (csrc/step_wide.hpp, merge_loop): per pass of 8 columns two words per viewer
+__global__ __launch_bounds__(512, 6) void chain_c3(const Args p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned int* const s_mtab = reinterpret_cast<unsigned int*>(smem + kScr3);
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  load_mtab3(p, e, s_mtab, tid);
+  const unsigned long long actw = p.actw[e];
+  unsigned long long txs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) txs[j] = p.txs[(size_t)e * 4 + j];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  u32x2* const sv = reinterpret_cast<u32x2*>(smem + 2048u * wave);
+  const unsigned char* const svb = reinterpret_cast<const unsigned char*>(sv);
+#pragma unroll 1
+  for (int pch = 0; pch < 4; ++pch) {
+    const int q0 = wave * 8 + pch * 2;
+    unsigned int kp[8];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kp[w * 4 + j] = p.codes[((size_t)e * NQ3 + q0 + w) * N3 + lane + 64 * j];
+    auto put_slot = [&](int j) {
+      u32x2 t;
+      t.x = kp[j]; t.y = kp[4 + j];
+      sv[lane + 64 * j] = t;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) put_slot(j);
+    lds_order();
+    unsigned long long rem = actw;
+    unsigned int m_next = rem ? s_mtab[__builtin_ctzll(rem) * MT3 + lane] : 0u;
+    while (rem) {
+      const unsigned long long low = rem & (0ull - rem);
+      rem ^= low;
+      const unsigned int mw = m_next;
+      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT3 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (txs[j] & low) put_slot(j);
+      lds_order();
+      unsigned int v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x2 g = *reinterpret_cast<const u32x2*>(svb + (((mw >> (8 * j)) & 255u) << 3));
+        v[j] = g.x; v[4 + j] = g.y;
+      }
+      lds_order();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kp[q] |= v[q];
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p.out[((size_t)b * NQ3 + q0 + w) * N3 + lane + 64 * j] = kp[w * 4 + j];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 8 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t1; d[3] = t1;
+  }
+}
+
+// closure + one product.  NATURAL: the merged words go back in the table's own lane = viewer arrangement (four
+// accumulator tiles transposed with v_permlane32_swap / v_permlane16_swap), as the finalize phase of the step kernel
+// wants them; otherwise straight from the accumulator layout (four 64-byte row pieces per store).
+template <bool NATURAL>
+__global__ __launch_bounds__(512, 6) void closure_c3(const Args p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned int* const s_mtab = reinterpret_cast<unsigned int*>(smem + kScr3);
+  u32x4* const lut = reinterpret_cast<u32x4*>(smem + 8192u);           // bits -> 8 x bf16 (0.0 / 1.0)
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  load_mtab3(p, e, s_mtab, tid);
+  if (tid < 256) {
+    u32x4 t;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      t[jj] = (((unsigned int)tid >> (2 * jj)) & 1u ? 0x3f80u : 0u) | (((unsigned int)tid >> (2 * jj + 1)) & 1u ? 0x3f800000u : 0u);
+    lut[tid] = t;
+  }
+  const unsigned long long actw = p.actw[e];
+  unsigned long long txs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) txs[j] = p.txs[(size_t)e * 4 + j];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  // ---- closure: P[u] restricted to the sources [32 wave, 32 wave + 32), one dword per viewer
+  {
+    unsigned int* const pl = reinterpret_cast<unsigned int*>(smem + 1024u * wave);
+    const unsigned char* const plb = reinterpret_cast<const unsigned char*>(pl);
+    unsigned int pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = lane + 64 * j;
+      pw[j] = (u >> 5) == wave ? 1u << (u & 31) : 0u;
+      pl[u] = pw[j];
+    }
+    lds_order();
+    unsigned long long rem = actw;
+    unsigned int m_next = rem ? s_mtab[__builtin_ctzll(rem) * MT3 + lane] : 0u;
+    while (rem) {
+      const unsigned long long low = rem & (0ull - rem);
+      rem ^= low;
+      const unsigned int mw = m_next;
+      if (rem) m_next = s_mtab[__builtin_ctzll(rem) * MT3 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (txs[j] & low) pl[lane + 64 * j] = pw[j];
+      lds_order();
+      unsigned int v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const unsigned int*>(plb + (((mw >> (8 * j)) & 255u) << 2));
+      lds_order();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw[j] |= v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pl[lane + 64 * j] = pw[j];
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long ta = 0, tm = 0;
+  // ---- apply: per pass of 16 subject columns D[subject][viewer] = sum over sources A[subject][source] B[source][viewer]
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+    const int kbase = wave * 32 + pass * 16;
+    const int kk = kbase + c;                                    // A: this lane's subject (row of the product)
+    const unsigned int sh = 8u * (unsigned int)(kk & 3);
+    const unsigned int* const crow = p.codes + ((size_t)e * NQ3 + (kk >> 2)) * N3 + 8 * g;
+    u32x4 a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      // sources 32 s + 8 g + (0 .. 7): eight consecutive words of the subject's quad row
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(crow + 32 * s), w1 = *reinterpret_cast<const u32x4*>(crow + 32 * s + 4);
+      auto bf = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+        return ((unsigned int)__popc((lo >> sh) & 255u) << 11) | ((unsigned int)__popc((hi >> sh) & 255u) << 27);
+      };
+      a[s][0] = bf(w0.x, w0.y); a[s][1] = bf(w0.z, w0.w); a[s][2] = bf(w1.x, w1.y); a[s][3] = bf(w1.z, w1.w);
+    }
+    const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
+    ta += ta1 - ta0;
+    const unsigned char* const lutb = reinterpret_cast<const unsigned char*>(lut);
+    unsigned int res[4];
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const int u = 16 * t + c;                                    // B: this lane's viewer (column of the product)
+      const unsigned char* const pb = smem + ((unsigned int)u << 2) + g;   // byte g of P[s][u], s = 0 .. 7 at + 1024 s
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const unsigned int bits = pb[1024 * s];
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(lutb + (bits << 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+      }
+      // accumulator r = subject kbase + 4 g + r, viewer u: the four bytes of one code word
+      unsigned int word = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) word |= ((0xff00u >> (__float_as_uint(acc[r]) >> 27)) & 0xffu) << (8 * r);
+      if constexpr (!NATURAL) {
+        p.out[((size_t)b * NQ3 + (kbase >> 2) + g) * N3 + u] = word;
+      } else {
+        res[t & 3] = word;
+        if ((t & 3) == 3) {
+          // four tiles = viewers 64 j ... 64 j + 63: tile tt, 16-lane row g holds (quad g, viewers 16 tt + c); wanted:
+          // word q, row tt = (quad q, viewers 16 tt + c) - a 4 x 4 transpose of 16-lane rows across four registers
+          const auto s02 = __builtin_amdgcn_permlane32_swap(res[0], res[2], false, false);
+          const auto s13 = __builtin_amdgcn_permlane32_swap(res[1], res[3], false, false);
+          const auto n01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+          const auto n23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+          const int j = t >> 2;
+          unsigned int* const orow = p.out + ((size_t)b * NQ3 + (kbase >> 2)) * N3 + lane + 64 * j;
+          orow[0] = n01[0]; orow[N3] = n01[1]; orow[2 * N3] = n23[0]; orow[3 * N3] = n23[1];
+        }
+      }
+    }
+    tm += __builtin_amdgcn_s_memtime() - ta1;
+  }
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 8 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t1 + ta; d[3] = t1 + ta + tm;
+  }
+}
+
+
+// Second arrangement of the same algorithm (what the first one's cycle counts asked for):
+//  * the chain walks ALL A resources in groups of four, statically (an idle resource's row is the identity: a gather of
+//    the own word), the four source words of a group arrive with one ds_read_b128 of the gather table stored
+//    [lane][resource] (row stride 68 words: 16-byte aligned, conflict-free per quarter wave), the transmitter tests are
+//    one s_bitcmp1 each - no loop-carried scalar bookkeeping per step;
+//  * CW = chain words per wave: 1 (eight waves x 32 source bits), 2 (waves 0-3 x 64 bits, 8-byte gathers) or 4 (waves
+//    0-1 x 128 bits, 16-byte gathers) - the chain is a latency chain, wider steps cost the same time on fewer waves;
+//  * the closure leaves P as bytes [viewer][lane group][K step], so that the product's lane reads the eight table
+//    indices of a 16-viewer tile with ONE ds_read_b64, and the eight bf16 rows are requested back to back
+//    (v_lshlrev_b32_sdwa builds each address from its byte) in front of the eight MFMAs.
+constexpr int ML3 = 68;                       // gather table [lane][resource] row stride (words)
+constexpr unsigned int kPb3 = 8192u;          // P bytes [256][4][8]
+constexpr unsigned int kLut3 = 16384u;        // bits -> 8 x bf16 table (4 KB)
+constexpr unsigned int kMt3 = 20480u;         // gather table [64][68] words
+template <int BYTE>
+__device__ inline unsigned int lut_addr(unsigned int w) {
+  unsigned int r;
+  if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(4u), "v"(w));
+  if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(4u), "v"(w));
+  return r;
+}
+template <int CW>
+__global__ __launch_bounds__(512, 6) void closure2_c3(const Args p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned int* const s_mt = reinterpret_cast<unsigned int*>(smem + kMt3);
+  u32x4* const lut = reinterpret_cast<u32x4*>(smem + kLut3);
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < A3 * 64; i += 512) s_mt[(i & 63) * ML3 + (i >> 6)] = p.mtab[(size_t)e * A3 * 64 + i];
+  if (tid < 256) {
+    u32x4 t;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      t[jj] = (((unsigned int)tid >> (2 * jj)) & 1u ? 0x3f80u : 0u) | (((unsigned int)tid >> (2 * jj + 1)) & 1u ? 0x3f800000u : 0u);
+    lut[tid] = t;
+  }
+  unsigned long long txs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) txs[j] = p.txs[(size_t)e * 4 + j];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 8 / CW) {
+    // ---- closure: P[u] restricted to the sources [32 CW wave, 32 CW (wave + 1)), CW dwords per viewer
+    typedef unsigned int cvec __attribute__((ext_vector_type(CW)));
+    cvec* const pl = reinterpret_cast<cvec*>(smem + 1024u * CW * wave);
+    const unsigned char* const plb = reinterpret_cast<const unsigned char*>(pl);
+    cvec pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = lane + 64 * j;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) pw[j][w] = (u >> 5) == wave * CW + w ? 1u << (u & 31) : 0u;
+      pl[u] = pw[j];
+    }
+    lds_order();
+    const u32x4* const mrow = reinterpret_cast<const u32x4*>(s_mt + lane * ML3);
+    u32x4 mq = mrow[0];
+#pragma unroll 1
+    for (int g4 = 0; g4 < A3 / 4; ++g4) {
+      const u32x4 cur = mq;
+      if (g4 + 1 < A3 / 4) mq = mrow[g4 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned int mw = cur[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((txs[j] >> r) & 1ull) pl[lane + 64 * j] = pw[j];
+        lds_order();
+        cvec v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const cvec*>(plb + (((mw >> (8 * j)) & 255u) * (4u * CW)));
+        lds_order();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pw[j] |= v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) txs[j] >>= 4;
+    }
+    // P as bytes [viewer][lane group g][K step s]: byte g of dword s of the viewer's row
+    unsigned char* const pbytes = smem + kPb3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = lane + 64 * j;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) pbytes[(u * 4 + gg) * 8 + wave * CW + w] = (unsigned char)(pw[j][w] >> (8 * gg));
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long ta = 0, tm = 0;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+    const int kbase = wave * 32 + pass * 16;
+    const int kk = kbase + c;
+    const unsigned int sh = 8u * (unsigned int)(kk & 3);
+    const unsigned int* const crow = p.codes + ((size_t)e * NQ3 + (kk >> 2)) * N3 + 8 * g;
+    u32x4 a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(crow + 32 * s), w1 = *reinterpret_cast<const u32x4*>(crow + 32 * s + 4);
+      auto bf = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+        return ((unsigned int)__popc((lo >> sh) & 255u) << 11) | ((unsigned int)__popc((hi >> sh) & 255u) << 27);
+      };
+      a[s][0] = bf(w0.x, w0.y); a[s][1] = bf(w0.z, w0.w); a[s][2] = bf(w1.x, w1.y); a[s][3] = bf(w1.z, w1.w);
+    }
+    const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
+    ta += ta1 - ta0;
+    const unsigned char* const lutb = smem + kLut3;
+    const u32x2* const prow = reinterpret_cast<const u32x2*>(smem + kPb3) + (c * 4 + g);   // + 64 t: the next 16 viewers
+    unsigned int res[4];
+    u32x2 idx = prow[0];
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const u32x2 cur = idx;
+      if (t + 1 < 16) idx = prow[64 * (t + 1)];
+      const int u = 16 * t + c;
+      u32x4 bv[8];
+      bv[0] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<0>(cur.x));
+      bv[1] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<1>(cur.x));
+      bv[2] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<2>(cur.x));
+      bv[3] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<3>(cur.x));
+      bv[4] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<0>(cur.y));
+      bv[5] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<1>(cur.y));
+      bv[6] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<2>(cur.y));
+      bv[7] = *reinterpret_cast<const u32x4*>(lutb + lut_addr<3>(cur.y));
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, bv[s]), acc, 0, 0, 0);
+      unsigned int word = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) word |= ((0xff00u >> (__float_as_uint(acc[r]) >> 27)) & 0xffu) << (8 * r);
+      res[t & 3] = word;
+      if ((t & 3) == 3) {
+        const auto s02 = __builtin_amdgcn_permlane32_swap(res[0], res[2], false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(res[1], res[3], false, false);
+        const auto n01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const auto n23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        const int j = t >> 2;
+        unsigned int* const orow = p.out + ((size_t)b * NQ3 + (kbase >> 2)) * N3 + lane + 64 * j;
+        orow[0] = n01[0]; orow[N3] = n01[1]; orow[2 * N3] = n23[0]; orow[3 * N3] = n23[1];
+      }
+      (void)u;
+    }
+    tm += __builtin_amdgcn_s_memtime() - ta1;
+  }
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 8 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t1 + ta; d[3] = t1 + ta + tm;
+  }
+}
+
+
+// Third arrangement: the product on 32 x 32 x 16 tiles - ALL 32 subject columns of the wave against 32 viewers per
+// tile - so that a 16-byte row of the bits -> bf16 table feeds twice the multiply-adds (the table reads are what loads
+// LDS in the second arrangement).  The A operand of the whole K range then takes 64 VGPRs: a 128-register kernel, four
+// waves per SIMD, two workgroups per CU (LDS request kLds3b).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr unsigned int kLds3b = 80u * 1024u;
+// MODE 0: the transmitters' words go to LDS under a test per viewer slot; 1: every slot stores every step (no scalar
+// tests or branches); 2: the rows live in LDS only - gather, then ds_or (no return) into the own row: no stores, no VALU OR
+template <int CW, int MODE>
+__global__ __launch_bounds__(512, 4) void closure3_c3(const Args p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned int* const s_mt = reinterpret_cast<unsigned int*>(smem + kMt3);
+  u32x4* const lut = reinterpret_cast<u32x4*>(smem + kLut3);
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < A3 * 64; i += 512) s_mt[(i & 63) * ML3 + (i >> 6)] = p.mtab[(size_t)e * A3 * 64 + i];
+  if (tid < 256) {
+    u32x4 t;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      t[jj] = (((unsigned int)tid >> (2 * jj)) & 1u ? 0x3f80u : 0u) | (((unsigned int)tid >> (2 * jj + 1)) & 1u ? 0x3f800000u : 0u);
+    lut[tid] = t;
+  }
+  unsigned long long txs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) txs[j] = p.txs[(size_t)e * 4 + j];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 8 / CW) {
+    typedef unsigned int cvec __attribute__((ext_vector_type(CW)));
+    cvec* const pl = reinterpret_cast<cvec*>(smem + 1024u * CW * wave);
+    const unsigned char* const plb = reinterpret_cast<const unsigned char*>(pl);
+    cvec pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = lane + 64 * j;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) pw[j][w] = (u >> 5) == wave * CW + w ? 1u << (u & 31) : 0u;
+      pl[u] = pw[j];
+    }
+    lds_order();
+    const u32x4* const mrow = reinterpret_cast<const u32x4*>(s_mt + lane * ML3);
+    u32x4 mq = mrow[0];
+#pragma unroll 1
+    for (int g4 = 0; g4 < A3 / 4; ++g4) {
+      const u32x4 cur = mq;
+      if (g4 + 1 < A3 / 4) mq = mrow[g4 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned int mw = cur[r];
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((txs[j] >> r) & 1ull) pl[lane + 64 * j] = pw[j];
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pl[lane + 64 * j] = pw[j];
+        }
+        lds_order();
+        cvec v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const cvec*>(plb + (((mw >> (8 * j)) & 255u) * (4u * CW)));
+        lds_order();
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (CW == 1) {
+              __hip_atomic_fetch_or(reinterpret_cast<unsigned int*>(&pl[lane + 64 * j]), v[j][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              unsigned long long* const row = reinterpret_cast<unsigned long long*>(&pl[lane + 64 * j]);
+#pragma unroll
+              for (int w = 0; w < CW; w += 2)
+                __hip_atomic_fetch_or(row + (w >> 1), ((unsigned long long)v[j][w + 1] << 32) | v[j][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          lds_order();
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pw[j] |= v[j];
+        }
+      }
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) txs[j] >>= 4;
+      }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pw[j] = pl[lane + 64 * j];
+    }
+    // P as bytes [viewer][lane half g2][K step s]: byte 2 s + g2 of the viewer's 32-byte row (sources 16 s + 8 g2 + 0..7)
+    unsigned char* const pbytes = smem + kPb3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = lane + 64 * j;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int byte = 4 * (wave * CW + w) + bb;                 // of the row
+          pbytes[(u * 2 + (byte & 1)) * 16 + (byte >> 1)] = (unsigned char)(pw[j][w] >> (8 * bb));
+        }
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const int n = lane & 31, g2 = lane >> 5;
+  const int kbase = wave * 32;
+  const int kk = kbase + n;                                      // A: this lane's subject
+  const unsigned int sh = 8u * (unsigned int)(kk & 3);
+  const unsigned int* const crow = p.codes + ((size_t)e * NQ3 + (kk >> 2)) * N3 + 8 * g2;
+  u32x4 a[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const u32x4 w0 = *reinterpret_cast<const u32x4*>(crow + 16 * s), w1 = *reinterpret_cast<const u32x4*>(crow + 16 * s + 4);
+    auto bf = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+      return ((unsigned int)__popc((lo >> sh) & 255u) << 11) | ((unsigned int)__popc((hi >> sh) & 255u) << 27);
+    };
+    a[s][0] = bf(w0.x, w0.y); a[s][1] = bf(w0.z, w0.w); a[s][2] = bf(w1.x, w1.y); a[s][3] = bf(w1.z, w1.w);
+  }
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  const unsigned char* const lutb = smem + kLut3;
+  const u32x4* const prow = reinterpret_cast<const u32x4*>(smem + kPb3) + (n * 2 + g2);   // + 64 t: the next 32 viewers
+  unsigned int res[2][4];
+  u32x4 idx = prow[0];
+#pragma unroll 2
+  for (int t = 0; t < 8; ++t) {
+    const u32x4 cur = idx;
+    if (t + 1 < 8) idx = prow[64 * (t + 1)];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32x4 b0 = *reinterpret_cast<const u32x4*>(lutb + lut_addr<0>(cur[q]));
+      const u32x4 b1 = *reinterpret_cast<const u32x4*>(lutb + lut_addr<1>(cur[q]));
+      const u32x4 b2 = *reinterpret_cast<const u32x4*>(lutb + lut_addr<2>(cur[q]));
+      const u32x4 b3 = *reinterpret_cast<const u32x4*>(lutb + lut_addr<3>(cur[q]));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[4 * q + 0]), __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[4 * q + 1]), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[4 * q + 2]), __builtin_bit_cast(bf16x8, b2), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[4 * q + 3]), __builtin_bit_cast(bf16x8, b3), acc, 0, 0, 0);
+    }
+    // accumulator 4 i + r = subject kbase + 8 i + 4 g2 + r, viewer 32 t + n: word i = quad 2 i + g2 of the wave's eight
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned int word = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) word |= ((0xff00u >> (__float_as_uint(acc[4 * i + r]) >> 27)) & 0xffu) << (8 * r);
+      res[t & 1][i] = word;
+    }
+    if (t & 1) {
+      const int j = t >> 1;
+      unsigned int* const orow = p.out + ((size_t)b * NQ3 + (kbase >> 2)) * N3 + lane + 64 * j;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(res[0][i], res[1][i], false, false);
+        orow[(2 * i) * N3] = sw[0];
+        orow[(2 * i + 1) * N3] = sw[1];
+      }
+    }
+  }
+  const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 8 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host: topologies, tables, the restatement
+// ------------------------------------------------------------------------------------------------------------------
+struct HostEnv {
+  std::vector<unsigned int> mtab;          // [A][64]
+  unsigned long long actw;
+  unsigned long long txs[4];
+  std::vector<unsigned int> codes;         // [N / 4][N]
+  std::vector<unsigned int> merged;        // host result
+};
+
+// Network.find_closest_tx (network.py:378-398): ascending id, strict '<', in range
+static void make_env(HostEnv& h, int N, int A, double L, double Rc, std::mt19937_64& rng) {
+  std::vector<double> x(N);
+  std::vector<int> act(N);
+  for (int u = 0; u < N; ++u) { x[u] = (double)(rng() % (unsigned long long)L); act[u] = (int)(rng() % (unsigned long long)A); }
+  const int slots = (N + 63) / 64;
+  h.mtab.assign((size_t)A * 64, 0u);
+  h.actw = 0ull;
+  for (int j = 0; j < 4; ++j) h.txs[j] = 0ull;
+  std::vector<int> src((size_t)A * N);
+  for (int i = 0; i < A; ++i) {
+    bool any = false;
+    for (int u = 0; u < N; ++u) {
+      int best = u;
+      if (act[u] != i) {
+        double bd = 1e30;
+        for (int w = 0; w < N; ++w) {
+          if (act[w] != i) continue;
+          const double d = std::fabs(x[w] - x[u]);
+          if (d < Rc && d < bd) { bd = d; best = w; }
+        }
+      } else {
+        any = true;
+        h.txs[u >> 6] |= 1ull << i;
+      }
+      src[(size_t)i * N + u] = best;
+    }
+    if (any) h.actw |= 1ull << i;
+    for (int l = 0; l < 64; ++l) {
+      unsigned int mw = 0u;
+      for (int j = 0; j < slots; ++j) mw |= (unsigned int)(src[(size_t)i * N + l + 64 * j] & 255) << (8 * j);
+      h.mtab[(size_t)i * 64 + l] = mw;
+    }
+  }
+  // stamped codes: the own entry at lag 0, the others 1 ... 7 stamps behind (mostly 1 ... 4) or never heard
+  std::vector<unsigned char> row((size_t)N * N);    // [viewer][subject]
+  for (int u = 0; u < N; ++u)
+    for (int k = 0; k < N; ++k) {
+      unsigned char cde;
+      if (u == k) cde = 0xff;
+      else {
+        const unsigned int r = (unsigned int)(rng() & 1023u);
+        const int lag = r < 40 ? -1 : 1 + (r < 400 ? 0 : r < 700 ? 1 : r < 880 ? 2 : r < 960 ? 3 : r < 1000 ? 4 : r < 1015 ? 5 : 6);
+        cde = lag < 0 ? 0 : (unsigned char)((0xffu << lag) & 0xffu);
+      }
+      row[(size_t)u * N + k] = cde;
+    }
+  h.codes.assign((size_t)(N / 4) * N, 0u);
+  for (int k = 0; k < N; ++k)
+    for (int u = 0; u < N; ++u) h.codes[(size_t)(k >> 2) * N + u] |= (unsigned int)row[(size_t)u * N + k] << (8 * (k & 3));
+  // received_update, resources ascending; a transmitter of i is no receiver of i, so in place is exact
+  for (int i = 0; i < A; ++i) {
+    if (!((h.actw >> i) & 1ull)) continue;
+    for (int u = 0; u < N; ++u) {
+      const int s = src[(size_t)i * N + u];
+      if (s == u) continue;
+      for (int k = 0; k < N; ++k) row[(size_t)u * N + k] |= row[(size_t)s * N + k];
+    }
+  }
+  h.merged.assign((size_t)(N / 4) * N, 0u);
+  for (int k = 0; k < N; ++k)
+    for (int u = 0; u < N; ++u) h.merged[(size_t)(k >> 2) * N + u] |= (unsigned int)row[(size_t)u * N + k] << (8 * (k & 3));
+}
+
+struct Phase { double v[3]; };
+static Phase phases(const std::vector<unsigned long long>& dbg, int blocks, int waves) {
+  Phase ph{{0, 0, 0}};
+  for (int i = 0; i < blocks * waves; ++i)
+    for (int k = 0; k < 3; ++k) ph.v[k] += (double)(dbg[(size_t)i * 4 + k + 1] - dbg[(size_t)i * 4 + k]);
+  for (int k = 0; k < 3; ++k) ph.v[k] /= (double)(blocks * waves);
+  return ph;
+}
+
+int main(int argc, char** argv) {
+  const int envs = 64;
+  const int blocks_loaded = argc > 1 ? std::atoi(argv[1]) : 8192;
+  std::mt19937_64 rng(20260929);
+  // ---------------- C3 ----------------
+  std::vector<HostEnv> he(envs);
+  for (auto& h : he) make_env(h, N3, A3, 4000.0, 250.0, rng);
+  std::vector<unsigned int> mtab, codes;
+  std::vector<unsigned long long> actw, txs;
+  for (auto& h : he) {
+    mtab.insert(mtab.end(), h.mtab.begin(), h.mtab.end());
+    codes.insert(codes.end(), h.codes.begin(), h.codes.end());
+    actw.push_back(h.actw);
+    for (int j = 0; j < 4; ++j) txs.push_back(h.txs[j]);
+  }
+  Args a;
+  unsigned int *d_mtab, *d_codes, *d_out;
+  unsigned long long *d_actw, *d_txs, *d_dbg;
+  const size_t out_words = (size_t)blocks_loaded * NQ3 * N3;
+  CHECK(hipMalloc(&d_mtab, mtab.size() * 4));
+  CHECK(hipMalloc(&d_codes, codes.size() * 4 + 4096));
+  CHECK(hipMalloc(&d_out, out_words * 4));
+  CHECK(hipMalloc(&d_actw, actw.size() * 8));
+  CHECK(hipMalloc(&d_txs, txs.size() * 8));
+  CHECK(hipMalloc(&d_dbg, (size_t)blocks_loaded * 8 * 4 * 8));
+  CHECK(hipMemcpy(d_mtab, mtab.data(), mtab.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_codes, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_actw, actw.data(), actw.size() * 8, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_txs, txs.data(), txs.size() * 8, hipMemcpyHostToDevice));
+  a.mtab = d_mtab; a.actw = d_actw; a.txs = d_txs; a.codes = d_codes; a.out = d_out; a.dbg = d_dbg; a.envs = envs;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_c3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure_c3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure_c3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure2_c3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure2_c3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure2_c3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(closure3_c3<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds3b));
+
+  auto check = [&](const char* name) -> bool {
+    std::vector<unsigned int> out((size_t)envs * NQ3 * N3);
+    CHECK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (int e = 0; e < envs; ++e)
+      for (size_t i = 0; i < (size_t)NQ3 * N3; ++i)
+        if (out[(size_t)e * NQ3 * N3 + i] != he[e].merged[i]) {
+          if (bad < 4) std::printf("  %s: env %d quad %zu viewer %zu: %08x, host %08x\n", name, e, i / N3, i % N3, out[(size_t)e * NQ3 * N3 + i], he[e].merged[i]);
+          ++bad;
+        }
+    std::printf("%-26s %s (%zu of %zu words differ from the host restatement)\n", name, bad ? "MISMATCH" : "bit-equal", bad, out.size());
+    return bad == 0;
+  };
+  auto run = [&](const char* name, auto kernel, int blocks, int iters, unsigned int lds = kLds3) -> double {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, 0, a);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, 0, a);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)name;
+    return (double)ms * 1000.0 / iters;
+  };
+  auto dbg_phases = [&](int blocks) -> Phase {
+    std::vector<unsigned long long> d((size_t)blocks * 8 * 4);
+    CHECK(hipMemcpy(d.data(), d_dbg, d.size() * 8, hipMemcpyDeviceToHost));
+    return phases(d, blocks, 8);
+  };
+
+  bool ok = true;
+  std::printf("== C3 shapes: N = 256, A = 64, 8 waves x 32 subject columns; %d distinct envs, %d workgroups loaded ==\n", envs, blocks_loaded);
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("chain_c3", chain_c3, envs, 1);
+  ok &= check("chain_c3 (today)");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure_c3", closure_c3<false>, envs, 1);
+  ok &= check("closure_c3");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure_c3<NATURAL>", closure_c3<true>, envs, 1);
+  ok &= check("closure_c3 natural layout");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure2_c3<1>", closure2_c3<1>, envs, 1);
+  ok &= check("closure2_c3 8 waves x 1 word");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure2_c3<2>", closure2_c3<2>, envs, 1);
+  ok &= check("closure2_c3 4 waves x 2 words");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure2_c3<4>", closure2_c3<4>, envs, 1);
+  ok &= check("closure2_c3 2 waves x 4 words");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure3_c3<2, 0>", closure3_c3<2, 0>, envs, 1, kLds3b);
+  ok &= check("closure3_c3 32x32 tiles, 4 x 2");
+  CHECK(hipMemset(d_out, 0, out_words * 4));
+  run("closure3_c3<4, 0>", closure3_c3<4, 0>, envs, 1, kLds3b);
+  ok &= check("closure3_c3 32x32 tiles, 2 x 4");
+#define CHK3(CWV, MD)                                                              \
+  CHECK(hipMemset(d_out, 0, out_words * 4));                                       \
+  run("closure3_c3", closure3_c3<CWV, MD>, envs, 1, kLds3b);                       \
+  ok &= check("closure3_c3 CW=" #CWV " MODE=" #MD);
+  CHK3(2, 1) CHK3(2, 2) CHK3(1, 1) CHK3(1, 2) CHK3(4, 1) CHK3(4, 2)
+
+  // lone workgroups (one per CU at most), then the loaded chip
+  for (int blocks : {64, blocks_loaded}) {
+    const double t_chain = run("chain_c3", chain_c3, blocks, 10);
+    const Phase pc = dbg_phases(blocks);
+    const double t_clo = run("closure_c3", closure_c3<false>, blocks, 10);
+    const Phase pn = dbg_phases(blocks);
+    const double t_nat = run("closure_c3<NATURAL>", closure_c3<true>, blocks, 10);
+    const Phase pt = dbg_phases(blocks);
+    std::printf("-- %d workgroups --\n", blocks);
+    std::printf("chain_c3            %9.1f us   cycles per wave: merge %8.0f\n", t_chain, pc.v[0]);
+    std::printf("closure_c3          %9.1f us   cycles per wave: closure %7.0f  A operand %7.0f  product + epilogue %7.0f  (sum %7.0f)\n",
+                t_clo, pn.v[0], pn.v[1], pn.v[2], pn.v[0] + pn.v[1] + pn.v[2]);
+    std::printf("closure_c3 natural  %9.1f us   cycles per wave: closure %7.0f  A operand %7.0f  product + epilogue %7.0f  (sum %7.0f)\n",
+                t_nat, pt.v[0], pt.v[1], pt.v[2], pt.v[0] + pt.v[1] + pt.v[2]);
+    std::printf("ratio closure / chain: kernel %.3f, cycles %.3f\n", t_nat / t_chain, (pt.v[0] + pt.v[1] + pt.v[2]) / pc.v[0]);
+    auto second = [&](const char* name, auto kernel, unsigned int lds = kLds3) {
+      const double t2 = run(name, kernel, blocks, 10, lds);
+      const Phase p2 = dbg_phases(blocks);
+      std::printf("%-19s %9.1f us   cycles per wave: closure %7.0f  A operand %7.0f  product + epilogue %7.0f  (sum %7.0f)  kernel ratio %.3f\n",
+                  name, t2, p2.v[0], p2.v[1], p2.v[2], p2.v[0] + p2.v[1] + p2.v[2], t2 / t_chain);
+    };
+    second("closure2_c3 8x1", closure2_c3<1>);
+    second("closure2_c3 4x2", closure2_c3<2>);
+    second("closure2_c3 2x4", closure2_c3<4>);
+    second("closure3_c3 4x2 (2 WG/CU)", closure3_c3<2, 0>, kLds3b);
+    second("closure3_c3 2x4 (2 WG/CU)", closure3_c3<4, 0>, kLds3b);
+    second("closure3 4x2 all-store", closure3_c3<2, 1>, kLds3b);
+    second("closure3 4x2 ds_or", closure3_c3<2, 2>, kLds3b);
+    second("closure3 8x1 all-store", closure3_c3<1, 1>, kLds3b);
+    second("closure3 8x1 ds_or", closure3_c3<1, 2>, kLds3b);
+    second("closure3 2x4 all-store", closure3_c3<4, 1>, kLds3b);
+    second("closure3 2x4 ds_or", closure3_c3<4, 2>, kLds3b);
+  }
+  std::printf(ok ? "ALL EQUAL\n" : "FAILED\n");
+  return ok ? 0 : 1;
+}
