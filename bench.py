@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_PACKED, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
                               bench_config)
 from diral_amd.metrics import gather_metrics  # noqa: E402
-from diral_amd.roofline import (HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot,  # noqa: E402
+from diral_amd.roofline import (HBM_ACHIEVABLE_GBPS, HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot, memory_level,  # noqa: E402
                                 layout_bytes_per_env_slot)
 from diral_amd.spawn import check_visible_gpus, spawn_ranks, under_launcher  # noqa: E402
 from diral_amd.vec_env import VecV2VEnv  # noqa: E402
@@ -250,6 +250,16 @@ def roofline_object(res, pmc):
         "pmc_current": (pmc.get("csrc_sha") == csrc_digest()) if pmc and pmc.get("csrc_sha") else None,
         "pmc_note": "traffic / valu_busy / clock_GHz come from the committed rocprofv3 --pmc passes of this command "
                     "(separate runs; counter_frac uses the kernel time of those passes), not from this run" if pmc else None,
+        # frac is a fraction of the 8 TB/s SPEC; the copy rate the guide measured is 6.29 TB/s
+        "frac_of_achievable": res["layout_rate_GBps"] / HBM_ACHIEVABLE_GBPS,
+        # HBM or Infinity Cache?  No gfx950 counter tells a MALL hit from a DRAM access (rocprofv3 --list-avail:
+        # TCC_EA0_RDREQ_DRAM counts requests "destined for DRAM (MC)", the memory-side cache sits behind that interface),
+        # so the line says what CAN be cache-resident: `memory.reads_served_by`, and DRAM fraction bounds - the outputs
+        # alone (streamed, never read back: they reach HBM) ... every layout byte
+        "memory": res.get("memory"),
+        "dram_frac_bounds": ([res["memory"]["output_bytes"] / k_s / 1e9 / HBM_PEAK_GBPS, res["layout_rate_GBps"] / HBM_PEAK_GBPS]
+                             if res.get("memory") and res["memory"]["resident_bytes"] <= res["memory"]["infinity_cache_bytes"]
+                             else [res["layout_rate_GBps"] / HBM_PEAK_GBPS] * 2) if res.get("memory") else None,
         "model_bytes_per_launch": res["algorithmic_bytes_per_launch"],
         "model_throughput_TBps": res["algorithmic_bytes_per_launch"] / k_s / 1e12,
         "model_note": "SURVEY 8d's canonical byte model (16-byte table entry read + written) over the kernel time: a throughput "
@@ -347,6 +357,7 @@ def run_workload(name, device, rank, world, steps, warmup, batch=0, out_dtype="f
         "kernel": kernel_name(code, N, out_dtype), "kernel_code": code,
         "algorithmic_bytes_per_launch": bytes_launch, "emit_chobs": bool(emit_chobs),
         "layout_bytes_per_launch": layout_launch,
+        "memory": memory_level(N, A, cfg.state_space, B, emit_chobs, 8 if out_dtype == "f64" else 4, packed=bool(code & KERNEL_PACKED)),
         "layout_rate_GBps": layout_launch / (kernel_ms * 1e-3) / 1e9,
         "preroll_slots": preroll, "wall_this_rank": wall_local,
     }

@@ -21,6 +21,8 @@ it plus the register-spill scratch of the kernel, profiles/README.md).  bench.py
 the layout figure over the kernel time is the real HBM rate.
 """
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+HBM_ACHIEVABLE_GBPS = 6290.0   # measured float4 copy (MI355X_MICROARCH.md: 79 % of the spec)
+INFINITY_CACHE_BYTES = 256 << 20   # die-level L3 in front of HBM (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
@@ -46,3 +48,26 @@ def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_byte
     entry = 2 if packed else 4
     table = 2 * entry * n * n + 64 * n + 8 * n + (8 * n if packed else 0)
     return table + n * (4 + 16 + 8 + 8) + out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0)
+
+
+def resident_bytes_per_env(n: int, packed=None) -> int:
+    """The state a launch RE-READS from the launch before - stored table words (read and written in place), ring rows, own
+    sequence numbers, per-vehicle arrays: what must survive in a cache between two launches for the reads of the second
+    not to reach DRAM.  The outputs are written once and never read back by the kernels."""
+    if packed is None:
+        packed = packed_table(n)
+    entry = 2 if packed else 4
+    return entry * n * n + 64 * n + (4 * n if packed else 0) + n * (4 + 8 + 8 + 8)
+
+
+def memory_level(n: int, a: int, s: int, batch: int, emit_chobs: bool, out_bytes: int = 4, packed=None) -> dict:
+    """Where the bytes of one launch can come from / go to: `resident` = batch x resident_bytes_per_env against the 256 MiB
+    Infinity Cache.  The rocprofv3 FETCH_SIZE / WRITE_SIZE counters (and the layout bytes) count requests at the L2 <->
+    fabric interface: when the resident state fits the Infinity Cache they are FABRIC bytes - an upper bound on DRAM
+    traffic - and only the outputs (streamed, never read back) certainly reach HBM."""
+    resident = batch * resident_bytes_per_env(n, packed)
+    outputs = batch * (out_bytes * n + out_bytes * n * s + (out_bytes * n * a if emit_chobs else 0))
+    fits = resident <= INFINITY_CACHE_BYTES
+    return {"resident_bytes": resident, "output_bytes": outputs, "infinity_cache_bytes": INFINITY_CACHE_BYTES,
+            "reads_served_by": "infinity cache (resident state fits: fabric bytes, an upper bound on DRAM reads)" if fits
+                               else "hbm (resident state exceeds the Infinity Cache)"}

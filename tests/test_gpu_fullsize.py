@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GLOBAL_SEED = 1234      # bench.py's
 
 
-def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32, env_offset=0):
+def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32, env_offset=0, n_gap=0, min_slow=0):
     from diral_amd.vec_env import VecV2VEnv
     from oracle.oracle import Oracle, SQ_IEEE
     cfg = bench_config(N, A, L, mobility_vary=vary)
@@ -25,7 +25,18 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32,
     env.reset_topology(seed=GLOBAL_SEED)                    # the device draws bench.py uses
     st0 = env.export_state(tables=False)
     rng = np.random.default_rng(N * 1000 + A)
-    sample = np.sort(rng.choice(B, size=n_sample, replace=False))
+    sample = rng.choice(B, size=n_sample, replace=False)
+    if n_gap:
+        # ... and the envs the kernel's scheduler treats specially: a highway with a gap wider than the communication range
+        # keeps the tables on either side stale - entries beyond the 8-level codes, quads on the keyed path, the env on the
+        # slow-first list (csrc/step_fast64.hpp).  The n_gap widest gaps of the batch (no wrap-around: network.py:318-332).
+        xs = torch.sort(st0["pos_x"], dim=1).values
+        gap = (xs[:, 1:] - xs[:, :-1]).max(dim=1).values
+        widest = torch.argsort(gap, descending=True)[:n_gap].cpu().numpy()
+        assert float(gap[int(widest[-1])]) > cfg.communication_range, "the batch holds no %d envs with a gap > Rc" % n_gap
+        sample = np.concatenate([sample, widest])
+    sample = np.unique(sample)
+    n_sample = len(sample)
     sample_t = torch.as_tensor(sample, device="cuda:0")
     orc = Oracle(cfg, batch=n_sample, sq_mode=SQ_IEEE, threads=8)
     orc.reset(st0["pos_x"][sample_t].cpu().numpy(), st0["pos_y"][sample_t].cpu().numpy(), st0["vel"][sample_t].cpu().numpy())
@@ -77,12 +88,25 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32,
     for k in ("pos_x", "vel", "seq", "x"):
         assert np.array_equal(st[k][sample_t].cpu().numpy(), oe[k]), k
     assert np.array_equal(st["age"][sample_t].cpu().numpy(), np.minimum(oe["age"], 255))
+    if min_slow:
+        # which envs ended the run on the slow list: an entry that was heard and lags its subject by 7 stamps or more flags
+        # its quad for the keyed path of the next slot (step_fast64.hpp `keep` / `hand`).  Enough of them were compared above.
+        seq = st["seq"]
+        beyond = ((seq > 0) & (diag.unsqueeze(1) - seq >= 7)).flatten(1).any(dim=1)
+        dense = ~((seq == 0).flatten(1).any(dim=1)) & ~beyond          # every entry heard and within the codes: fast quads only
+        slow_sampled = int(beyond[sample_t].sum())
+        assert slow_sampled >= min_slow, (slow_sampled, int(beyond.sum()))
+        assert int(dense[sample_t].sum()) >= 8, int(dense[sample_t].sum())
+        # slow-first dispatch is on (DIRAL_NO_SLOW_FIRST unset): the listed envs ran in the front-of-grid blocks, every env
+        # exactly once - the diagonal check above
     env.check()
 
 
 def test_c2_benchmarked_instantiation_full_size():
-    """configs[1]: 64 UE / 32 res, B = 4096 - step_fast64_kernel<true,false,false,false,true>."""
-    _run(64, 32, 2000.0, 4096, False, n_sample=48, T=32, fam=KERNEL_FAST64)
+    """configs[1]: 64 UE / 32 res, B = 4096 - step_fast64_kernel<true,false,false,false,true>; 64 slots (past the ghost
+    phase of SURVEY Q4 and past lag 7), the 12 envs with the widest highway gaps in the oracle sample beside 48 random ones:
+    at least 8 envs that end on the slow-first list and 8 that run on fast quads only are compared bit for bit."""
+    _run(64, 32, 2000.0, 4096, False, n_sample=48, T=64, fam=KERNEL_FAST64, n_gap=12, min_slow=8)
 
 
 def test_c3_benchmarked_instantiation_full_size():
@@ -98,8 +122,8 @@ def test_c5_benchmarked_instantiation_full_size():
 def test_c4_shard_benchmarked_instantiation_full_size():
     """configs[3]: one GPU's share of the 262144-env job, B = 32768 at the env offset of rank 5 - the RICH instantiation
     `also_measured.c4shard` times (state + reward + channel observation in one launch), 24 envs sampled across the shard
-    against the oracle."""
-    _run(64, 32, 2000.0, 32768, False, n_sample=24, T=16, fam=KERNEL_FAST64, env_offset=5 * 32768)
+    against the oracle, 48 slots, with the 12 widest-gap envs of the shard (>= 8 slow-listed ones compared)."""
+    _run(64, 32, 2000.0, 32768, False, n_sample=24, T=48, fam=KERNEL_FAST64, env_offset=5 * 32768, n_gap=12, min_slow=8)
 
 
 @pytest.mark.parametrize("N,A,L,B,vary,ns,T", [(64, 32, 2000.0, 4096, False, 16, 14), (256, 64, 4000.0, 8192, False, 4, 8),

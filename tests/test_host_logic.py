@@ -229,3 +229,11 @@ def test_byte_models_of_the_roofline_bookkeeping():
     assert lay(128, 64, 84, False) == 2 * 4 * 128 * 128 + 72 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
     assert lay(256, 64, 84, False) == 2 * 2 * 256 * 256 + 80 * 256 + 36 * 256 + 4 * 256 + 4 * 256 * 84
     assert 5 * lay(256, 64, 84, False) < alg(256, 64, 84)
+    # where a launch's reads can come from (`roofline.memory`): the state C2's 4096 envs re-read every launch fits the
+    # 256 MiB Infinity Cache (the counters then see fabric bytes), the C4 shard's and C3's do not
+    from diral_amd.roofline import INFINITY_CACHE_BYTES, memory_level, resident_bytes_per_env
+    assert resident_bytes_per_env(64) == 2 * 64 * 64 + 64 * 64 + 4 * 64 + 28 * 64
+    m2, m4, m3 = memory_level(64, 32, 52, 4096, True), memory_level(64, 32, 52, 32768, True), memory_level(256, 64, 84, 8192, True)
+    assert m2["resident_bytes"] < INFINITY_CACHE_BYTES < m4["resident_bytes"] < m3["resident_bytes"]
+    assert m2["reads_served_by"].startswith("infinity cache") and m4["reads_served_by"].startswith("hbm")
+    assert m2["output_bytes"] == 4096 * (4 * 64 + 4 * 64 * 52 + 4 * 64 * 32)
