@@ -464,6 +464,45 @@ def rollout_sps_fused(device, envs=4096, slots=400, warm=80, write_chobs=False):
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
+def rollout_sps_kslots(device, envs=4096, K=25, launches=16, warm=4, want_obs=False, per_slot_outputs=True):
+    """The closed loop of `rollout_sps_fused` with K slots per launch (`diral_env_step_policy`, DiralSlotPolicy::slots = K:
+    step_fast64_slots_kernel keeps every env in registers and LDS from slot to slot - no table traffic between slots, no
+    histogram unless the last slot's state vector is asked for).  Per-slot shaped rewards / sums / collisions leave as
+    [K, ...] arrays; equal to K one-slot launches bit for bit
+    (tests/test_gpu_parity.py::test_k_slots_in_one_launch_equal_k_one_slot_launches)."""
+    from diral_amd import c2_config
+    from diral_amd.sps import SpsPolicy
+    cfg = c2_config()
+    env = VecV2VEnv(cfg, batch=envs, device=device, out_dtype=torch.float32, io_ring=2)
+    env.reset_topology(seed=GLOBAL_SEED)
+    pol = SpsPolicy(env.B, env.N, env.A, device=device, seed=0)
+    acts = [pol.prev_action.clone(), torch.empty_like(pol.prev_action)]
+    shaped = torch.empty((K, envs, env.N), dtype=torch.float32, device=device) if per_slot_outputs else None
+    sum_r = torch.empty((K, envs), dtype=torch.float32, device=device) if per_slot_outputs else None
+    coll = torch.empty((K, envs), dtype=torch.float32, device=device) if per_slot_outputs else None
+    t0 = None
+    for n in range(warm + launches):
+        if n == warm:
+            torch.cuda.synchronize(device)
+            env.metrics(clear=True)
+            t0 = time.perf_counter()
+        i = n & 1
+        env.step_policy(acts[i], n * K, pol, acts[i ^ 1], shaped_out=shaped, sum_r_out=sum_r, collision_out=coll,
+                        global_reward_avg=True, slots=K, want_obs=want_obs)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    env.check()
+    from diral_amd.config import KERNEL_POLICY
+    assert env.last_kernel() & KERNEL_POLICY
+    m = env.metrics().sum(0)
+    slots = launches * K
+    return {"what": "the closed loop of rollout_sps with %d slots per launch (diral_env_step_policy, slots = %d: the env stays on "
+                    "the chip from slot to slot; per-slot shaped rewards %s, the last slot's state vector %s), %d envs, %d slots" % (
+                        K, K, "written" if per_slot_outputs else "not written", "written" if want_obs else "not computed", envs, slots),
+            "agent_steps_per_s": envs * env.N * slots / dt, "ms_per_slot": dt / slots * 1e3,
+            "collision_fraction": float(m[3] / (m[2] + m[3]))}
+
+
 def c2_graph(device, envs=4096, K=24, replays=42):
     """The headline step (c2: state + reward + channel observation, iid-uniform actions from a ring of K action tensors)
     with K slots captured into ONE hipGraph (slot number on the device: diral_env_set_clock) and replayed: what is left of
@@ -769,6 +808,8 @@ def main() -> int:
                 also["rollout_sps_graph"] = rollout_sps_graph(device)
                 also["rollout_sps_fused"] = rollout_sps_fused(device)
                 also["rollout_sps_fused_chobs"] = rollout_sps_fused(device, write_chobs=True)
+                also["rollout_sps_kslots"] = rollout_sps_kslots(device)
+                also["rollout_sps_kslots_state"] = rollout_sps_kslots(device, K=5, launches=80, warm=16, want_obs=True)
                 also["c2_graph"] = c2_graph(device)
                 torch.cuda.empty_cache()
                 also["secondary_observation_modes"] = secondary_modes(device)

@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1
@@ -127,6 +127,9 @@ class DiralSlotPolicy(ctypes.Structure):
         ("seed", ctypes.c_uint64),
         ("seed_clock", ctypes.c_void_p),
         ("actions_out", ctypes.c_void_p),
+        ("slots", ctypes.c_int32),
+        ("reserved1", ctypes.c_int32),
+        ("vel_seed", ctypes.c_uint64),
     ]
 
 

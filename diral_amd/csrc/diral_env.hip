@@ -399,7 +399,10 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     f.slow_cnt_r = nullptr; f.slow_list_r = nullptr; f.slow_flag_r = nullptr;
     f.slow_cnt_w = nullptr; f.slow_list_w = nullptr; f.slow_flag_w = nullptr; f.slow_cnt_z = nullptr;
     bool slow_first = false;
-    if (use_fast64 && e->slow && e->slow_first) {
+    // K slots per launch (diral_env_step_policy, DiralSlotPolicy::slots > 1): blocks = envs in order - over K slots a
+    // straggler averages out; the slow-env sets stay as the last one-slot launch left them (complete or empty), unread
+    const bool kslots = pol && d.pol_ok && pol->K > 1;
+    if (use_fast64 && e->slow && e->slow_first && !kslots) {
       const size_t w = slow_set_words(e);
       uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
       uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
@@ -431,6 +434,13 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
                      ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
     if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
+    if (kslots) {
+      // the env stays on the chip from slot to slot: step_fast64_slots_kernel
+      if (!k.rich) { r.plain_state = 1; }
+      e->last_kernel |= DIRAL_KERNEL_RICH | DIRAL_KERNEL_POLICY;
+      if (fused) *fused = true;
+      return launch_fast64_slots(f, r, *pol, k.out64, p.B, s);
+    }
     const int grid = p.B + (slow_first ? fast_slow_max(p.B) : 0);
     if (pol && d.pol_ok) {
       // the policy epilogue: RICH instantiation (the channel observation is staged in LDS whether or not it is written out)
@@ -843,9 +853,13 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   q.threshold = pol->rssi_threshold; q.inc_db = pol->inc_db; q.keep_prob = pol->keep_prob;
   q.draw_counter = pol->draw_counter; q.draw_keep = pol->draw_keep; q.draw_choice = pol->draw_choice;
   q.seed = pol->seed; q.clock = (const long long*)pol->seed_clock; q.actions_out = pol->actions_out;
+  const int slots = pol->slots > 1 ? pol->slots : 1;
+  q.K = slots; q.vel_vary = has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0; q.vel_seed = pol->vel_seed;
+  q.idx0 = (uint64_t)e->env_offset * (uint64_t)e->N; q.vel_w = e->vel;
+  if (slots > 1 && (pol->draw_counter || pol->draw_keep || pol->draw_choice)) return DIRAL_ERR_BAD_ARG;
   // (decided before anything is launched: a caller without a channel-observation buffer can retry with one)
   const bool will_fuse = step_dispatch(e, p).pol_ok;
-  if (!will_fuse && !chobs_out) return DIRAL_ERR_UNSUPPORTED;
+  if (!will_fuse && (!chobs_out || slots > 1)) return DIRAL_ERR_UNSUPPORTED;
   bool fused = false;
   HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, will_fuse ? &q : nullptr, &fused));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));

@@ -33,4 +33,12 @@ hipError_t launch_fast64_policy(const FastParams& f, const RichParams& r, const 
   else hipLaunchKernelGGL((step_fast64_kernel<true, false, false, false, true, true>), dim3(B), dim3(256), lds, s, f, r, q);
   return hipGetLastError();
 }
+
+// ... K slots per launch (PolParams::K > 1): step_fast64_slots_kernel, the same body with the env kept on the chip
+hipError_t launch_fast64_slots(const FastParams& f, const RichParams& r, const PolParams& q, bool out64, int B, hipStream_t s) {
+  const uint32_t lds = fast_lds_layout(f.K, f.A, true, out64, true, false, true).total;
+  if (out64) hipLaunchKernelGGL((step_fast64_slots_kernel<true, true, false, false, true, true>), dim3(B), dim3(256), lds, s, f, r, q);
+  else hipLaunchKernelGGL((step_fast64_slots_kernel<true, false, false, false, true, true>), dim3(B), dim3(256), lds, s, f, r, q);
+  return hipGetLastError();
+}
 }  // namespace diral

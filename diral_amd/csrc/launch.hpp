@@ -28,6 +28,7 @@ struct KernelSel {
 
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t launch_fast64_policy(const FastParams& f, const RichParams& r, const PolParams& q, bool out64, int B, hipStream_t s);
+hipError_t launch_fast64_slots(const FastParams& f, const RichParams& r, const PolParams& q, bool out64, int B, hipStream_t s);
 hipError_t launch_wide2(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t launch_wide4(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);
 hipError_t set_attr_wide2(int A, int K);

@@ -28,6 +28,13 @@ struct PolParams {
   uint64_t seed;
   const long long* clock;        // null, or a device counter added to the seed (captured rollouts)
   int32_t* actions_out;          // [B][N] the next slot's actions
+  // K slots in ONE launch (diral_env_step_policy with DiralSlotPolicy::slots > 1): the workgroup keeps its env - code
+  // and age words, ring rows, positions, velocities, the agents' policy state - in registers and LDS from slot to slot
+  int K;                         // slots of this launch (>= 1)
+  int vel_vary;                  // mobility_vary: Network.update_velocity (network.py:208-223) at every episode end inside the launch
+  uint64_t vel_seed;             // ... device draws seeded vel_seed + episode index, as diral_env_update_velocity(env, NULL, seed)
+  uint64_t idx0;                 // global index of agent 0 of env 0 (DIRAL_OPT_ENV_OFFSET * N): the draws are indexed globally
+  double* vel_w;                 // [B][N] velocities (written back behind the last slot when vel_vary)
 };
 
 // counter-based generator (splitmix64 finaliser over seed/stream/index); the

@@ -316,7 +316,8 @@ class VecV2VEnv:
 
     def step_policy(self, actions: torch.Tensor, t: int, policy, actions_out: torch.Tensor, shaped_out=None, sum_r_out=None,
                     collision_out=None, global_reward_avg: bool = True, want_chobs: bool = False, clock=None,
-                    seed_offset: Optional[int] = None, mode: Optional[int] = None):
+                    seed_offset: Optional[int] = None, mode: Optional[int] = None, slots: int = 1, vel_seed: int = 0,
+                    want_obs: bool = True):
         """One slot of a policy-only rollout as ONE launch (`diral_env_step_policy`): env step (state, reward, done,
         optionally the channel observation) + the driver's reward shaping (main_test.py:171-206 without the
         information-age terms) + the SPS agents' decisions for the next slot (algorithms/v2x_sps.py:76-104), the
@@ -326,8 +327,18 @@ class VecV2VEnv:
         fused kernel does not take run exactly those three launches (then the channel observation is materialised
         whatever `want_chobs` says).  `clock`: a rollout.SlotClock / int64 device tensor added to the policy's seed
         (`step_from_chobs_clocked` semantics, `seed_offset` as its `offset`); without it the policy's own step counter
-        advances as in `step_from_chobs`."""
+        advances as in `step_from_chobs`.
+
+        `slots` = K > 1: K slots in ONE launch, the env kept on the chip from slot to slot (include/diral_env.h,
+        DiralSlotPolicy::slots): `actions` are slot t's, the policy decides the later ones; obs / reward / done / the channel
+        observation are the LAST slot's (without `want_obs` no slot computes a state vector), `shaped_out` [K, B, N] and
+        `sum_r_out` / `collision_out` [K, B] hold every slot's; configs with mobility_vary update the velocities at the
+        episode ends inside the launch (`update_velocity(seed=vel_seed + slot // episode_interval)`).  Equal, bit for bit,
+        to K one-slot calls; raises DiralError(UNSUPPORTED) where the fused kernel does not apply."""
         from .config import DiralSlotPolicy, ERR_UNSUPPORTED
+        K = int(slots)
+        if K < 1:
+            raise ValueError("step_policy: slots must be >= 1")
         # raw pointers cross the C-ABI: what they point at is checked here (an int64 or strided tensor would be read as
         # garbage; `actions_out` aliasing `actions` lets the fused kernel's policy wave overwrite actions the
         # three-launch form still reads)
@@ -338,8 +349,9 @@ class VecV2VEnv:
                                  (name, self.B, self.N, self.device))
         if actions_out.data_ptr() == actions.data_ptr():
             raise ValueError("step_policy: actions_out must not alias actions")
-        for name, a, shape in (("shaped_out", shaped_out, (self.B, self.N)), ("sum_r_out", sum_r_out, (self.B,)),
-                               ("collision_out", collision_out, (self.B,))):
+        lead = (K,) if K > 1 else ()
+        for name, a, shape in (("shaped_out", shaped_out, lead + (self.B, self.N)), ("sum_r_out", sum_r_out, lead + (self.B,)),
+                               ("collision_out", collision_out, lead + (self.B,))):
             if a is not None and (a.dtype != self.out_dtype or tuple(a.shape) != shape or not a.is_contiguous()
                                   or a.device != self.device):
                 raise ValueError("step_policy: %s must be a contiguous %s tensor %s on %s" %
@@ -369,14 +381,18 @@ class VecV2VEnv:
             policy._t += 1
             q.seed = (int(policy.seed) * 1000003 + policy._t) & (2**64 - 1)
         q.actions_out = _ptr(actions_out)
+        q.slots = K
+        q.vel_seed = int(vel_seed) & (2**64 - 1)
+        if K > 1 and clock is None:
+            policy._t += K - 1                                   # slot k draws with seed + k: what K one-slot calls would be given
         use_chobs = self._chobs if (want_chobs or not fusable) else None
 
         def call(chobs):
             return self.lib.diral_env_step_policy(self._h, self.step_mode if mode is None else mode, _ptr(actions), int(t),
-                                                  _ptr(self._obs) if self.S > 0 else None, _ptr(self._rew), _ptr(self._done),
-                                                  _ptr(chobs), self._dt, ctypes.byref(q), self._stream())
+                                                  _ptr(self._obs) if (want_obs and self.S > 0) else None, _ptr(self._rew),
+                                                  _ptr(self._done), _ptr(chobs), self._dt, ctypes.byref(q), self._stream())
         st = call(use_chobs)
-        if st == ERR_UNSUPPORTED and use_chobs is None:  # not a fused configuration, nothing launched
+        if st == ERR_UNSUPPORTED and use_chobs is None and K == 1:  # not a fused configuration, nothing launched
             self._policy_needs_chobs = True
             if slot["chobs"] is None:
                 slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 5
+#define DIRAL_ABI_VERSION 6
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -408,6 +408,18 @@ typedef struct DiralSlotPolicy {
   uint64_t seed;
   const int64_t* seed_clock;      /* NULL, or a device counter added to the seed */
   int32_t* actions_out;           /* [B][N] */
+  /* K slots in ONE launch (ABI 6).  slots <= 1: one slot, as above.  slots = K > 1 (configurations the fused kernel takes -
+   * N <= 64, my_step, the flat highway; otherwise DIRAL_ERR_UNSUPPORTED with nothing launched): the workgroup of an env
+   * keeps it on the chip for K slots of [env step -> shaping -> SPS decision], `actions` being slot 0's and the policy's
+   * decisions the later ones'.  Equal, bit for bit, to K one-slot calls with t, t + 1, ... and seed, seed + 1, ... (plus
+   * diral_env_update_velocity(env, NULL, vel_seed + slot / episode_interval) behind every slot that ends an episode, when
+   * the config has mobility_vary) - tables, positions, velocities, metrics, policy state, actions_out (the actions of
+   * slot t + K).  state_out / rew_out / done_out / chobs_out: of the LAST slot (each may be NULL; without state_out no
+   * slot computes the positional histogram); shaped_out / sum_r_out / collision_out: [K][...] arrays, slot-major.
+   * Injected draws (draw_*) must be NULL. */
+  int32_t  slots;
+  int32_t  reserved1;
+  uint64_t vel_seed;
 } DiralSlotPolicy;
 int diral_env_step_policy(DiralEnv* env, int mode, const int32_t* actions, int64_t t, void* state_out, void* rew_out,
                           uint8_t* done_out, void* chobs_out, int out_dtype, const DiralSlotPolicy* policy,

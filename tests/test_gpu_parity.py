@@ -1936,3 +1936,75 @@ def test_step_policy_rejects_tensors_the_c_abi_would_misread():
         env.step_policy(a, 0, pol, out, shaped_out=torch.empty((B, N), dtype=torch.float64, device="cuda:0"))
     env.step_policy(a, 0, pol, out)
     env.check()
+
+
+@pytest.mark.parametrize("vary,K,t0,want_obs", [(False, 5, 0, True), (False, 25, 3, False), (True, 25, 10, True), (True, 5, 22, False),
+                                                (True, 6, 19, True)])
+def test_k_slots_in_one_launch_equal_k_one_slot_launches(vary, K, t0, want_obs):
+    """`diral_env_step_policy` with DiralSlotPolicy::slots = K (step_fast64_slots_kernel: the env stays in registers and
+    LDS from slot to slot, no table traffic, no histogram unless the last slot's state is asked for) against K fused
+    one-slot launches - and, with mobility_vary, `update_velocity(seed = vel_seed + episode)` behind every slot that ends
+    an episode (main_test.py:226-233): per-slot shaped rewards / sums / collisions, the last slot's state, reward, done,
+    the next actions, the policy state, the metrics and the exported tables, positions and velocities, bit for bit.  A
+    warm-up puts entries beyond the codes (keyed quads) into the tables first; two K-slot launches back to back, then a
+    one-slot launch on both sides."""
+    from diral_amd.config import KERNEL_POLICY
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    N, A, B = 64, 32, 96
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2, mobility_vary=vary)
+    vel_seed = 777
+    runs = []
+    for fused_k in (False, True):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32)
+        env.reset_topology(seed=11)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=5)
+        pol.keep_prob = 0.9
+        a = pol.prev_action.clone()
+        nxt = torch.empty_like(a)
+        t = 0
+        for _ in range(t0):                                   # warm-up, one slot per launch on both sides
+            env.step_policy(a, t, pol, nxt)
+            if vary and t % cfg.episode_interval == cfg.episode_interval - 1:
+                env.update_velocity(seed=vel_seed + t // cfg.episode_interval)
+            a, nxt = nxt, a
+            t += 1
+        outs = []
+        for rep in range(2):
+            sh = torch.zeros((K, B, N), dtype=torch.float32, device="cuda:0")
+            sr = torch.zeros((K, B), dtype=torch.float32, device="cuda:0")
+            co = torch.zeros((K, B), dtype=torch.float32, device="cuda:0")
+            if fused_k:
+                env.step_policy(a, t, pol, nxt, shaped_out=sh, sum_r_out=sr, collision_out=co, slots=K, vel_seed=vel_seed,
+                                want_obs=want_obs)
+                assert env.last_kernel() & KERNEL_POLICY
+                a, nxt = nxt, a
+                t += K
+            else:
+                for k in range(K):
+                    env.step_policy(a, t, pol, nxt, shaped_out=sh[k], sum_r_out=sr[k], collision_out=co[k])
+                    if vary and t % cfg.episode_interval == cfg.episode_interval - 1:
+                        env.update_velocity(seed=vel_seed + t // cfg.episode_interval)
+                    a, nxt = nxt, a
+                    t += 1
+            outs.append((sh, sr, co, env._obs.clone(), env._rew.clone(), env._done.clone(), a.clone()))
+        env.step_policy(a, t, pol, nxt)                        # a one-slot launch behind the K-slot ones
+        torch.cuda.synchronize()
+        runs.append((env, pol, outs, nxt.clone()))
+    (e1, p1, o1, n1), (e2, p2, o2, n2) = runs
+    for rep in range(2):
+        for i, name in enumerate(("shaped", "sum_r", "collisions")):
+            assert torch.equal(o1[rep][i], o2[rep][i]), (rep, name)
+        if want_obs:
+            assert torch.equal(o1[rep][3], o2[rep][3]), rep
+        assert torch.equal(o1[rep][4], o2[rep][4]) and torch.equal(o1[rep][5], o2[rep][5]) and torch.equal(o1[rep][6], o2[rep][6]), rep
+    assert torch.equal(n1, n2) and torch.equal(e1._obs, e2._obs) and torch.equal(e1._rew, e2._rew)
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    sa, sb = e1.export_state(), e2.export_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(e1.metrics(), e2.metrics())
+    if vary:
+        assert not torch.equal(sa["vel"], torch.full_like(sa["vel"], 1.7))      # an episode ended inside the launches
+    e1.check()
+    e2.check()

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     from diral_amd.config import ABI_VERSION
     src = open(os.path.join(ROOT, "include", "diral_env.h")).read()
-    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 5
+    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 6
 
 
 def test_cfg_struct_layout_matches_header():
