@@ -77,7 +77,8 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K, bool p
   // reachability matrix P of the slot as bytes [viewer][lane half][K step] (8 KB at N = 256) and the 256-entry
   // bits -> 8 x bf16 table of the product's B operand
   l.pbytes = l.lut = o;
-  if (packed) { l.pbytes = o; o += 32u * npad; l.lut = o; o += 4096u; o += 32u * npad; }   // (+ the closure's own rows of P, 8 bytes x 4 waves per viewer)
+  // (+ the closure's own rows of P - 16 bytes x 2 waves per viewer - and one row-ready flag per resource: it runs beside P1)
+  if (packed) { l.pbytes = o; o += 32u * npad; l.lut = o; o += 4096u; o += 32u * npad; o += 4u * (uint32_t)kWideMaxA; }
   l.px = o;    o += 8u * npad;
   l.npx = o;   o += 8u * npad;
   l.rv = o;    o += 8u * A;
@@ -386,6 +387,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   }
   for (int j = tid; j < KP * NPAD; j += THREADS) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+  // PACKED: the closure of the slot's gossip runs beside P1 (below): compile-time LDS addresses behind the merge scratch
+  // (step_wide_closure.inc), the bits -> 8 x bf16 table of the product and the row-ready flags of the gather table
+  constexpr unsigned int kClPb = wide_scratch(VPL) * WAVES, kClLut = kClPb + 32u * NPAD, kClRows = kClLut + 4096u,
+                         kClFlag = kClRows + 32u * NPAD;
+  constexpr int P1W = PACKED ? WAVES - 2 : WAVES;         // waves that run P1 (PACKED: the last two walk the closure)
+  if constexpr (PACKED) {
+    if (tid < 256) {
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      u32x4 t;                                              // entry e, element j = bit j of e, 0.0 / 1.0
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        t[jj] = ((((unsigned int)tid >> (2 * jj)) & 1u) ? 0x3f80u : 0u) | ((((unsigned int)tid >> (2 * jj + 1)) & 1u) ? 0x3f800000u : 0u);
+      reinterpret_cast<u32x4*>(smem + kClLut)[tid] = t;
+    } else if (tid < 256 + kWideMaxA) {
+      reinterpret_cast<unsigned int*>(smem + kClFlag)[tid - 256] = 0u;
+    }
+  }
   // (the barrier P1 needs anyway, carrying one bit: every position of the env is 0 or >= 2^-447, so every nonzero
   // |x_w - x_u| is >= 2^-499 and IS the reference's sqrt(fl(dx^2)) - the search runs without the per-pair exponent test)
   // (carried through the `s_red` slots, free until P2: __syncthreads_or would bring static LDS, and the merge loop
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #pragma unroll
     for (int j = 0; j < VPL; ++j) mypx[j] = s_px[lane + 64 * j];
 #pragma unroll 1
-    for (int i = wave; i < A; i += WAVES) {
+    for (int i = wave; i < (wave < P1W ? A : 0); i += P1W) {
       unsigned long long mk[VPL];
       int c = 0;
 #pragma unroll
@@ -472,6 +490,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         if (EXTRA && CH && p.la && got) p.la[(bN + bid[j]) * N + u] = (int32_t)(p.t + (p.t_dev ? *p.t_dev : 0ll));   // test_env.py:436
       }
       s_mtab[i * MT + lane] = (mword_t)mw;
+      if constexpr (PACKED) {
+        // the row is ready (a wave's LDS operations execute in order: whoever sees the flag sees the row)
+        wave_lds_order();
+        if (lane == 0) reinterpret_cast<volatile unsigned int*>(smem + kClFlag)[i] = 1u;
+      }
       if (CH || (EXTRA && p.prr)) {
         if (c > 1) {
           // received[tx] = #rx whose nearest in-range tx is tx; R = received / in_range (test_env.py:398-405)
@@ -515,6 +538,79 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
         if (lane == 0) s_rv[i] = rw;
       }
+    }
+  }
+  if constexpr (PACKED) {
+    // ---- the reachability closure of the slot (step_wide_closure.inc: final = P . stamped, P = (I + E_A) ... (I + E_1)),
+    //      walked ONCE per env, BESIDE P1: waves 6 and 7 - 128 source bits each, rows of P in LDS, gather the source's 16
+    //      bytes and ds_or them into the own row - take the rows of the gather table in resource order as the six P1 waves
+    //      finish them (a flag per row; an idle resource's row is the identity), and leave P as bytes
+    //      [viewer][lane group][K step of 32 sources] for the products.  Behind P1, on waves 4-7 with the others waiting at
+    //      a barrier for it, the walk was 15 k of a workgroup's 140 k cycles; beside it P1 takes six waves 21 k instead of
+    //      eight waves 15.5 k and the walk disappears behind it.
+    if (wave >= P1W) {
+      if (!(__builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u)) __builtin_trap();   // (compile-time LDS addresses: dynamic segment at 0)
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      const int cwv = wave - P1W;
+      unsigned char* const rows = smem + kClRows + 16u * NPAD * cwv;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const int u = lane + 64 * j;                       // identity: bit u of the 256-bit row, this wave's 128-bit half
+        u32x4 id = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) id[w] = (u >> 5) == 4 * cwv + w ? 1u << (u & 31) : 0u;
+        reinterpret_cast<u32x4*>(rows)[u] = id;
+      }
+      wave_lds_order();
+      const volatile unsigned int* const flag = reinterpret_cast<const volatile unsigned int*>(smem + kClFlag);
+      // (the flag and the row of step i + 1 are requested in front of step i's gathers - flag first: in-order LDS queue, a
+      // set flag vouches for the row read behind it - so that a walk that lags the P1 waves pays no LDS round trip per
+      // step for them; polled with a round trip per step the walk took 36 k cycles against P1's 22 k)
+      unsigned int mw_n = 0u, fl_n = 0u;
+      __builtin_amdgcn_s_setprio(3);                          // (the walk is the critical path of P1; it shares its SIMD with a P1 wave)
+#pragma unroll 1
+      for (int i = 0; i < A; ++i) {
+        unsigned int mw = mw_n;
+        if (fl_n == 0u) {                                     // (uniform) not seen ready yet: poll
+          while (flag[i] == 0u) __builtin_amdgcn_s_sleep(1);
+          mw = (unsigned int)s_mtab[i * MT + lane];
+        }
+        const int i1 = i + 1 < A ? i + 1 : i;
+        fl_n = flag[i1];
+        mw_n = (unsigned int)s_mtab[i1 * MT + lane];
+        fl_n = (unsigned int)__builtin_amdgcn_readfirstlane((int)fl_n);
+        if (i + 1 >= A) fl_n = 0u;
+        unsigned int sa[VPL];
+        unpack_src<VPL, 4u>(mw, sa);                          // source viewer * 16: the byte offset of its row
+        u32x4 g[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) g[j] = *reinterpret_cast<const u32x4*>(rows + sa[j]);
+        wave_lds_order();
+        // (a vehicle without a source gathers its own row: a no-op; the transmitters of this resource are nobody's
+        // receivers in this step, so their rows are read as the earlier steps left them - in-order LDS queue)
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          unsigned long long* const own = reinterpret_cast<unsigned long long*>(rows) + 2 * (lane + 64 * j);
+          __hip_atomic_fetch_or(own, ((unsigned long long)g[j][1] << 32) | g[j][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_or(own + 1, ((unsigned long long)g[j][3] << 32) | g[j][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        wave_lds_order();
+      }
+      // P as bytes [viewer][lane group g][K step s]: byte g of dword s of the viewer's 32-byte row = the sources
+      // 32 s + 8 g + (0 .. 7); this wave owns the dwords s = 4 cwv ... 4 cwv + 3: four bytes per lane group
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const unsigned int u = (unsigned int)lane + 64u * j;
+        const u32x4 r = reinterpret_cast<const u32x4*>(rows)[u];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const unsigned int sel = 0x0c0c0000u | ((4u + gg) << 8) | (unsigned int)gg;
+          const unsigned int lo16 = __builtin_amdgcn_perm(r[1], r[0], sel), hi16 = __builtin_amdgcn_perm(r[3], r[2], sel);
+          *reinterpret_cast<unsigned int*>(smem + kClPb + u * 32u + gg * 8u + 4u * cwv) = lo16 | (hi16 << 16);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      wave_lds_order();
     }
   }
   DIRAL_WSTAMP(2);
