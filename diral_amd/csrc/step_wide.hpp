@@ -479,8 +479,43 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         }
       }
       };
-      if (p1_fast) search(std::true_type{});
-      else search(std::false_type{});
+      // my_step without the EXTRA switches: nothing needs "in range" per transmitter, and the closest IN-RANGE transmitter
+      // (strict '<', first of equals: network.py:378-398) is the closest of all if that one is in range, else none - a plain
+      // running minimum (v_min_f64 on the magnitude) and ONE range test per resource and viewer slot: 4 vector instructions
+      // per (transmitter, slot) instead of 8 (step_fast64_body.inc, search_min).  Worth nothing while the merge chain paced the
+      // kernel (round 4: +- 0 on C3); with the merge on the matrix pipe P1 is a fifth of a workgroup's life.
+      auto search_min = [&](auto fast_tag) {
+        constexpr bool ABS = decltype(fast_tag)::value;
+#pragma unroll
+        for (int jt = 0; jt < VPL; ++jt) {
+          unsigned long long m = mk[jt];
+          while (m) {
+            const int wl = __builtin_ctzll(m);
+            const int w = jt * 64 + wl;
+            m &= m - 1;
+            const double xw = readlane_f64(mypx[jt], wl);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              double d;
+              if constexpr (ABS) d = mypx[j] - xw;                 // signed: the magnitude through source modifiers
+              else d = fast_dist<true>(xw, 0.0, mypx[j], 0.0);
+              const bool bt = __builtin_fabs(d) < best[j];
+              bid[j] = bt ? w : bid[j];
+              asm("v_min_f64 %0, %0, |%1|" : "+v"(best[j]) : "v"(d));
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+          if (!(best[j] < pRc)) bid[j] = -1;                       // network.py:385-386: none in range
+      };
+      if constexpr (!CH && !EXTRA) {
+        if (p1_fast) search_min(std::true_type{});
+        else search_min(std::false_type{});
+      } else {
+        if (p1_fast) search(std::true_type{});
+        else search(std::false_type{});
+      }
       unsigned int mw = 0u;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {

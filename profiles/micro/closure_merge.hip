@@ -584,6 +584,158 @@ __global__ __launch_bounds__(512, 4) void closure3_c3(const Args p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// C2 shapes: N = 64 vehicles (one lane per viewer), A = 32 resources, 4 waves x 16 subject columns = 4 code words per
+// lane.  Today (csrc/step_fast64_body.inc, merge_walk): the four words gathered by ds_bpermute from the source LANE and
+// ORed, one step per active resource, software-pipelined by one step.  Closure: the 64-bit row of P per lane walks the
+// same chain (two ds_bpermute per step instead of four), every wave on its own (no barrier, no LDS for it), then one
+// product per wave: A = its 16 columns x 64 sources (two K steps), B = P as 0.0 / 1.0 built from the lane's bits with
+// VALU (the workgroup has no LDS left for a 4 KB table: 20 KB at A <= 32 is what keeps 8 workgroups per CU), 8 MFMAs,
+// decode, one 4 x 4 transpose of 16-lane rows.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int N2 = 64, A2 = 32, NQ2 = N2 / 4, MS2 = 36;
+struct Args2 {
+  const unsigned char* mtab;           // [envs][64 vehicles][MS2]: gather source LANE * 4 of (vehicle, resource)
+  const unsigned long long* actw;
+  const unsigned int* codes;           // [envs][16 quads][64 viewers]
+  unsigned int* out;                   // [blocks][16][64]
+  unsigned long long* dbg;             // [blocks][4 waves][4]
+  int envs;
+};
+
+__global__ __launch_bounds__(256, 7) void chain_c2(const Args2 p) {
+  __shared__ __align__(16) unsigned char s_mtab[64 * MS2];
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 64 * MS2 / 4; i += 256)
+    reinterpret_cast<unsigned int*>(s_mtab)[i] = reinterpret_cast<const unsigned int*>(p.mtab + (size_t)e * 64 * MS2)[i];
+  const unsigned long long actw = p.actw[e];
+  unsigned int w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = p.codes[((size_t)e * NQ2 + wave * 4 + q) * N2 + lane];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  {
+    const unsigned int* const mrow = reinterpret_cast<const unsigned int*>(s_mtab + lane * MS2);
+    unsigned int mw = mrow[0];
+    unsigned long long act = actw;
+    int t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (int)w[j];
+    auto step = [&](int m4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[j] |= (unsigned int)t[j];
+        t[j] = __builtin_amdgcn_ds_bpermute(m4, (int)w[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g < A2 / 4; ++g) {
+      const unsigned int cur = mw;
+      mw = mrow[g + 1];
+      const unsigned int a4 = (unsigned int)act & 15u;
+      act >>= 4;
+      if (a4 & 1u) step((int)(cur & 255u));
+      if (a4 & 2u) step((int)((cur >> 8) & 255u));
+      if (a4 & 4u) step((int)((cur >> 16) & 255u));
+      if (a4 & 8u) step((int)(cur >> 24));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] |= (unsigned int)t[j];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p.out[((size_t)b * NQ2 + wave * 4 + q) * N2 + lane] = w[q];
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 4 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t1; d[3] = t1;
+  }
+}
+
+__global__ __launch_bounds__(256, 7) void closure_c2(const Args2 p) {
+  __shared__ __align__(16) unsigned char s_mtab[64 * MS2];
+  __shared__ unsigned long long s_p[4][64];                   // P rows, a copy per wave (no barrier)
+  const int b = blockIdx.x, e = b % p.envs, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 64 * MS2 / 4; i += 256)
+    reinterpret_cast<unsigned int*>(s_mtab)[i] = reinterpret_cast<const unsigned int*>(p.mtab + (size_t)e * 64 * MS2)[i];
+  const unsigned long long actw = p.actw[e];
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  // ---- closure: this lane's row of P, the chain of the active resources, two dwords per step
+  unsigned int plo = lane < 32 ? 1u << lane : 0u, phi = lane >= 32 ? 1u << (lane - 32) : 0u;
+  {
+    const unsigned int* const mrow = reinterpret_cast<const unsigned int*>(s_mtab + lane * MS2);
+    unsigned int mw = mrow[0];
+    unsigned long long act = actw;
+    auto step = [&](int m4) {
+      const int glo = __builtin_amdgcn_ds_bpermute(m4, (int)plo), ghi = __builtin_amdgcn_ds_bpermute(m4, (int)phi);
+      plo |= (unsigned int)glo; phi |= (unsigned int)ghi;
+    };
+#pragma unroll 1
+    for (int g = 0; g < A2 / 4; ++g) {
+      const unsigned int cur = mw;
+      mw = mrow[g + 1];
+      const unsigned int a4 = (unsigned int)act & 15u;
+      act >>= 4;
+      if (a4 & 1u) step((int)(cur & 255u));
+      if (a4 & 2u) step((int)((cur >> 8) & 255u));
+      if (a4 & 4u) step((int)((cur >> 16) & 255u));
+      if (a4 & 8u) step((int)(cur >> 24));
+    }
+  }
+  s_p[wave][lane] = ((unsigned long long)phi << 32) | plo;
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  // ---- A operand: this wave's 16 columns x 64 sources, two K steps of 32
+  const int c = lane & 15, g = lane >> 4;
+  const int kk = wave * 16 + c;
+  const unsigned int sh = 8u * (unsigned int)(kk & 3);
+  const unsigned int* const crow = p.codes + ((size_t)e * NQ2 + (kk >> 2)) * N2 + 8 * g;
+  u32x4 a[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const u32x4 w0 = *reinterpret_cast<const u32x4*>(crow + 32 * s), w1 = *reinterpret_cast<const u32x4*>(crow + 32 * s + 4);
+    auto bf = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+      return ((unsigned int)__popc((lo >> sh) & 255u) << 11) | ((unsigned int)__popc((hi >> sh) & 255u) << 27);
+    };
+    a[s][0] = bf(w0.x, w0.y); a[s][1] = bf(w0.z, w0.w); a[s][2] = bf(w1.x, w1.y); a[s][3] = bf(w1.z, w1.w);
+  }
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  // ---- product: 4 tiles of 16 viewers; B from the viewer's bits (VALU), decode, transpose
+  unsigned int res[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const unsigned long long pr = s_p[wave][16 * tt + c];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned int bits = ((unsigned int)(pr >> (32 * s)) >> (8 * g)) & 255u;     // sources 32 s + 8 g + (0 .. 7)
+      u32x4 bv;
+#pragma unroll
+      for (int vi = 0; vi < 4; ++vi)
+        bv[vi] = (((bits >> (2 * vi)) & 1u) ? 0x3f80u : 0u) | (((bits >> (2 * vi + 1)) & 1u) ? 0x3f800000u : 0u);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    }
+    unsigned int word = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) word |= ((0xff00u >> (__float_as_uint(acc[r]) >> 27)) & 0xffu) << (8 * r);
+    res[tt] = word;
+  }
+  const auto s02 = __builtin_amdgcn_permlane32_swap(res[0], res[2], false, false);
+  const auto s13 = __builtin_amdgcn_permlane32_swap(res[1], res[3], false, false);
+  const auto n01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+  const auto n23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+  const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+  unsigned int* const orow = p.out + ((size_t)b * NQ2 + wave * 4) * N2 + lane;
+  orow[0] = n01[0]; orow[N2] = n01[1]; orow[2 * N2] = n23[0]; orow[3 * N2] = n23[1];
+  if (lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)b * 4 + wave) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host: topologies, tables, the restatement
 // ------------------------------------------------------------------------------------------------------------------
@@ -810,6 +962,75 @@ int main(int argc, char** argv) {
     second("closure3 8x1 ds_or", closure3_c3<1, 2>, kLds3b);
     second("closure3 2x4 all-store", closure3_c3<4, 1>, kLds3b);
     second("closure3 2x4 ds_or", closure3_c3<4, 2>, kLds3b);
+  }
+  // ---------------- C2 ----------------
+  {
+    const int envs2 = 256, blocks2 = argc > 2 ? std::atoi(argv[2]) : 4096;
+    std::vector<HostEnv> h2(envs2);
+    for (auto& h : h2) make_env(h, N2, A2, 2000.0, 250.0, rng);
+    std::vector<unsigned char> mt2((size_t)envs2 * 64 * MS2, 0);
+    std::vector<unsigned int> cd2;
+    std::vector<unsigned long long> aw2;
+    for (int e = 0; e < envs2; ++e) {
+      for (int u = 0; u < 64; ++u)
+        for (int i = 0; i < A2; ++i) mt2[((size_t)e * 64 + u) * MS2 + i] = (unsigned char)((h2[e].mtab[(size_t)i * 64 + u] & 255u) << 2);
+      for (int u = 0; u < 64; ++u)
+        for (int i = A2; i < MS2; ++i) mt2[((size_t)e * 64 + u) * MS2 + i] = (unsigned char)(u << 2);
+      cd2.insert(cd2.end(), h2[e].codes.begin(), h2[e].codes.end());
+      aw2.push_back(h2[e].actw);
+    }
+    Args2 a2;
+    unsigned char* d_mt2; unsigned int *d_cd2, *d_out2; unsigned long long *d_aw2, *d_dbg2;
+    CHECK(hipMalloc(&d_mt2, mt2.size())); CHECK(hipMalloc(&d_cd2, cd2.size() * 4 + 4096)); CHECK(hipMalloc(&d_out2, (size_t)blocks2 * NQ2 * N2 * 4));
+    CHECK(hipMalloc(&d_aw2, aw2.size() * 8)); CHECK(hipMalloc(&d_dbg2, (size_t)blocks2 * 4 * 4 * 8));
+    CHECK(hipMemcpy(d_mt2, mt2.data(), mt2.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_cd2, cd2.data(), cd2.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_aw2, aw2.data(), aw2.size() * 8, hipMemcpyHostToDevice));
+    a2.mtab = d_mt2; a2.actw = d_aw2; a2.codes = d_cd2; a2.out = d_out2; a2.dbg = d_dbg2; a2.envs = envs2;
+    auto run2 = [&](auto kernel, int blocks, int iters) -> double {
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, a2);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, a2);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      return (double)ms * 1000.0 / iters;
+    };
+    auto check2 = [&](const char* name) -> bool {
+      std::vector<unsigned int> out((size_t)envs2 * NQ2 * N2);
+      CHECK(hipMemcpy(out.data(), d_out2, out.size() * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (int e = 0; e < envs2; ++e)
+        for (size_t i = 0; i < (size_t)NQ2 * N2; ++i) bad += out[(size_t)e * NQ2 * N2 + i] != h2[e].merged[i];
+      std::printf("%-26s %s (%zu of %zu words differ from the host restatement)\n", name, bad ? "MISMATCH" : "bit-equal", bad, out.size());
+      return bad == 0;
+    };
+    auto ph2 = [&](int blocks) -> Phase {
+      std::vector<unsigned long long> d((size_t)blocks * 4 * 4);
+      CHECK(hipMemcpy(d.data(), d_dbg2, d.size() * 8, hipMemcpyDeviceToHost));
+      return phases(d, blocks, 4);
+    };
+    std::printf("== C2 shapes: N = 64, A = 32, 4 waves x 16 subject columns; %d distinct envs, %d workgroups loaded ==\n", envs2, blocks2);
+    CHECK(hipMemset(d_out2, 0, (size_t)blocks2 * NQ2 * N2 * 4));
+    run2(chain_c2, envs2, 1);
+    ok &= check2("chain_c2 (today)");
+    CHECK(hipMemset(d_out2, 0, (size_t)blocks2 * NQ2 * N2 * 4));
+    run2(closure_c2, envs2, 1);
+    ok &= check2("closure_c2");
+    for (int blocks : {256, blocks2}) {
+      const double tc = run2(chain_c2, blocks, 20);
+      const Phase pc = ph2(blocks);
+      const double tn = run2(closure_c2, blocks, 20);
+      const Phase pn = ph2(blocks);
+      std::printf("-- %d workgroups --\n", blocks);
+      std::printf("chain_c2     %8.2f us   cycles per wave: merge %6.0f\n", tc, pc.v[0]);
+      std::printf("closure_c2   %8.2f us   cycles per wave: closure %6.0f  A operand %6.0f  product + epilogue %6.0f  (sum %6.0f)   ratio: kernel %.3f, cycles %.3f\n",
+                  tn, pn.v[0], pn.v[1], pn.v[2], pn.v[0] + pn.v[1] + pn.v[2], tn / tc, (pn.v[0] + pn.v[1] + pn.v[2]) / pc.v[0]);
+    }
   }
   std::printf(ok ? "ALL EQUAL\n" : "FAILED\n");
   return ok ? 0 : 1;

@@ -1,0 +1,48 @@
+#!/bin/bash
+# The round-5 profiling session (GPU box, through gpurun, from the repo root):
+#   PMC_COMMIT=<git short hash> bash profiles/session_r05.sh
+# kernel-trace + PMC passes (every counter group in its own run) for the bench workloads, then the bench lines of the same
+# box, the launch timeline of the headline kernel with and without slow-first dispatch, the rollouts, the side paths.
+# profiles/collect_r05.sh copies the results into profiles/r05/ and builds profiles/pmc_counters.json.
+set -u
+mkdir -p gpurun_out
+export PMC_COMMIT=${PMC_COMMIT:-unknown}
+FULL_PMC=1 bash profiles/run_profile.sh c2_chobs1 > /dev/null 2>&1
+FULL_PMC=1 bash profiles/run_profile.sh c2_chobs0 --emit-chobs 0 > /dev/null 2>&1
+for w in c3 c5; do
+  FULL_PMC=1 bash profiles/run_profile.sh ${w}_chobs1 --workload $w --steps 200 --warmup 20 > /dev/null 2>&1
+  bash profiles/run_profile.sh ${w}_chobs0 --workload $w --emit-chobs 0 --steps 200 --warmup 20 > /dev/null 2>&1
+done
+FULL_PMC=1 bash profiles/run_profile.sh c4shard --workload c4shard --steps 200 --warmup 20 > /dev/null 2>&1
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_r05_full.json
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/bench_r05_driverlike.json
+for w in c3 c5; do
+  python bench.py --workload $w --lean --steps 100 --warmup 10 2>/dev/null | tail -1 > gpurun_out/bench_r05_$w.json
+  python bench.py --workload $w --lean --steps 100 --warmup 10 --emit-chobs 0 2>/dev/null | tail -1 > gpurun_out/bench_r05_${w}_nochobs.json
+done
+NCCL_DEBUG=INFO python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
+  bench.py --gpus 1 --steps 200 --warmup 20 --lean > gpurun_out/bench_r05_torchrun1.stdout 2> gpurun_out/bench_r05_torchrun1.log
+tail -1 gpurun_out/bench_r05_torchrun1.stdout > gpurun_out/bench_r05_torchrun1.json
+grep -v '^{' gpurun_out/bench_r05_torchrun1.stdout >> gpurun_out/bench_r05_torchrun1.log
+(bash profiles/scale.sh 1; bash profiles/scale.sh 1 2; echo "rc=$?") > gpurun_out/scale_r05.txt 2>&1
+python profiles/rollout_lines.py 2>&1 | grep -v amdgpu > gpurun_out/rollout_r05.txt
+python profiles/side_paths.py 2>&1 | grep -v amdgpu > gpurun_out/side_paths_r05.txt
+WORKLOADS=c2,c5,c3 python profiles/secondary_modes.py 2>&1 | grep -v amdgpu > gpurun_out/secondary_modes_r05.txt
+for v in 0 1; do echo "== DIRAL_NO_SLOW_FIRST=$v"; DIRAL_NO_SLOW_FIRST=$v bash profiles/batch_sweep.sh 64 256 1024 1792 2048 3584 4096 8192 32768 2>&1 | grep -v amdgpu; done > gpurun_out/batch_sweep_r05.txt
+if [ -f variants_tmp/lib_timing.so ]; then
+  for v in 0 1; do echo "== DIRAL_NO_SLOW_FIRST=$v"; DIRAL_NO_SLOW_FIRST=$v B=4096 DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/launch_timeline.py 2>&1 | grep -v amdgpu; done > gpurun_out/launch_timeline_r05.txt
+  for B in 64 4096; do echo "=== B=$B"; B=$B DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -10; done > gpurun_out/phase_timing_r05.txt
+fi
+python profiles/kslots_bench.py 2>&1 | grep -v amdgpu > gpurun_out/kslots_r05.txt
+if [ -f variants_tmp/lib_timing.so ]; then
+  for W in c3:8192 c5:16384; do w=${W%%:*}; B=${W##*:}; for b in 64 $B; do echo "=== $w B=$b"; WORKLOAD=$w B=$b DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -10; done; done > gpurun_out/phase_timing_wide_r05.txt
+  DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/kslots_timing.py 2>&1 | grep -v amdgpu > gpurun_out/kslots_timing_r05.txt
+fi
+hipcc --offload-arch=gfx950 -O3 profiles/micro/closure_merge.hip -o /tmp/closure_merge && /tmp/closure_merge > gpurun_out/closure_merge_r05.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_secondary -o t -- env WORKLOADS=c2,c5,c3 python $GRAFT_REPO_ROOT/profiles/secondary_modes.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_rollout -o t -- python $GRAFT_REPO_ROOT/profiles/rollout_lines.py > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_secondary gpurun_out/prof_rollout -name "*_kernel_trace.csv" | xargs rm -f
+for t in c2_chobs1 c2_chobs0 c3_chobs1 c3_chobs0 c5_chobs1 c5_chobs0 c4shard; do echo "== $t"; grep "steady state" gpurun_out/prof_$t/summary.txt; done
+cat gpurun_out/rollout_r05.txt gpurun_out/scale_r05.txt
