@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--one-launch", action="store_true",
                     help="SPS policy: the whole slot (env step + reward shaping + SPS decision) as ONE launch, "
                          "diral_env_step_policy - the channel observation never leaves the chip")
+    ap.add_argument("--slots-per-launch", type=int, default=1,
+                    help="with --one-launch: K slots in ONE launch (DiralSlotPolicy::slots): the env stays on the chip from "
+                         "slot to slot, only the per-slot shaped rewards and the metrics leave it")
     args = ap.parse_args()
     rank, local_rank, world = rank_world()
     torch.cuda.set_device(local_rank)
@@ -49,11 +52,22 @@ def main():
     t0 = time.perf_counter()
     if args.one_launch and args.policy == "sps":
         acts = [actions, torch.empty_like(actions)]
-        shaped = torch.empty((env.B, env.N), dtype=torch.float32, device=env.device)
-        for t in range(args.slots):
-            state, _, _ = env.step_policy(acts[t & 1], t, pol, acts[(t + 1) & 1], shaped_out=shaped, global_reward_avg=True)
-            if t == args.slots // 2:
-                env.metrics(clear=True)
+        K = max(1, args.slots_per_launch)
+        if K > 1:
+            args.slots -= args.slots % K
+            shaped = torch.empty((K, env.B, env.N), dtype=torch.float32, device=env.device)
+            for n in range(args.slots // K):
+                # (want_obs=False: a policy-only rollout - no state vector, so no histogram either)
+                env.step_policy(acts[n & 1], n * K, pol, acts[(n + 1) & 1], shaped_out=shaped, global_reward_avg=True,
+                                slots=K, want_obs=False)
+                if n == args.slots // K // 2:
+                    env.metrics(clear=True)
+        else:
+            shaped = torch.empty((env.B, env.N), dtype=torch.float32, device=env.device)
+            for t in range(args.slots):
+                state, _, _ = env.step_policy(acts[t & 1], t, pol, acts[(t + 1) & 1], shaped_out=shaped, global_reward_avg=True)
+                if t == args.slots // 2:
+                    env.metrics(clear=True)
         args.slots_done = True
     for t in range(0 if not getattr(args, "slots_done", False) else args.slots, args.slots):
         out = loop.slot(actions, t)                   # one fused env launch + reward shaping
