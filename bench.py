@@ -232,7 +232,7 @@ def roofline_object(res, pmc):
         "frac": res["layout_rate_GBps"] / HBM_PEAK_GBPS,
         "bytes_per_launch": res["layout_bytes_per_launch"],
         "bytes_note": "compulsory HBM bytes of this build's table layout per launch (per entry one code byte + one age byte read "
-                      "+ written - a 4-byte (seq, age) word for 64 < N <= 128 -, per-subject xpos rings and sequence numbers, "
+                      "+ written - a 4-byte (seq, age) word for step_wide's plane form on sparse topologies -, per-subject xpos rings and sequence numbers, "
                       "per-vehicle arrays, outputs): diral_amd/roofline.py",
         "kernel": res["kernel"],
         "kernel_ms": res["kernel_ms"],

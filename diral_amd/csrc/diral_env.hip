@@ -135,22 +135,25 @@ Offsets state_offsets(const DiralCfg* c) {
 int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
 
 // The table form of a handle (fixed at create): packed thermometer codes + ages + own sequence numbers, or the (seq, age)
-// plane `tkey` of round 2.  N <= 64: always packed (step_fast64 has no other form).  64 < N <= 128: the plane (step_wide
-// <2>).  128 < N <= 256: packed where the vehicles are dense enough for tables to stay fresh - on average at least
-// kPackedMinNeighbours vehicles within communication range (N * 2 Rc / L; BASELINE configs[2]: 32) -, else the plane: on a
-// sparse highway most entries lag their subject by more than the 7 stamps the codes carry, and every pass of the packed
-// form would detour through the planes (measured + 60 % at 2.4 neighbours, + 58 % at 10.7).  DIRAL_TABLE_FORM = packed |
-// plane in the environment overrides the choice for N > 128 (tests run both forms on both kinds of topology).
+// plane `tkey` of round 2.  N <= 64: always packed (step_fast64 has no other form).  64 < N <= 256 (step_wide): packed
+// where the vehicles are dense enough for tables to stay fresh - on average at least kPackedMinNeighbours vehicles within
+// communication range (N * 2 Rc / L; BASELINE configs[2]: 32, configs[4]: 16) -, else the plane: on a sparse highway most
+// entries lag their subject by more than the 7 stamps the codes carry, and every pass of the packed form would detour
+// through the planes (N > 128: measured + 60 % at 2.4 neighbours, + 58 % at 10.7).  At configs[4]'s density one env in
+// ten has broken into clusters and runs nearly all its passes through the planes at three times the price of a plane-form
+// pass, the other nine run coded passes at a third of it: 1.11 -> 1.02-1.04 ms with those envs dispatched first (step_wide.hpp).
+// DIRAL_TABLE_FORM = packed | plane in the environment overrides the choice for N > 64 (tests run both forms on both
+// kinds of topology).
 constexpr double kPackedMinNeighbours = 20.0;
+constexpr double kPackedMinNeighbours2 = 15.0;           // 64 < N <= 128
 bool use_packed_table(const DiralEnv* e) {
   if (e->vpl == 1) return true;
-  if (e->vpl == 2) return false;
   if (const char* f = std::getenv("DIRAL_TABLE_FORM")) {
     if (std::strcmp(f, "packed") == 0) return true;
     if (std::strcmp(f, "plane") == 0) return false;
   }
   const double neigh = e->N * 2.0 * e->cfg.communication_range / e->cfg.highway_length;
-  return neigh >= kPackedMinNeighbours;
+  return neigh >= (e->vpl == 2 ? kPackedMinNeighbours2 : kPackedMinNeighbours);
 }
 
 // Every entry point that touches the device runs with the handle's device current and
@@ -402,7 +405,10 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     // K slots per launch (diral_env_step_policy, DiralSlotPolicy::slots > 1): blocks = envs in order - over K slots a
     // straggler averages out; the slow-env sets stay as the last one-slot launch left them (complete or empty), unread
     const bool kslots = pol && d.pol_ok && pol->K > 1;
-    if (use_fast64 && e->slow && e->slow_first && !kslots) {
+    // (step_wide: the packed form at N <= 128 only - its slow envs are 4 x the others; the plane form's are 1.6 x and measured
+    // 4 % SLOWER dispatched first, N > 128 packed runs on dense topologies without any: - 0.7 % for the bookkeeping)
+    const bool wide_slow = use_wide && vpl == 2 && e->tcode != nullptr;
+    if ((use_fast64 || wide_slow) && e->slow && e->slow_first && !kslots) {
       const size_t w = slow_set_words(e);
       uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
       uint32_t* const set_w = e->slow + ((e->slow_launches + 1) % 3) * w;
@@ -429,11 +435,14 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     k.flat = flat_y; k.out64 = p.out_f64 != 0; k.full = p.N == 64 * vpl; k.ch = ch;
     k.extra = d.extra;                                          // EXTRA instantiation: the run-time switches compiled in
     k.rich = !plain;
-    k.packed = use_wide && vpl == 4 && e->tcode != nullptr;
+    k.packed = use_wide && e->tcode != nullptr;
     e->last_kernel = (use_wide ? DIRAL_KERNEL_WIDE : DIRAL_KERNEL_FAST64) | (k.rich ? DIRAL_KERNEL_RICH : 0) |
                      ((k.packed || use_fast64) ? DIRAL_KERNEL_PACKED : 0) |
                      (k.extra ? DIRAL_KERNEL_EXTRA : 0) | (k.ch ? DIRAL_KERNEL_CH : 0) | (use_ring ? DIRAL_KERNEL_RING : 0);
-    if (use_wide) return vpl == 2 ? launch_wide2(f, r, k, p.B, s) : launch_wide4(f, r, k, p.B, s);
+    if (use_wide) {
+      const int grid = p.B + (slow_first ? fast_slow_max(p.B) : 0);
+      return vpl == 2 ? launch_wide2(f, r, k, grid, s) : launch_wide4(f, r, k, grid, s);
+    }
     if (kslots) {
       // the env stays on the chip from slot to slot: step_fast64_slots_kernel
       if (!k.rich) { r.plain_state = 1; }
@@ -649,11 +658,13 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
       CREATE_TRY(hipMemset(e->tseq, 0, ((size_t)e->B * e->NR + 64) * 4));
       CREATE_TRY(hipMemset(e->told, 0, (nq + 16) * 4));
     }
-    if (e->vpl == 1) {
+    {
       CREATE_TRY(alloc((void**)&e->slow, 3 * slow_set_words(e) * 4));
       CREATE_TRY(hipMemset(e->slow, 0, 3 * slow_set_words(e) * 4));
       const char* off = std::getenv("DIRAL_NO_SLOW_FIRST");
       e->slow_first = !(off && off[0] == '1');
+    }
+    if (e->vpl == 1) {
       if (const char* fm = std::getenv("DIRAL_F32_MARGIN")) e->f32_margin = std::max(0, std::atoi(fm));
     }
     e->ring_valid = true;                                       // all tables zero: never heard, age 0, xpos 0

@@ -23,7 +23,7 @@ struct KernelSel {
   bool ch;      // my_step_ch
   bool extra;   // my_step_design / arrival stamps / trace replay compiled in
   bool rich;    // rich_out.hpp output tail
-  bool packed;  // step_wide at N > 128: the packed table form (codes + ages), else the (seq, age) plane
+  bool packed;  // step_wide: the packed table form (codes + ages), else the (seq, age) plane
 };
 
 hipError_t launch_fast64(const FastParams& f, const RichParams& r, const KernelSel& k, int B, hipStream_t s);

@@ -36,7 +36,7 @@ namespace diral {
 constexpr int kWideMaxA = 64;
 
 struct WideLds {
-  uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, pbytes, lut, total;
+  uint32_t px, npx, rv, edges, red, mask, act, cnt, hist, mtab, scratch, pbytes, lut, slow, total;
 };
 #ifndef DIRAL_WIDE_WAVES4
 #define DIRAL_WIDE_WAVES4 8              // waves per workgroup at N <= 256 (each owns 256 / waves subject columns)
@@ -49,6 +49,14 @@ __host__ __device__ constexpr int wide_waves(int vpl) { return vpl == 2 ? 8 : DI
 #ifndef DIRAL_WIDE_PC4
 #define DIRAL_WIDE_PC4 8                 // subject columns per merge pass, N <= 256 (4 until the xpos ring freed the registers: C3 -3.5 %)
 #endif
+// The B operand's table: 256 entries of 8 x bf16 - one 16-byte read per K step; the rows a quarter wave reads are random, half
+// the LDS cycles of the product are bank conflicts.  DIRAL_WIDE_NIBBLE_LUT=1: 16 entries of 4 x bf16 instead - 128 bytes, every
+// entry in banks of its own, two conflict-free 8-byte reads per K step: bit-exact, and measured SLOWER (C3 1.33 -> 1.36 ms, C5
+// +- 0: twice the LDS instructions and two more VALU instructions per K step cost more than the conflicts).
+#ifndef DIRAL_WIDE_NIBBLE_LUT
+#define DIRAL_WIDE_NIBBLE_LUT 0
+#endif
+constexpr uint32_t kWideLutBytes = DIRAL_WIDE_NIBBLE_LUT ? 128u : 4096u;
 // merge scratch per wave: a pass's rank words (one byte per column and viewer), then the
 // rank -> xpos table (256 doubles)
 // (N <= 256: + 64 bytes in front of the lag -> xpos table of the packed form's finalize phase, whose lookup of a
@@ -74,16 +82,17 @@ __host__ __device__ inline WideLds wide_lds_layout(int vpl, int A, int K, bool p
   l.scratch = 0;
   uint32_t o = wide_scratch(vpl) * wide_waves(vpl);        // 2 KB per wave (4 KB at 16 columns per pass)
   // the packed form's merge (step_wide_closure.inc), at compile-time addresses as well (DS immediate offsets): the
-  // reachability matrix P of the slot as bytes [viewer][lane half][K step] (8 KB at N = 256) and the 256-entry
-  // bits -> 8 x bf16 table of the product's B operand
+  // reachability matrix P of the slot as bytes [viewer][lane group][K step] (8 KB at N = 256, 2 KB at N = 128) and the
+  // 256-entry bits -> 8 x bf16 table of the product's B operand
   l.pbytes = l.lut = o;
-  // (+ the closure's own rows of P - 16 bytes x 2 waves per viewer - and one row-ready flag per resource: it runs beside P1)
-  if (packed) { l.pbytes = o; o += 32u * npad; l.lut = o; o += 4096u; o += 32u * npad; o += 4u * (uint32_t)kWideMaxA; }
+  // (+ the closure's own rows of P - npad / 16 bytes x 2 waves per viewer - and one row-ready flag per resource: it runs beside P1)
+  if (packed) { l.pbytes = o; o += 8u * vpl * npad; l.lut = o; o += kWideLutBytes; o += 8u * vpl * npad; o += 4u * (uint32_t)kWideMaxA; }
   l.px = o;    o += 8u * npad;
   l.npx = o;   o += 8u * npad;
   l.rv = o;    o += 8u * A;
   l.edges = o; o += 8u * (K + 2);
   l.red = o;   o += 8u * 4 * vpl;
+  l.slow = o;  o += 8u;                                  // the env holds a pass beyond the codes: a place among the first blocks of the next launch
   l.mask = o;  o += 8u * A * vpl;
   l.act = o;   o += 4u * npad;
   l.cnt = o;   o += 4u * npad;
@@ -201,16 +210,16 @@ __device__ inline void unpack_src(unsigned int mw, unsigned int (&a)[VPL]) {
   }
 }
 
-// byte BYTE of a word of table indices, times 16: the LDS byte offset of that row of the bits -> 8 x bf16 table
+// byte BYTE of a word of table indices, times 2^SH: the LDS byte offset of that row of the bits -> bf16 table
 // (step_wide_closure.inc), shift and byte extraction in one SDWA instruction
-template <int BYTE>
+template <int BYTE, unsigned int SH = 4u>
 __device__ inline unsigned int lut_row(unsigned int w) {
   unsigned int r;
   static_assert(BYTE >= 0 && BYTE < 4, "byte select");
-  if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(4u), "v"(w));
-  if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(4u), "v"(w));
-  if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(4u), "v"(w));
-  if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(4u), "v"(w));
+  if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(SH), "v"(w));
+  if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(SH), "v"(w));
+  if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(SH), "v"(w));
+  if constexpr (BYTE == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(SH), "v"(w));
   return r;
 }
 
@@ -280,6 +289,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_MINWAVES4P
 #define DIRAL_WIDE_MINWAVES4P 4          // ... the packed form: 128 VGPRs (the product's A operand alone takes 64), two workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_MINWAVES2P
+#define DIRAL_WIDE_MINWAVES2P 6          // N <= 128, packed form: 84 VGPRs, three workgroups per CU (43 KB of LDS each)
+#endif
 
 // FULL: N == 64 * VPL (every viewer slot and subject row exists): the u < N / k < N predicates
 // are compiled out (BASELINE.json's 128- and 256-vehicle configurations)
@@ -292,8 +304,7 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 // by more than 7 stamps (sparse topologies, and configs[4] at N <= 128) every pass of the packed form would detour
 // through the planes - those handles keep the plane form.
 template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH, bool PACKED>
-__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVES2 : (PACKED ? DIRAL_WIDE_MINWAVES4P : DIRAL_WIDE_MINWAVES4)) void step_wide_kernel(const FastParams p, const RichParams r) {
-  static_assert(!PACKED || VPL == 4, "the packed pass exists for N > 128");
+__global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WIDE_MINWAVES2P : DIRAL_WIDE_MINWAVES2) : (PACKED ? DIRAL_WIDE_MINWAVES4P : DIRAL_WIDE_MINWAVES4)) void step_wide_kernel(const FastParams p, const RichParams r) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
   constexpr int CPW = NPAD / WAVES;            // subject columns per wave
   constexpr int PC = VPL == 2 ? DIRAL_WIDE_PC2 : DIRAL_WIDE_PC4;   // subject columns per pass
@@ -348,7 +359,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     return reinterpret_cast<int*>(smem + lay.scratch + SCR * (u >> 6) + 512u) + (u & 63);
   };
 
-  const int b = blockIdx.x;
+  // which env: blocks = envs in order, or (slow envs first, FastParams::slow_*: step_fast64.hpp) the listed envs in the
+  // first fast_slow_max(B) blocks.  At N <= 128 on a highway of configs[4]'s density one env in ten has broken into
+  // clusters that no longer hear each other: nearly all its passes leave the codes (byte ranks through the planes) and
+  // its workgroup lives 3-4 times as long as the others' - dispatched in batch order the last of them end the launch late.
+  int b = blockIdx.x;
+  unsigned int listed = 0u;                  // (ordinary block) != 0: this env ran in one of the first blocks
+  if (p.slow_cnt_r) {
+    const int smax = fast_slow_max(p.B);
+    if (blockIdx.x < (unsigned int)smax) {
+      if (blockIdx.x >= *p.slow_cnt_r) return;
+      b = (int)p.slow_list_r[blockIdx.x];
+    } else {
+      b = (int)blockIdx.x - smax;
+      listed = p.slow_flag_r[b];             // a scalar load in flight next to the loads of P0; tested before any global store
+    }
+  }
+  unsigned int* const s_slow = reinterpret_cast<unsigned int*>(smem + lay.slow);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,20 +414,23 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   }
   for (int j = tid; j < KP * NPAD; j += THREADS) s_hist[j] = 0u;
   if (tid <= K + 1) s_edges[tid] = p.edges[tid < K ? tid : K];
+  if (tid == THREADS - 1) s_slow[0] = 0u;
   // PACKED: the closure of the slot's gossip runs beside P1 (below): compile-time LDS addresses behind the merge scratch
   // (step_wide_closure.inc), the bits -> 8 x bf16 table of the product and the row-ready flags of the gather table
-  constexpr unsigned int kClPb = wide_scratch(VPL) * WAVES, kClLut = kClPb + 32u * NPAD, kClRows = kClLut + 4096u,
-                         kClFlag = kClRows + 32u * NPAD;
+  constexpr unsigned int kClPb = wide_scratch(VPL) * WAVES, kClLut = kClPb + 8u * VPL * NPAD, kClRows = kClLut + kWideLutBytes,
+                         kClFlag = kClRows + 8u * VPL * NPAD;
   constexpr int P1W = PACKED ? WAVES - 2 : WAVES;         // waves that run P1 (PACKED: the last two walk the closure)
   if constexpr (PACKED) {
-    if (tid < 256) {
+    if (tid < (DIRAL_WIDE_NIBBLE_LUT ? 16 : 256)) {
       typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
       u32x4 t;                                              // entry e, element j = bit j of e, 0.0 / 1.0
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
         t[jj] = ((((unsigned int)tid >> (2 * jj)) & 1u) ? 0x3f80u : 0u) | ((((unsigned int)tid >> (2 * jj + 1)) & 1u) ? 0x3f800000u : 0u);
-      reinterpret_cast<u32x4*>(smem + kClLut)[tid] = t;
-    } else if (tid < 256 + kWideMaxA) {
+      if constexpr (DIRAL_WIDE_NIBBLE_LUT) reinterpret_cast<u32x2*>(smem + kClLut)[tid] = u32x2{t[0], t[1]};
+      else reinterpret_cast<u32x4*>(smem + kClLut)[tid] = t;
+    } else if (tid >= 256 && tid < 256 + kWideMaxA) {
       reinterpret_cast<unsigned int*>(smem + kClFlag)[tid - 256] = 0u;
     }
   }
@@ -408,6 +438,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // |x_w - x_u| is >= 2^-499 and IS the reference's sqrt(fl(dx^2)) - the search runs without the per-pair exponent test)
   // (carried through the `s_red` slots, free until P2: __syncthreads_or would bring static LDS, and the merge loop
   // relies on the dynamic segment starting at LDS address 0)
+  if (listed) return;                        // (uniform; nothing has left the workgroup yet)
   if (tid < NPAD) {
     const unsigned long long uns = __ballot(x_unsafe != 0);
     if (lane == 0) reinterpret_cast<int*>(s_red)[wave] = uns != 0ull ? 1 : 0;
@@ -586,15 +617,20 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
     if (wave >= P1W) {
       if (!(__builtin_amdgcn_readfirstlane(lds_addr(smem)) == 0u)) __builtin_trap();   // (compile-time LDS addresses: dynamic segment at 0)
       typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+      // a wave's share of a row of P: NPAD / 2 source bits = 16 bytes (N <= 256) / 8 bytes (N <= 128) per viewer
+      typedef typename std::conditional<VPL == 4, u32x4, u32x2>::type rowv_t;
+      constexpr unsigned int RB = 4u * VPL;                // bytes of that share; log2: 4 / 3
+      constexpr unsigned int RSH = VPL == 4 ? 4u : 3u;
       const int cwv = wave - P1W;
-      unsigned char* const rows = smem + kClRows + 16u * NPAD * cwv;
+      unsigned char* const rows = smem + kClRows + RB * NPAD * cwv;
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
-        const int u = lane + 64 * j;                       // identity: bit u of the 256-bit row, this wave's 128-bit half
-        u32x4 id = {0u, 0u, 0u, 0u};
+        const int u = lane + 64 * j;                       // identity: bit u of the NPAD-bit row, this wave's half
+        rowv_t id;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) id[w] = (u >> 5) == 4 * cwv + w ? 1u << (u & 31) : 0u;
-        reinterpret_cast<u32x4*>(rows)[u] = id;
+        for (int w = 0; w < VPL; ++w) id[w] = (u >> 5) == VPL * cwv + w ? 1u << (u & 31) : 0u;
+        reinterpret_cast<rowv_t*>(rows)[u] = id;
       }
       wave_lds_order();
       const volatile unsigned int* const flag = reinterpret_cast<const volatile unsigned int*>(smem + kClFlag);
@@ -616,32 +652,38 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
         fl_n = (unsigned int)__builtin_amdgcn_readfirstlane((int)fl_n);
         if (i + 1 >= A) fl_n = 0u;
         unsigned int sa[VPL];
-        unpack_src<VPL, 4u>(mw, sa);                          // source viewer * 16: the byte offset of its row
-        u32x4 g[VPL];
+        unpack_src<VPL, RSH>(mw, sa);                         // source viewer * RB: the byte offset of its row
+        rowv_t g[VPL];
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) g[j] = *reinterpret_cast<const u32x4*>(rows + sa[j]);
+        for (int j = 0; j < VPL; ++j) g[j] = *reinterpret_cast<const rowv_t*>(rows + sa[j]);
         wave_lds_order();
         // (a vehicle without a source gathers its own row: a no-op; the transmitters of this resource are nobody's
         // receivers in this step, so their rows are read as the earlier steps left them - in-order LDS queue)
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
-          unsigned long long* const own = reinterpret_cast<unsigned long long*>(rows) + 2 * (lane + 64 * j);
+          unsigned long long* const own = reinterpret_cast<unsigned long long*>(rows + RB * (lane + 64 * j));
           __hip_atomic_fetch_or(own, ((unsigned long long)g[j][1] << 32) | g[j][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_or(own + 1, ((unsigned long long)g[j][3] << 32) | g[j][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if constexpr (VPL == 4)
+            __hip_atomic_fetch_or(own + 1, ((unsigned long long)g[j][3] << 32) | g[j][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         wave_lds_order();
       }
-      // P as bytes [viewer][lane group g][K step s]: byte g of dword s of the viewer's 32-byte row = the sources
-      // 32 s + 8 g + (0 .. 7); this wave owns the dwords s = 4 cwv ... 4 cwv + 3: four bytes per lane group
+      // P as bytes [viewer][lane group g][K step s]: byte g of dword s of the viewer's row = the sources
+      // 32 s + 8 g + (0 .. 7); this wave owns the dwords s = VPL cwv ... VPL cwv + VPL - 1: VPL bytes per lane group
 #pragma unroll
       for (int j = 0; j < VPL; ++j) {
         const unsigned int u = (unsigned int)lane + 64u * j;
-        const u32x4 r = reinterpret_cast<const u32x4*>(rows)[u];
+        const rowv_t r = reinterpret_cast<const rowv_t*>(rows)[u];
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
           const unsigned int sel = 0x0c0c0000u | ((4u + gg) << 8) | (unsigned int)gg;
-          const unsigned int lo16 = __builtin_amdgcn_perm(r[1], r[0], sel), hi16 = __builtin_amdgcn_perm(r[3], r[2], sel);
-          *reinterpret_cast<unsigned int*>(smem + kClPb + u * 32u + gg * 8u + 4u * cwv) = lo16 | (hi16 << 16);
+          const unsigned int lo16 = __builtin_amdgcn_perm(r[1], r[0], sel);
+          if constexpr (VPL == 4) {
+            const unsigned int hi16 = __builtin_amdgcn_perm(r[3], r[2], sel);
+            *reinterpret_cast<unsigned int*>(smem + kClPb + u * 32u + gg * 8u + 4u * cwv) = lo16 | (hi16 << 16);
+          } else {
+            *reinterpret_cast<unsigned short*>(smem + kClPb + u * 16u + gg * 4u + 2u * cwv) = (unsigned short)lo16;
+          }
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -740,7 +782,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
   // neighbour count per viewer: in registers where the VGPR budget has room (N <= 128: one
   // barrier and one pass over the histogram less), else the row sum of the histogram
-  constexpr bool REGCNT = VPL == 2;
+  constexpr bool REGCNT = VPL == 2 && !PACKED;   // (the packed form's coded finalize counts by the row sum)
   unsigned int mycnt[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
@@ -897,6 +939,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
           }
         }
         if (lane == 0) g_told[qrow + w] = anyk ? 1u : 0u;
+        if (anyk && lane == 0) s_slow[0] = 1u;
       }
     }
       }
@@ -909,6 +952,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
 #define DIRAL_PASS_THERMO_FIRST true
 #include "step_wide_pass.inc"
 #undef DIRAL_PASS_THERMO_FIRST
+    if (!thermo && lane == 0) s_slow[0] = 1u;    // (the pass left the codes: byte ranks or 32-bit keys)
 #ifdef DIRAL_TIMING
     DIRAL_WCLOCK(tc3);
     acc_load += tc1 - tc0; acc_merge += tc2 - tc1; acc_fin += tc3 - tc2;
@@ -946,6 +990,20 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? DIRAL_WIDE_MINWAVE
   const LateFastArgs lp = (LateFastArgs)late;
   void* const state_out = lp->state_out;
   if (tid == 0) {
+    // the next launch's order: a slow env asks for a place among the first blocks (as step_fast64_body.inc)
+    uint32_t* const flag_w = lp->slow_flag_w;
+    if (flag_w) {
+      unsigned int fl = 0u;
+      if (s_slow[0]) {
+        const unsigned int pos = atomicAdd(lp->slow_cnt_w, 1u);
+        if (pos < (unsigned int)fast_slow_max(lp->B)) { lp->slow_list_w[pos] = (unsigned int)b; fl = 1u; }
+      }
+      flag_w[b] = fl;
+      // the set the launch after the next builds: count AND flags emptied (step_fast64.hpp)
+      uint32_t* const set_z = lp->slow_cnt_z;
+      set_z[16 + fast_slow_max(lp->B) + b] = 0u;
+      if (b == 0) *set_z = 0u;
+    }
     uint8_t* const done_out = lp->done_out;
     if (done_out) {
       int dn = lp->done_now;                                      // (slot clock: see step_fast64.hpp)

@@ -12,8 +12,8 @@ C2 (N=64, A=32, S=52): 155136 B/env-slot = 2424 B/agent-step.  This is the figur
 `roofline.achieved` is built from (the task's definition).
 
 The layout of this build moves fewer bytes: per table entry one byte of thermometer code (the
-entry's lag behind its subject) and one byte of age (N <= 64 and N > 128; a 4-byte (seq, age)
-word for 64 < N <= 128) - the xpos of an entry that lags its subject by at most 7 stamps comes
+entry's lag behind its subject) and one byte of age (a 4-byte (seq, age) word for step_wide's
+plane form: sparse topologies at N > 64) - the xpos of an entry that lags its subject by at most 7 stamps comes
 from an 8-deep per-subject ring (csrc/step_fast64.hpp, step_wide.hpp), and in
 steady state that is every entry; the per-entry planes are touched only for older entries.
 `layout_bytes_per_env_slot` is that figure (the rocprofv3 FETCH_SIZE / WRITE_SIZE counters show
@@ -30,11 +30,12 @@ def algorithmic_bytes_per_env_slot(n: int, a: int, s: int) -> int:
 
 
 def packed_table(n: int) -> bool:
-    """The DEFAULT table form by size: packed codes + ages (2 B per entry) for step_fast64 (N <= 64) and step_wide at
-    N > 128 on dense topologies; N in (64, 128] keeps the 4-byte (seq, age) word (csrc/step_wide.hpp).  The runtime
-    chooses per handle (density, DIRAL_TABLE_FORM: csrc/diral_env.hip use_packed_table): callers that have a handle
-    pass `packed = bool(env.last_kernel() & KERNEL_PACKED)` to layout_bytes_per_env_slot instead of relying on this."""
-    return n <= 64 or n > 128
+    """The DEFAULT table form of the BASELINE configurations: packed codes + ages (2 B per entry) for step_fast64
+    (N <= 64) and for step_wide on dense topologies (configs[2] and [4]); a sparse highway at N > 64 keeps the 4-byte
+    (seq, age) word (csrc/step_wide.hpp).  The runtime chooses per handle (density, DIRAL_TABLE_FORM: csrc/diral_env.hip
+    use_packed_table): callers that have a handle pass `packed = bool(env.last_kernel() & KERNEL_PACKED)` to
+    layout_bytes_per_env_slot instead of relying on this."""
+    return True
 
 
 def layout_bytes_per_env_slot(n: int, a: int, s: int, emit_chobs: bool, out_bytes: int = 4, packed=None) -> int:

@@ -3,6 +3,8 @@ output dtype and outputs bench.py times - f32 state + reward + channel observati
 topology from the bench's seed - at the bench's batch sizes.  Size-independent properties on EVERY env, and
 sampled envs compared bit for bit with the oracle (state, reward AND channel observation; the f32 outputs are
 the float32 cast of the reference's float64 values)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GLOBAL_SEED = 1234      # bench.py's
 
 
-def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32, env_offset=0, n_gap=0, min_slow=0):
+def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32, env_offset=0, n_gap=0, min_slow=0, min_dense=8):
     from diral_amd.vec_env import VecV2VEnv
     from oracle.oracle import Oracle, SQ_IEEE
     cfg = bench_config(N, A, L, mobility_vary=vary)
@@ -41,12 +43,12 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32,
     orc = Oracle(cfg, batch=n_sample, sq_mode=SQ_IEEE, threads=8)
     orc.reset(st0["pos_x"][sample_t].cpu().numpy(), st0["pos_y"][sample_t].cpu().numpy(), st0["vel"][sample_t].cpu().numpy())
     g = torch.Generator(device="cuda:0").manual_seed(7)
+    packed = os.environ.get("DIRAL_TABLE_FORM") != "plane"       # (the BASELINE configurations are dense: packed by default)
     for t in range(T):
         a_t = torch.randint(0, A, (B, N), device="cuda:0", dtype=torch.int32, generator=g)
         obs, rew, done = env._step(STEP_MY_STEP, a_t, t, want_chobs=True)     # what bench.py's timed step calls
         chobs = env._chobs
-        # (the packed table form: N <= 64, and N > 128 on a dense topology; N = 128 keeps the (seq, age) plane)
-        assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_RING | (0 if N == 128 else KERNEL_PACKED), env.last_kernel()
+        assert env.last_kernel() == fam | KERNEL_RICH | KERNEL_RING | (KERNEL_PACKED if packed else 0), env.last_kernel()
         al = a_t.long()
         # (1) one-hot section == actions
         assert torch.equal(obs[..., :A].argmax(-1), al) and torch.all(obs[..., :A].sum(-1) == 1)
@@ -96,7 +98,7 @@ def _run(N, A, L, B, vary, n_sample, T, fam, vel_slot=None, dtype=torch.float32,
         dense = ~((seq == 0).flatten(1).any(dim=1)) & ~beyond          # every entry heard and within the codes: fast quads only
         slow_sampled = int(beyond[sample_t].sum())
         assert slow_sampled >= min_slow, (slow_sampled, int(beyond.sum()))
-        assert int(dense[sample_t].sum()) >= 8, int(dense[sample_t].sum())
+        assert int(dense[sample_t].sum()) >= min_dense, int(dense[sample_t].sum())
         # slow-first dispatch is on (DIRAL_NO_SLOW_FIRST unset): the listed envs ran in the front-of-grid blocks, every env
         # exactly once - the diagonal check above
     env.check()
@@ -115,8 +117,12 @@ def test_c3_benchmarked_instantiation_full_size():
 
 
 def test_c5_benchmarked_instantiation_full_size():
-    """configs[4]: 128 UE / 64 res, mobility_vary, B = 16384 - step_wide_kernel<2,...>; one update_velocity."""
-    _run(128, 64, 4000.0, 16384, True, n_sample=10, T=32, fam=KERNEL_WIDE, vel_slot=24)
+    """configs[4]: 128 UE / 64 res, mobility_vary, B = 16384 - step_wide_kernel<2,false,true,false,false,true,true>, the packed
+    table form; one update_velocity.  One env in ten of this density has broken into clusters that no longer hear each
+    other - its passes leave the codes (flagged passes through the planes, byte ranks) and it runs in the front-of-grid
+    blocks of the slow-first dispatch: the 6 envs with the widest gaps are in the oracle sample beside 10 random ones, at
+    least 4 envs that end the run with an entry beyond the codes are compared bit for bit."""
+    _run(128, 64, 4000.0, 16384, True, n_sample=10, T=48, fam=KERNEL_WIDE, vel_slot=24, n_gap=6, min_slow=4, min_dense=0)
 
 
 def test_c4_shard_benchmarked_instantiation_full_size():

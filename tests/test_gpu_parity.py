@@ -946,18 +946,22 @@ def test_wide_kernel_matches_general_kernel_and_oracle(N, A, K, rd, toy):
 
 @pytest.mark.parametrize("N,stale_frac,lag_hi", [(256, 0.0, 40), (256, 0.01, 40), (128, 0.3, 40), (150, 0.05, 40),
                                                  (256, 0.0, 8), (128, 0.0, 8), (150, 0.0, 5), (256, 0.0, -1), (128, 0.0, -1),
-                                                 (200, 0.002, -1), (256, 0.0, 9)])
+                                                 (200, 0.002, -1), (256, 0.0, 9),
+                                                 (128, -0.3, 40), (256, -0.2, 40), (150, -0.4, -1), (100, -0.5, 8)])
 def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac, lag_hi):
     """step_wide merges a pass of subject columns as 8-level thermometer codes when every entry
     of the pass is at most 7 slots behind (or never heard), as 8-bit ranks when younger than 255
     slots, and takes the 32-bit (seq, source) path otherwise; imported tables with chosen lags
     exercise all three against the oracle (lag_hi -1: subjects alternate between lags < 8 and
     < 40, so consecutive passes of one launch take different paths; 9: a single lag-8 entry
-    here and there is enough to leave the thermometer path)."""
+    here and there is enough to leave the thermometer path).  A negative stale_frac: the stale entries of a subject
+    all hold ONE sequence number (what a highway that broke into clusters leaves behind) - except for every seventh
+    subject, which holds two: the byte ranks carry the former (they share the lowest rank), the latter still takes the
+    32-bit path."""
     from oracle.oracle import Oracle, SQ_IEEE
     A, T0, B = 64, 5000, 4
     cfg = bench_config(N, A, 15.0 * N + 100)
-    rng = np.random.default_rng(int(stale_frac * 1000) + N + 7 * lag_hi)
+    rng = np.random.default_rng(int(abs(stale_frac) * 1000) + N + 7 * lag_hi + (500 if stale_frac < 0 else 0))
     x0 = rng.integers(0, int(cfg.highway_length), size=(B, N)).astype(np.float64)
     v0 = rng.uniform(1.1, 2.7, size=(B, N))
     if lag_hi > 0:
@@ -965,8 +969,13 @@ def test_wide_rank_merge_and_its_fallback_on_stale_tables(N, stale_frac, lag_hi)
     else:
         hi = np.where((np.arange(N) // 4) % 3 == 0, 40, 8)[None, :, None] * np.ones((B, 1, 1), dtype=np.int64)
     seq = T0 - rng.integers(0, hi, size=(B, N, N))             # [env][subject][viewer]
-    stale = rng.random((B, N, N)) < stale_frac
-    seq = np.where(stale, rng.integers(0, T0 - 255, size=(B, N, N)), seq)   # lag >= 255, some seq == 0
+    stale = rng.random((B, N, N)) < abs(stale_frac)
+    if stale_frac < 0:
+        common = rng.integers(1, T0 - 255, size=(B, N, 1)) + np.zeros((1, 1, N), dtype=np.int64)
+        two = (np.arange(N) % 7 == 3)[None, :, None] & (rng.random((B, N, N)) < 0.5)
+        seq = np.where(stale, np.where(two, np.maximum(common - 3, 1), common), seq)
+    else:
+        seq = np.where(stale, rng.integers(0, T0 - 255, size=(B, N, N)), seq)   # lag >= 255, some seq == 0
     seq = np.where(rng.random((B, N, N)) < 0.05, 0, seq)                    # never-heard entries
     seq[:, np.arange(N), np.arange(N)] = T0
     age = rng.integers(0, 40, size=(B, N, N))
@@ -1240,9 +1249,10 @@ def test_dispatch_guard_specialised_kernels_serve_the_common_configurations(N, A
     a = env.sample(seed=1)
     env.step(a, 0)
     from diral_amd.config import KERNEL_PACKED
-    # the xpos ring rides on every specialised launch; the packed table form at N <= 64 and, on these dense topologies,
-    # at N > 128
-    ring = KERNEL_RING | (KERNEL_PACKED if (N <= 64 or N > 128) else 0)
+    # the xpos ring rides on every specialised launch; the packed table form at N <= 64 and, on dense topologies
+    # (N * 2 Rc / L >= 15 neighbours at N <= 128, 20 above), at N > 64
+    dense = N * 2 * cfg.communication_range / L >= (15 if N <= 128 else 20)
+    ring = KERNEL_RING | (KERNEL_PACKED if (N <= 64 or dense) else 0)
     assert env.last_kernel() == fam | ring                              # plain
     chobs, rew = env.my_step(a, 1)
     assert env.last_kernel() == fam | KERNEL_RICH | ring
@@ -1382,6 +1392,8 @@ def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
 
 @pytest.mark.parametrize("N,A,L,Rc,form", [(64, 32, 2000.0, 250.0, None), (40, 9, 1500.0, 250.0, None), (64, 16, 9000.0, 140.0, None),
                                            (33, 5, 6000.0, 100.0, None), (128, 64, 4000.0, 250.0, None), (96, 12, 20000.0, 120.0, None),
+                                           (128, 64, 4000.0, 250.0, "plane"), (96, 12, 20000.0, 120.0, "packed"), (100, 20, 2500.0, 250.0, None),
+                                           (100, 20, 2500.0, 250.0, "plane"),
                                            (256, 64, 4000.0, 250.0, None), (256, 64, 4000.0, 250.0, "plane"),
                                            (200, 24, 30000.0, 140.0, None), (200, 24, 30000.0, 140.0, "packed"),
                                            (256, 16, 12000.0, 250.0, "packed")])
@@ -1398,11 +1410,11 @@ def test_packed_tables_and_xpos_ring_agree_with_the_oracle_through_every_consume
     from oracle.oracle import Oracle, SQ_IEEE
     from diral_amd.config import KERNEL_FAST64, KERNEL_GENERAL, KERNEL_PACKED, KERNEL_RING, KERNEL_WIDE
     cfg = bench_config(N, A, L, mobility_vary=True, communication_range=Rc)
-    # the table form of a 128 < N <= 256 handle follows the density (N * 2 Rc / L >= 20 neighbours: packed); `form`
-    # forces the other one (DIRAL_TABLE_FORM, read at create): both forms on both kinds of topology
+    # the table form of a 64 < N <= 256 handle follows the density (N * 2 Rc / L >= 20 neighbours, 15 at N <= 128: packed);
+    # `form` forces the other one (DIRAL_TABLE_FORM, read at create): both forms on both kinds of topology
     if form:
         monkeypatch.setenv("DIRAL_TABLE_FORM", form)
-    want_packed = N <= 64 or (N > 128 and (form == "packed" or (form is None and N * 2 * Rc / L >= 20)))
+    want_packed = N <= 64 or form == "packed" or (form is None and N * 2 * Rc / L >= (15 if N <= 128 else 20))
     B = 4
     rng = np.random.default_rng(N * 7 + A)
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)

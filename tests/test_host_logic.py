@@ -216,17 +216,18 @@ def test_metric_allreduce_over_gloo_world2():
 
 def test_byte_models_of_the_roofline_bookkeeping():
     """SURVEY 8d's canonical bytes per env-slot (reported as `roofline.model_*`) at the three bench configurations,
-    and this build's layout bytes (`roofline.achieved` / `frac`): packed code + age bytes at N <= 64 and N > 128,
-    4-byte (seq, age) words in between, plus the subjects' xpos rings."""
+    and this build's layout bytes (`roofline.achieved` / `frac`): packed code + age bytes (the BASELINE configurations),
+    4-byte (seq, age) words for step_wide's plane form, plus the subjects' xpos rings."""
     from diral_amd.roofline import (algorithmic_bytes_per_env_slot as alg, layout_bytes_per_env_slot as lay,
                                     packed_table)
     assert alg(64, 32, 52) == 155136 and alg(256, 64, 84) == 2258944 and alg(128, 64, 84) == 605184
-    assert packed_table(64) and packed_table(256) and not packed_table(128) and not packed_table(65)
+    assert packed_table(64) and packed_table(256) and packed_table(128)
     # entries read + written, ring rows read + one stamp written (+ own sequence numbers r/w), per-vehicle arrays,
     # reward, state (+ channel observation)
     assert lay(64, 32, 52, False) == 2 * 2 * 64 * 64 + 80 * 64 + 36 * 64 + 4 * 64 + 4 * 64 * 52
     assert lay(64, 32, 52, True) - lay(64, 32, 52, False) == 4 * 64 * 32
-    assert lay(128, 64, 84, False) == 2 * 4 * 128 * 128 + 72 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
+    assert lay(128, 64, 84, False, packed=False) == 2 * 4 * 128 * 128 + 72 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
+    assert lay(128, 64, 84, False) == 2 * 2 * 128 * 128 + 80 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
     assert lay(256, 64, 84, False) == 2 * 2 * 256 * 256 + 80 * 256 + 36 * 256 + 4 * 256 + 4 * 256 * 84
     assert 5 * lay(256, 64, 84, False) < alg(256, 64, 84)
     # where a launch's reads can come from (`roofline.memory`): the state C2's 4096 envs re-read every launch fits the
