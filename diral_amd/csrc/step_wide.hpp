@@ -289,6 +289,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_MINWAVES4P
 #define DIRAL_WIDE_MINWAVES4P 4          // ... the packed form: 128 VGPRs (the product's A operand alone takes 64), two workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_FLAG_UNROLL
+#define DIRAL_WIDE_FLAG_UNROLL 1         // column loops of a flagged pass's unpack / repack stages (4 - the four loads of a word in flight together - measured C5 + 4 %: registers)
+#endif
 #ifndef DIRAL_WIDE_MINWAVES2P
 #define DIRAL_WIDE_MINWAVES2P 6          // N <= 128, packed form: 84 VGPRs, three workgroups per CU (43 KB of LDS each)
 #endif
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
   // (Network.dist_piggy + get_positional_dist_2_piggy, network.py:538-558, 473-513)
   // neighbour count per viewer: in registers where the VGPR budget has room (N <= 128: one
   // barrier and one pass over the histogram less), else the row sum of the histogram
-  constexpr bool REGCNT = VPL == 2 && !PACKED;   // (the packed form's coded finalize counts by the row sum)
+  constexpr bool REGCNT = VPL == 2 && !PACKED;   // (the packed form's coded finalize counts by the row sum: a per-slot count + one LDS atomic there measured C5 + 5 %)
   unsigned int mycnt[VPL];
 #pragma unroll
   for (int j = 0; j < VPL; ++j) mycnt[j] = 0u;
@@ -867,6 +870,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
 #endif
     }
     // ---- flagged pass: through the planes ------------------------------------------------------------------
+    // (timing builds: unpack / plane pass / repack of the flagged passes go to the load / merge / finalize accumulators)
+    unsigned long long tf0 = 0, tf1 = 0, tf2 = 0, tf3 = 0;
+    DIRAL_WCLOCK(tf0);
     {
       // the pass's entries as (seq, age) words, unstamped: coded ones from the subject's own number and the lag,
       // code-0 ones keep the sequence number `tkey` holds (0: never heard); ages from the age words
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
           cwj[j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
           awj[j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
         }
-#pragma unroll 1
+#pragma unroll DIRAL_WIDE_FLAG_UNROLL
         for (int cc = 0; cc < 4; ++cc) {
           const int k = kbase + 4 * w + cc;
           if (!(FULL || k < N)) continue;
@@ -897,9 +903,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       }
       wave_lds_order();
     }
+    DIRAL_WCLOCK(tf1);
 #define DIRAL_PASS_THERMO_FIRST false             // (a flagged pass: the codes do not reach - byte ranks, then 32-bit keys)
 #include "step_wide_pass.inc"
 #undef DIRAL_PASS_THERMO_FIRST
+    DIRAL_WCLOCK(tf2);
     {
       // the packed words again, from the (seq, age) words the pass left in `tkey`; the fresh sequence numbers;
       // the flags of the next slot: an entry 7 or more behind keeps its quad on this path
@@ -911,7 +919,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
         bool keep = false;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) { ncw[j] = 0u; naw[j] = 0u; }
-#pragma unroll 1
+#pragma unroll DIRAL_WIDE_FLAG_UNROLL
         for (int cc = 0; cc < 4; ++cc) {
           const int c = 4 * w + cc;
           const int k = kbase + c;
@@ -942,6 +950,10 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
         if (anyk && lane == 0) s_slow[0] = 1u;
       }
     }
+#ifdef DIRAL_TIMING
+    DIRAL_WCLOCK(tf3);
+    acc_load += tf1 - tf0; acc_merge += tf2 - tf1; acc_fin += tf3 - tf2;
+#endif
       }
   } else {
 #pragma unroll 1

@@ -51,6 +51,13 @@ print("B=%d; mean cycles per wave per phase (s_memtime ticks), by wave:" % B)
 for i, n in enumerate(names):
     print("  %-32s %s   all=%.0f" % (n, " ".join("%7.0f" % d[:, w, i].mean() for w in range(min(NW, 4))), d[:, :, i].mean()))
 life = (t[:, :, 7] - t[:, :, 0])
+if os.environ.get("SLOW_SPLIT"):
+    # workgroups whose waves live more than twice the median (step_wide, packed form: envs whose passes left the codes)
+    wl = life.mean(axis=1)
+    slow = wl > 2 * np.median(wl)
+    for nm, sel in (("slow", slow), ("others", ~slow)):
+        if sel.any():
+            print("  %s workgroups (%d): %s  lifetime %.0f" % (nm, int(sel.sum()), " | ".join("%s %.0f" % (n.split()[0] + n.split()[1][:6] if len(n.split()) > 1 else n, d[sel][:, :, i].mean()) for i, n in enumerate(names)), wl[sel].mean()))
 print("  wave lifetime: mean %.0f  p50 %.0f  p99 %.0f" % (life.mean(), np.median(life), np.percentile(life, 99)))
 span = t[:, :, 7].max() - t[:, :, 0].min()
 print("  kernel span %d ticks" % span)
