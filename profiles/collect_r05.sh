@@ -10,7 +10,7 @@ for t in c2_chobs1 c2_chobs0 c3_chobs1 c3_chobs0 c5_chobs1 c5_chobs0 c4shard; do
 done
 for f in full driverlike c3 c3_nochobs c5 c5_nochobs torchrun1; do cp gpurun_out/bench_r05_$f.json profiles/r05/bench_$f.json; done
 grep -v "amdgpu.ids" gpurun_out/bench_r05_torchrun1.log | cut -c1-400 > profiles/r05/bench_torchrun1_rccl.log
-for f in scale rollout side_paths secondary_modes batch_sweep launch_timeline phase_timing phase_timing_wide kslots kslots_timing closure_merge; do [ -f gpurun_out/${f}_r05.txt ] && cp gpurun_out/${f}_r05.txt profiles/r05/$f.txt; done
+for f in scale rollout side_paths secondary_modes batch_sweep launch_timeline phase_timing phase_timing_wide kslots kslots_timing closure_merge c5_forms; do [ -f gpurun_out/${f}_r05.txt ] && cp gpurun_out/${f}_r05.txt profiles/r05/$f.txt; done
 find gpurun_out/prof_secondary -name "*kernel_stats.csv" -exec cp {} profiles/r05/secondary_modes_kernel_stats.csv \;
 find gpurun_out/prof_rollout -name "*kernel_stats.csv" -exec cp {} profiles/r05/rollout_kernel_stats.csv \;
 bash profiles/resource_usage.sh profiles/r05/resource_usage.txt

@@ -34,8 +34,12 @@ if [ -f variants_tmp/lib_timing.so ]; then
   for B in 64 4096; do echo "=== B=$B"; B=$B DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -10; done > gpurun_out/phase_timing_r05.txt
 fi
 python profiles/kslots_bench.py 2>&1 | grep -v amdgpu > gpurun_out/kslots_r05.txt
+# C5: the two table forms of 64 < N <= 128, the packed one with and without its slow envs dispatched first; how many passes leave the codes
+(for F in plane packed; do for S in 0 1; do [ $F = plane ] && [ $S = 0 ] && continue; for i in 1 2; do
+  DIRAL_NO_SLOW_FIRST=$S DIRAL_TABLE_FORM=$F python bench.py --workload c5 --lean --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 form=$F NO_SLOW_FIRST=$S: %.4f ms/step' % d['ms_per_step'], d['roofline'].get('kernel'))"
+done; done; done; python profiles/flag_fraction.py 2>&1 | grep -v amdgpu) > gpurun_out/c5_forms_r05.txt
 if [ -f variants_tmp/lib_timing.so ]; then
-  for W in c3:8192 c5:16384; do w=${W%%:*}; B=${W##*:}; for b in 64 $B; do echo "=== $w B=$b"; WORKLOAD=$w B=$b DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -10; done; done > gpurun_out/phase_timing_wide_r05.txt
+  for W in c3:8192 c5:16384; do w=${W%%:*}; B=${W##*:}; for b in 64 $B; do echo "=== $w B=$b"; SLOW_SPLIT=1 DIRAL_NO_SLOW_FIRST=1 WORKLOAD=$w B=$b DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -12; done; done > gpurun_out/phase_timing_wide_r05.txt
   DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/kslots_timing.py 2>&1 | grep -v amdgpu > gpurun_out/kslots_timing_r05.txt
 fi
 hipcc --offload-arch=gfx950 -O3 profiles/micro/closure_merge.hip -o /tmp/closure_merge && /tmp/closure_merge > gpurun_out/closure_merge_r05.txt 2>&1
