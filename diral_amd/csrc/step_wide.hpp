@@ -289,6 +289,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_MINWAVES4P
 #define DIRAL_WIDE_MINWAVES4P 4          // ... the packed form: 128 VGPRs (the product's A operand alone takes 64), two workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_FUSED_FLAGGED
+#define DIRAL_WIDE_FUSED_FLAGGED 1       // packed form: a flagged pass reads and writes the code words itself (no round trip through `tkey`)
+#endif
 #ifndef DIRAL_WIDE_FLAG_UNROLL
 #define DIRAL_WIDE_FLAG_UNROLL 1         // column loops of a flagged pass's unpack / repack stages (4 - the four loads of a word in flight together - measured C5 + 4 %: registers)
 #endif
@@ -303,9 +306,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 // RICH: the output tail of rich_out.hpp (channel observation output, cheap State flags)
 // PACKED: the table form (the host decides per handle, csrc/diral_env.hip `use_packed_table`): codes + ages + own sequence
 // numbers, or the round-2 (seq, age) plane `tkey` whose passes re-derive the lags every slot and fall back to byte
-// ranks in place.  Dense topologies (BASELINE configs[2]) are 16 % faster packed; where most entries lag their subject
-// by more than 7 stamps (sparse topologies, and configs[4] at N <= 128) every pass of the packed form would detour
-// through the planes - those handles keep the plane form.
+// ranks in place.  Dense topologies (BASELINE configs[2] and [4]) run packed - the coded passes merge as reachability
+// closure + one bf16 product, step_wide_closure.inc -; where most entries lag their subject by more than 7 stamps (sparse
+// topologies) every pass of the packed form would detour through the planes - those handles keep the plane form.
 template <int VPL, bool OUT64, bool FULL, bool CH, bool EXTRA, bool RICH, bool PACKED>
 __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WIDE_MINWAVES2P : DIRAL_WIDE_MINWAVES2) : (PACKED ? DIRAL_WIDE_MINWAVES4P : DIRAL_WIDE_MINWAVES4)) void step_wide_kernel(const FastParams p, const RichParams r) {
   constexpr int NPAD = 64 * VPL, WAVES = wide_waves(VPL), THREADS = 64 * WAVES;
@@ -799,11 +802,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     constexpr int XMODE = decltype(xmode_tag)::value;
     const int u = lane + 64 * j;
     const bool lv = FULL || ((u < N) && kvalid);
-    const bool slot_upd = XMODE == 0 ? (__ballot(upd || u == k) != 0ull) : (XMODE == 2 || upd);
+    const bool slot_upd = XMODE == 0 ? (__ballot(upd || u == k) != 0ull) : (XMODE == 2 || upd);   // (1, 4: the lanes with `upd`)
     if constexpr (XMODE == 3) {
       // coded entry (packed table): nothing goes to the planes (the hand-over at lag 7 is the caller's; `wn` is the age)
     } else if (lv) {
-      tkrow[(unsigned int)u] = wn;
+      if constexpr (XMODE != 4) tkrow[(unsigned int)u] = wn;     // (4: the flagged pass of the packed form writes the far entries' words itself)
       if (slot_upd) txrow[(unsigned int)u] = xg;
     }
     // all y == 0: v = x1 - x2 IS d * sign exactly, d = |v| - unless the square underflows, which only the comparison
@@ -841,11 +844,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
   bool ovf = false;
   unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, acc_load = 0, acc_merge = 0, acc_fin = 0, t_p3 = 0;
   DIRAL_WCLOCK(t_p3);
-  // PACKED (128 < N <= 256 on a dense topology, BASELINE configs[2]): codes, ages, own sequence numbers (below).
-  // Otherwise the (seq, age) plane `tkey` as in round 2: at configs[4]'s density (N <= 128) 2 % of the entries lag more
-  // than 7 stamps (profiles/lag_distribution.py) - most passes of 8 x 128 entries hold one -, on sparse topologies most
-  // entries do; the 8-level codes cannot carry them, and the packed form's detour through the planes for such passes
-  // costs more than it saves (C5 + 13 %, a sparse 256-vehicle highway + 60 %).
+  // PACKED (dense topologies, BASELINE configs[2] and [4]): codes, ages, own sequence numbers (below).
+  // Otherwise the (seq, age) plane `tkey` as in round 2: on sparse topologies most entries lag more than 7 stamps; the
+  // 8-level codes cannot carry them, and the packed form's detour through the planes for such passes costs more than it
+  // saves (a sparse 256-vehicle highway + 60 %).  At configs[4]'s density one env in ten - a highway that broke into
+  // clusters - runs nearly all its passes flagged (profiles/flag_fraction.py) and is dispatched first.
   if constexpr (PACKED) {
   // the coded merge + finalize of the clean passes: reachability closure + one bf16 product on the matrix pipe
   // (leaves `passbits`: bit pch = a quad of pass pch was flagged when the slot began -> the loop below)
@@ -873,83 +876,100 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     // (timing builds: unpack / plane pass / repack of the flagged passes go to the load / merge / finalize accumulators)
     unsigned long long tf0 = 0, tf1 = 0, tf2 = 0, tf3 = 0;
     DIRAL_WCLOCK(tf0);
-    {
-      // the pass's entries as (seq, age) words, unstamped: coded ones from the subject's own number and the lag,
-      // code-0 ones keep the sequence number `tkey` holds (0: never heard); ages from the age words
+    // the pass's entries as (seq, age) words in `tkey` / the packed words again from `tkey`: the round trip of round 4's
+    // flagged pass (unpack 35 k + repack 20 k cycles per wave beside a plane pass of 75 k, profiles/r05/phase_timing_wide.txt).
+    // DIRAL_WIDE_FUSED_FLAGGED: the pass builds its lag bytes from the code words and writes code words back itself
+    // (step_wide_pass.inc, DIRAL_PASS_PACKED_IO) - `tkey` is read for code-0 entries and written for entries 7 or more
+    // behind only - and the two stages below serve the 32-bit path alone (it walks `tkey` column by column).
+    auto unpack_pass = [&]() {
+      {
+        // the pass's entries as (seq, age) words, unstamped: coded ones from the subject's own number and the lag,
+        // code-0 ones keep the sequence number `tkey` holds (0: never heard); ages from the age words
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        unsigned int cwj[VPL], awj[VPL];
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          cwj[j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
-          awj[j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
-        }
-#pragma unroll DIRAL_WIDE_FLAG_UNROLL
-        for (int cc = 0; cc < 4; ++cc) {
-          const int k = kbase + 4 * w + cc;
-          if (!(FULL || k < N)) continue;
-          const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
-          const unsigned int ts_old = tsrow[4 * w + cc];
+        for (int w = 0; w < NW; ++w) {
+          unsigned int cwj[VPL], awj[VPL];
 #pragma unroll
           for (int j = 0; j < VPL; ++j) {
-            const int u = lane + 64 * j;
-            if (FULL || u < N) {
-              const unsigned int r = (cwj[j] >> (8 * cc)) & 255u, a = (awj[j] >> (8 * cc)) & 255u;
-              const unsigned int seq = r ? ts_old - 8u + (unsigned int)__popc(r) : (tkrow[(unsigned int)u] >> 8);
-              tkrow[(unsigned int)u] = (seq << 8) | a;
+            cwj[j] = tcrow[(unsigned int)(w * NV) + ul + 64u * j];
+            awj[j] = tarow[(unsigned int)(w * NV) + ul + 64u * j];
+          }
+#pragma unroll DIRAL_WIDE_FLAG_UNROLL
+          for (int cc = 0; cc < 4; ++cc) {
+            const int k = kbase + 4 * w + cc;
+            if (!(FULL || k < N)) continue;
+            const global_ptr<unsigned int> tkrow = uniform_ptr(p.tkey, (bR + k) * NV);
+            const unsigned int ts_old = tsrow[4 * w + cc];
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const int u = lane + 64 * j;
+              if (FULL || u < N) {
+                const unsigned int r = (cwj[j] >> (8 * cc)) & 255u, a = (awj[j] >> (8 * cc)) & 255u;
+                const unsigned int seq = r ? ts_old - 8u + (unsigned int)__popc(r) : (tkrow[(unsigned int)u] >> 8);
+                tkrow[(unsigned int)u] = (seq << 8) | a;
+              }
             }
           }
         }
+        wave_lds_order();
       }
-      wave_lds_order();
-    }
+    };
+    auto repack_pass = [&](unsigned int tkov) {
+      {
+        // the packed words again, from the (seq, age) words the pass left in `tkey`; the fresh sequence numbers;
+        // the flags of the next slot: an entry 7 or more behind keeps its quad on this path
+        if (ul < (unsigned int)PC) tsrow[ul] = tkov;
+        ovf = ovf || (ul < (unsigned int)PC && tkov >= (1u << 24) - 1u);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          unsigned int ncw[VPL], naw[VPL];
+          bool keep = false;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) { ncw[j] = 0u; naw[j] = 0u; }
+#pragma unroll DIRAL_WIDE_FLAG_UNROLL
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = 4 * w + cc;
+            const int k = kbase + c;
+            if (!(FULL || k < N)) continue;
+            const global_ptr<const unsigned int> tkrow = uniform_ptr<const unsigned int>(p.tkey, (bR + k) * NV);
+            const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const int u = lane + 64 * j;
+              if (FULL || u < N) {
+                const unsigned int wk = tkrow[(unsigned int)u];
+                const unsigned int seqf = wk >> 8, lagf = tk_own - seqf;
+                ncw[j] |= ((seqf != 0u && lagf <= 7u) ? ((0xffu << lagf) & 0xffu) : 0u) << (8 * cc);
+                naw[j] |= (wk & 255u) << (8 * cc);
+                keep = keep || (seqf != 0u && lagf >= 7u);
+              }
+            }
+          }
+          const bool anyk = __ballot(keep) != 0ull;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            if (FULL || lane + 64 * j < N) {
+              tcrow[(unsigned int)(w * NV) + ul + 64u * j] = ncw[j];
+              tarow[(unsigned int)(w * NV) + ul + 64u * j] = naw[j];
+            }
+          }
+          if (lane == 0) g_told[qrow + w] = anyk ? 1u : 0u;
+          if (anyk && lane == 0) s_slow[0] = 1u;
+        }
+      }
+    };
+#if !DIRAL_WIDE_FUSED_FLAGGED
+    unpack_pass();
+#endif
     DIRAL_WCLOCK(tf1);
 #define DIRAL_PASS_THERMO_FIRST false             // (a flagged pass: the codes do not reach - byte ranks, then 32-bit keys)
+#define DIRAL_PASS_PACKED_IO DIRAL_WIDE_FUSED_FLAGGED
 #include "step_wide_pass.inc"
+#undef DIRAL_PASS_PACKED_IO
 #undef DIRAL_PASS_THERMO_FIRST
     DIRAL_WCLOCK(tf2);
-    {
-      // the packed words again, from the (seq, age) words the pass left in `tkey`; the fresh sequence numbers;
-      // the flags of the next slot: an entry 7 or more behind keeps its quad on this path
-      if (ul < (unsigned int)PC) tsrow[ul] = tkov;
-      ovf = ovf || (ul < (unsigned int)PC && tkov >= (1u << 24) - 1u);
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        unsigned int ncw[VPL], naw[VPL];
-        bool keep = false;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) { ncw[j] = 0u; naw[j] = 0u; }
-#pragma unroll DIRAL_WIDE_FLAG_UNROLL
-        for (int cc = 0; cc < 4; ++cc) {
-          const int c = 4 * w + cc;
-          const int k = kbase + c;
-          if (!(FULL || k < N)) continue;
-          const global_ptr<const unsigned int> tkrow = uniform_ptr<const unsigned int>(p.tkey, (bR + k) * NV);
-          const unsigned int tk_own = (unsigned int)__builtin_amdgcn_readlane((int)tkov, c);
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            const int u = lane + 64 * j;
-            if (FULL || u < N) {
-              const unsigned int wk = tkrow[(unsigned int)u];
-              const unsigned int seqf = wk >> 8, lagf = tk_own - seqf;
-              ncw[j] |= ((seqf != 0u && lagf <= 7u) ? ((0xffu << lagf) & 0xffu) : 0u) << (8 * cc);
-              naw[j] |= (wk & 255u) << (8 * cc);
-              keep = keep || (seqf != 0u && lagf >= 7u);
-            }
-          }
-        }
-        const bool anyk = __ballot(keep) != 0ull;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j) {
-          if (FULL || lane + 64 * j < N) {
-            tcrow[(unsigned int)(w * NV) + ul + 64u * j] = ncw[j];
-            tarow[(unsigned int)(w * NV) + ul + 64u * j] = naw[j];
-          }
-        }
-        if (lane == 0) g_told[qrow + w] = anyk ? 1u : 0u;
-        if (anyk && lane == 0) s_slow[0] = 1u;
-      }
-    }
+#if !DIRAL_WIDE_FUSED_FLAGGED
+    repack_pass(tkov);
+#endif
 #ifdef DIRAL_TIMING
     DIRAL_WCLOCK(tf3);
     acc_load += tf1 - tf0; acc_merge += tf2 - tf1; acc_fin += tf3 - tf2;
@@ -962,7 +982,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     if (kbase >= NRows) break;
     if (EXTRA && RICH && p.notab) break;         // no piggybacked tables (test_env.py:138-139, 231-238): nothing to stamp, merge or observe
 #define DIRAL_PASS_THERMO_FIRST true
+#define DIRAL_PASS_PACKED_IO 0
 #include "step_wide_pass.inc"
+#undef DIRAL_PASS_PACKED_IO
 #undef DIRAL_PASS_THERMO_FIRST
     if (!thermo && lane == 0) s_slow[0] = 1u;    // (the pass left the codes: byte ranks or 32-bit keys)
 #ifdef DIRAL_TIMING
