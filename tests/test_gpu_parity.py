@@ -1871,20 +1871,22 @@ def test_graph_replays_with_rotating_slow_sets_survive_eager_steps_in_between():
         r.close()
 
 
-@pytest.mark.parametrize("K", [10, 4])
-def test_graph_replays_on_a_frozen_slow_set_survive_eager_steps_in_between(K):
+@pytest.mark.parametrize("K,N,A,L", [(10, 64, 32, 2020.0), (4, 64, 32, 2020.0), (4, 128, 64, 4000.0)])
+def test_graph_replays_on_a_frozen_slow_set_survive_eager_steps_in_between(K, N, A, L):
     """A captured rollout whose launch count is NOT a multiple of three cannot rotate the slow-env sets: every captured
     launch is baked with the set the last eager launch before the capture read.  Eager steps between two replays keep
     rotating through that set - one of them clears it, the next rebuilds it.  A set must be either a complete list or
     EMPTY at every launch boundary (count and flags: step_fast64.hpp), else a replay issued two eager steps after the
     capture finds a zero count under standing flags and steps the flagged envs not at all.  One, two
     and three eager steps between replays; against the same sequence without a graph, bit for bit; every env's slot
-    counter advanced by every launch.  Sticky actions keep a third of the envs on the list."""
+    counter advanced by every launch.  Sticky actions keep a third of the envs on the list.  The 128-vehicle case runs
+    step_wide's packed form, whose envs with a broken highway (one in ten at this density) ask for the first blocks the same
+    way (csrc/step_wide.hpp)."""
     from diral_amd.rollout import GraphRollout
     from diral_amd.sps import SpsPolicy
     from diral_amd.vec_env import VecV2VEnv
-    N, A, B = 64, 32, 256
-    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2)
+    B = 256
+    cfg = bench_config(N, A, L, reward_design=2)
     runs = []
     for capture in (True, False):
         env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32, io_ring=2)
@@ -1915,6 +1917,11 @@ def test_graph_replays_on_a_frozen_slow_set_survive_eager_steps_in_between(K):
     a, b = e1.export_state(), e2.export_state()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+    # (the lists were not empty: some envs hold entries 7 or more stamps behind their subject - the ones that ask for a
+    # place among the first blocks - and some hold none)
+    seq = a["seq"]
+    lagged = ((seq > 0) & (torch.diagonal(seq, dim1=1, dim2=2).unsqueeze(1) - seq >= 7)).flatten(1).any(dim=1)
+    assert 0 < int(lagged.sum()) < B, int(lagged.sum())
     assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
     assert torch.equal(e1._obs, e2._obs) and torch.equal(e1._rew, e2._rew) and torch.equal(e1._chobs, e2._chobs)
     m1, m2 = e1.metrics(), e2.metrics()
