@@ -289,6 +289,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_MINWAVES4P
 #define DIRAL_WIDE_MINWAVES4P 4          // ... the packed form: 128 VGPRs (the product's A operand alone takes 64), two workgroups per CU
 #endif
+#ifndef DIRAL_WIDE_INV_LDS
+#define DIRAL_WIDE_INV_LDS 1             // the float32 state vector's 1 / n per viewer through LDS (fetched in the count pass) instead of a global load in P4
+#endif
 #ifndef DIRAL_WIDE_FUSED_FLAGGED
 #define DIRAL_WIDE_FUSED_FLAGGED 1       // packed form: a flagged pass reads and writes the code words itself (no round trip through `tkey`)
 #endif
@@ -701,6 +704,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
   DIRAL_WSTAMP(3);
 
   // ---- P2 (first VPL waves): reward per transmitter, metric partials, positions --
+  // (the two stores of P2 - reward, position - moved behind P3, so that the table words P3 asks for first do not wait for
+  // them: measured, +- 0 at C3 and C5)
   if (tid < NPAD) {
     const unsigned long long late2 = late_kernarg_base();         // late-bound arguments: see step_fast64.hpp
     const int u = tid;
@@ -1015,6 +1020,13 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       unsigned int n = 0u;
       for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[tid * KP + q]; n += (w & 0xffffu) + (w >> 16); }
       s_cnt[tid] = n;
+      // 1 / n for the float32 state vector, fetched HERE and parked in the merge scratch (dead since the barrier above): in
+      // P4 the table load sat between streaming stores, and a wave's s_waitcnt vmcnt for it also waits for every store
+      // issued before it (step_wide_closure.inc found the same for its table words)
+      if constexpr (!OUT64 && DIRAL_WIDE_INV_LDS) {
+        const double* const it = ((LateFastArgs)late_kernarg_base())->inv_tab;
+        reinterpret_cast<double*>(smem + lay.scratch)[tid] = it[n < 256u ? n : 0u];
+      }
     }
     __syncthreads();
   }
@@ -1181,7 +1193,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
           const unsigned int* hw = s_hist + u * KP + ((s0 - A) >> 1);        // s0 - A is a multiple of 4: two words
           const unsigned int h01 = hw[0], h23 = hw[1];
           // one table load instead of four IEEE divisions: exact, see step_fast64.hpp
-          const double inv = inv_tab[n];
+          const double inv = (!REGCNT && DIRAL_WIDE_INV_LDS) ? reinterpret_cast<const double*>(smem + lay.scratch)[u] : inv_tab[n];
           v = make_float4((float)((double)(h01 & 0xffffu) * inv), (float)((double)(h01 >> 16) * inv),
                           (float)((double)(h23 & 0xffffu) * inv), (float)((double)(h23 >> 16) * inv));
         }
