@@ -497,13 +497,20 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
     q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   if (type1_lanes) {
-    const int lpv = p.N <= 128 ? 2 : 4, vw = 64 / lpv, nvb = (p.N + vw - 1) / vw;
+    // (DIRAL_TYPE1_LANES=wide: rounds 3-4's 64 values per lane, for A/B)
+    const char* const tl = std::getenv("DIRAL_TYPE1_LANES");
+    const bool wide_lanes = tl && std::strcmp(tl, "wide") == 0;
+    const int npad = p.N <= 128 ? 128 : 256;
+    const int lpv = npad / (wide_lanes ? 64 : 32), vw = 64 / lpv, nvb = (p.N + vw - 1) / vw;
     q.do_type1 = 1;
     q.ring = (e->ring && !e->plane_valid) ? e->ring : nullptr;
     if (q.ring && e->tcode) { q.tcode = e->tcode; q.tage = e->tage; q.tseq = e->tseq; }
-    const uint32_t lds = posdist_type1_lanes_lds_bytes(p.K, lpv);
-    if (lpv == 2) hipLaunchKernelGGL(posdist_type1_lanes_kernel<2>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
-    else hipLaunchKernelGGL(posdist_type1_lanes_kernel<4>, dim3((unsigned)p.B * nvb), dim3(64), lds, s, q);
+    const uint32_t lds = posdist_type1_lanes_lds_bytes(p.K, npad, lpv);
+    const dim3 grid((unsigned)p.B * nvb);
+    if (wide_lanes && lpv == 2) hipLaunchKernelGGL((posdist_type1_lanes_kernel<2, 64>), grid, dim3(64), lds, s, q);
+    else if (wide_lanes) hipLaunchKernelGGL((posdist_type1_lanes_kernel<4, 64>), grid, dim3(64), lds, s, q);
+    else if (lpv == 4) hipLaunchKernelGGL((posdist_type1_lanes_kernel<4, 32>), grid, dim3(64), lds, s, q);
+    else hipLaunchKernelGGL((posdist_type1_lanes_kernel<8, 32>), grid, dim3(64), lds, s, q);
     q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   q.do_full = (full && !full_flat) ? 1 : 0;

@@ -24,7 +24,7 @@
 //                                signed distances live in registers, sorted by a fully unrolled bitonic
 //                                network of v_min_f64 / v_max_f64; the sequential prefix sum runs in all
 //                                64 lanes at once and drops its running value into per-edge LDS slots.
-//   posdist_type1_lanes_kernel   a15 for 64 < N <= 256: 2 or 4 lanes per viewer, cross-lane bitonic merge.
+//   posdist_type1_lanes_kernel   a15 for 64 < N <= 256: 4 or 8 lanes per viewer (32 values each), cross-lane bitonic merge.
 #pragma once
 #include "common.hpp"
 #include "step_kernel.hpp"
@@ -283,8 +283,12 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
 #pragma unroll
   for (int k0 = 0; k0 < 64; k0 += 16) {                                    // 16 rows per batch: 48 registers in flight
     uint32_t tw[16];
+    // (the packed table on the one-lane highway: every word is rebuilt from the code / age words below - a code-0 entry's
+    // sequence number only decides its ypos -, the plane is not read at all)
+    if (!(p.tcode && p.flat_y)) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) tw[c] = trow[(k0 + c) * 64];
+      for (int c = 0; c < 16; ++c) tw[c] = trow[(k0 + c) * 64];
+    }
     if (p.tcode) {
       // the packed table: four code words + four age words serve the batch's 16 rows; the subjects' own sequence
       // numbers sit in `ts_lane` (lane k: subject k)
@@ -399,12 +403,12 @@ __global__ __launch_bounds__(64, 3) void posdist_type1_n64_kernel(const PosdistP
   }
 }
 
-// ---- a15, 64 < N <= 256: LPV = 2 or 4 lanes per viewer ----------------------------------------------
-// The same kernel with a viewer's table spread over LPV neighbouring lanes, 64 subjects each (lane l: viewer
-// l / LPV of the wave's 64 / LPV, subjects 64 (l % LPV) ...).  Every lane sorts its 64 values as above; the
+// ---- a15, 64 < N <= 256: LPV lanes per viewer, VL subjects per lane -----------------------------------
+// The same kernel with a viewer's table spread over LPV neighbouring lanes, VL subjects each (lane l: viewer
+// l / LPV of the wave's 64 / LPV, subjects VL (l % LPV) ...).  Every lane sorts its VL values as above; the
 // lanes of a viewer then merge their runs with the cross-lane steps of the same bitonic network - partner
-// values through quad-permute DPP moves, the low lane keeps the minima - after which lane s holds ranks
-// 64 s ... 64 s + 63 of the viewer's sorted list.  The sequential prefix sum passes from lane to lane (LPV
+// values through DPP moves (quad permutes, row_half_mirror), the low lane keeps the minima - after which lane s
+// holds ranks VL s ... VL s + VL - 1 of the viewer's sorted list.  The sequential prefix sum passes from lane to lane (LPV
 // passes over the same code, one lane of each viewer active per pass).
 template <int CTRL>
 __device__ inline double pd_quad_perm(double x) {
@@ -413,20 +417,29 @@ __device__ inline double pd_quad_perm(double x) {
   return __hiloint2double(hi, lo);
 }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B, kQuadShr1 = 0x90;   // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0] [0,0,1,2]
+constexpr int kRowHalfMirror = 0x141, kRowShr1 = 0x111;                                 // lane s <-> 7 - s within a row half; lane s <- s - 1 within a row of 16
+#ifndef DIRAL_TYPE1_MINWAVES
+#define DIRAL_TYPE1_MINWAVES 4           // posdist_type1_lanes_kernel<LPV, 32>: waves per SIMD the register allocation is held to
+#endif
 
 __device__ inline double pd_pick(bool upper, double a, double b) {        // the partner keeps the other one
   const double mn = __builtin_fmin(a, b), mx = __builtin_fmax(a, b);
   return upper ? mx : mn;
 }
 
-template <int LPV>
-__global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const PosdistParams p) {
-  static_assert(LPV == 2 || LPV == 4, "a viewer's lanes share a quad");
+template <int LPV, int VL>
+__global__ __launch_bounds__(64, VL == 64 ? 2 : DIRAL_TYPE1_MINWAVES) void posdist_type1_lanes_kernel(const PosdistParams p) {
+  // VL subjects per lane, LPV lanes per viewer: <2, 64> / <4, 64> (rounds 3-4: 128 VGPRs of values, two waves per SIMD - the
+  // kernel waited for its own round trips) or <4, 32> / <8, 32> (N <= 128 / 256: half the values per lane, one more level of
+  // cross-lane merging, twice the waves)
+  static_assert((LPV == 2 || LPV == 4 || LPV == 8) && (VL == 32 || VL == 64), "a viewer's lanes share a row of 8");
   constexpr int VW = 64 / LPV;                                           // viewers per wave
+  constexpr int ST = VW | 1;                                             // doubles per row of edge sums (one column per viewer of the wave)
   extern __shared__ __align__(16) unsigned char smem[];
   double* const s_e1 = reinterpret_cast<double*>(smem);                  // [K + 1] edges
-  double* const s_c = s_e1 + 66;                                         // [K + 2][kPd1Stride] edge sums per viewer (columns 0 .. VW - 1)
-  double* const s_py = s_c + (p.K + 2) * kPd1Stride;                     // [64 LPV] pos_y of the env
+  double* const s_c = s_e1 + 66;                                         // [K + 2][ST] edge sums per viewer (columns 0 .. VW - 1)
+  double* const s_py = s_c + (p.K + 2) * ST;                     // [VL LPV] pos_y of the env
+  uint32_t* const s_ts = reinterpret_cast<uint32_t*>(s_py + VL * LPV);   // [VL LPV] the subjects' own sequence numbers
   const int N = p.N, K = p.K, NV = p.NV, lane = threadIdx.x;
   const int nvb = (N + VW - 1) / VW;                                     // viewer blocks per env
   const int b = blockIdx.x / nvb, vb = blockIdx.x - b * nvb;
@@ -436,40 +449,47 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
   const bool live = t < N;
   const double xt = live ? p.pos_x[bN + t] : 0.0, yt = live ? p.pos_y[bN + t] : 0.0;
   for (int j = lane; j <= K; j += 64) s_e1[j] = p.edges1[j];
-  for (int u = lane; u < 64 * LPV; u += 64) s_py[u] = u < N ? p.pos_y[bN + u] : 0.0;
+  // (the one-lane highway: every y is 0; the subjects' own numbers - `tseq`, or the diagonal of the plane - once per wave
+  // into LDS: two global loads per ENTRY before)
+  for (int u = lane; u < VL * LPV; u += 64) {
+    s_py[u] = (u < N && !p.flat_y) ? p.pos_y[bN + u] : 0.0;
+    const size_t ru = (size_t)b * p.NR + (u < p.NR ? u : 0);
+    s_ts[u] = p.tseq ? p.tseq[ru] : p.tkey[ru * NV + (u < p.NR ? u : 0)] >> 8;
+  }
   __syncthreads();
   const double inf = __builtin_inf();
 
-  double v[64];
+  double v[VL];
   double dmax = 0.0;
   int nvalid = 0;
-  const size_t row0 = (size_t)b * p.NR + sub * 64;                        // the lane's first subject row
+  const size_t row0 = (size_t)b * p.NR + sub * VL;                        // the lane's first subject row
   const uint32_t* const trow = p.tkey + row0 * NV + t;
   const double* const xrow = p.tx + row0 * NV + t;
-  const uint32_t* const drow = p.tkey + row0 * NV + sub * 64;             // the subjects' own entries (diagonal)
   const double* const rrow = p.ring ? p.ring + row0 * 8 : nullptr;
 #pragma unroll
-  for (int k0 = 0; k0 < 64; k0 += 16) {
+  for (int k0 = 0; k0 < VL; k0 += 16) {
     uint32_t tw[16];
+    if (!(p.tcode && p.flat_y)) {                                          // (as in posdist_type1_n64_kernel)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) tw[c] = trow[(size_t)(k0 + c) * NV];
+      for (int c = 0; c < 16; ++c) tw[c] = trow[(size_t)(k0 + c) * NV];
+    }
     if (p.tcode) {
       // the packed table: four code words + four age words serve the batch's 16 rows (see posdist_type1_n64_kernel)
       uint32_t cq[4], aq[4];
       const int tq = t < NV ? t : 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int qi = ((sub * 64 + k0) >> 2) + q;
+        const int qi = ((sub * VL + k0) >> 2) + q;
         const size_t at = ((size_t)b * (p.NR >> 2) + (qi < (p.NR >> 2) ? qi : 0)) * NV + tq;
         cq[q] = p.tcode[at];
         aq[q] = p.tage[at];
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const int kg = sub * 64 + k0 + c;
+        const int kg = sub * VL + k0 + c;
         const uint32_t sh = 8u * (uint32_t)(c & 3);
         const uint32_t r = (cq[c >> 2] >> sh) & 255u, a = (aq[c >> 2] >> sh) & 255u;
-        const uint32_t tk = p.tseq[(size_t)b * p.NR + (kg < p.NR ? kg : 0)];
+        const uint32_t tk = s_ts[kg];
         const uint32_t seq = r ? tk - 8u + (uint32_t)__popc(r) : (p.flat_y ? 0u : (tw[c] >> 8));
         tw[c] = (seq << 8) | a;
       }
@@ -480,14 +500,14 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
       const uint32_t seq = tw[c] >> 8;
       const double* src = xrow + (size_t)k * NV;
       if (rrow) {                                                          // uniform: the plane holds only entries 7+ stamps old
-        const uint32_t tk = p.tseq ? p.tseq[row0 + (sub * 64 + k < p.NR ? k : 0)] : drow[(size_t)k * NV + k] >> 8;
-        if (sub * 64 + k < N && tk - seq <= 7u) src = rrow + k * 8 + (seq & 7u);
+        const uint32_t tk = s_ts[sub * VL + k];
+        if (sub * VL + k < N && tk - seq <= 7u) src = rrow + k * 8 + (seq & 7u);
       }
       v[k] = *src;
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const int k = k0 + c, kg = sub * 64 + k;
+      const int k = k0 + c, kg = sub * VL + k;
       const uint32_t w = tw[c];
       const double x1 = v[k];
       const bool valid = live && kg < N && kg != t && (int)(w & 255u) < p.age_limit;
@@ -506,21 +526,26 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
     double o = pd_quad_perm<kQuadXor1>(dmax);
     dmax = o > dmax ? o : dmax;
     nvalid += __builtin_amdgcn_mov_dpp(nvalid, kQuadXor1, 0xf, 0xf, true);
-    if constexpr (LPV == 4) {
+    if constexpr (LPV >= 4) {
       o = pd_quad_perm<kQuadXor2>(dmax);
       dmax = o > dmax ? o : dmax;
       nvalid += __builtin_amdgcn_mov_dpp(nvalid, kQuadXor2, 0xf, 0xf, true);
     }
+    if constexpr (LPV == 8) {                                              // the other quad of the viewer's eight lanes
+      o = pd_quad_perm<kRowHalfMirror>(dmax);
+      dmax = o > dmax ? o : dmax;
+      nvalid += __builtin_amdgcn_mov_dpp(nvalid, kRowHalfMirror, 0xf, 0xf, true);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 64; ++k) v[k] = v[k] / dmax;
-  // every lane: its 64 values ascending
+  for (int k = 0; k < VL; ++k) v[k] = v[k] / dmax;
+  // every lane: its VL values ascending
 #pragma unroll
-  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+  for (int k2 = 2; k2 <= VL; k2 <<= 1) {
 #pragma unroll
     for (int j = k2 >> 1; j > 0; j >>= 1) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) {
+      for (int i = 0; i < VL; ++i) {
         const int l = i ^ j;
         if (l > i) {
           const double a = v[i], c = v[l];
@@ -535,9 +560,9 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
   // a lane's 64 values are a bitonic sequence: ascending by the last six steps of the network
   auto merge_in_lane = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
+    for (int j = VL / 2; j > 0; j >>= 1) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) {
+      for (int i = 0; i < VL; ++i) {
         const int l = i ^ j;
         if (l > i) {
           const double a = v[i], c = v[l];
@@ -551,44 +576,67 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
   // place n-1-i - both halves bitonic, every low value <= every high one
   const bool odd = (sub & 1) != 0;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const double t1 = pd_quad_perm<kQuadXor1>(v[63 - i]), t2 = pd_quad_perm<kQuadXor1>(v[i]);
+  for (int i = 0; i < VL / 2; ++i) {
+    const double t1 = pd_quad_perm<kQuadXor1>(v[VL - 1 - i]), t2 = pd_quad_perm<kQuadXor1>(v[i]);
     v[i] = pd_pick(odd, v[i], t1);
-    v[63 - i] = pd_pick(odd, v[63 - i], t2);
-    asm volatile("" : "+v"(v[i]), "+v"(v[63 - i]));                       // (pair by pair: the permuted copies must not pile up)
+    v[VL - 1 - i] = pd_pick(odd, v[VL - 1 - i], t2);
+    asm volatile("" : "+v"(v[i]), "+v"(v[VL - 1 - i]));                   // (pair by pair: the permuted copies must not pile up)
   }
   merge_in_lane();
-  if constexpr (LPV == 4) {
-    const bool hi2 = (sub & 2) != 0;                                       // runs of 128: lanes 0,1 against lanes 3,2
+  const bool hi2 = (sub & 2) != 0;
+  if constexpr (LPV >= 4) {
+    // runs of 2 VL: lanes 0,1 against lanes 3,2
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const double t1 = pd_quad_perm<kQuadXor3>(v[63 - i]), t2 = pd_quad_perm<kQuadXor3>(v[i]);
+    for (int i = 0; i < VL / 2; ++i) {
+      const double t1 = pd_quad_perm<kQuadXor3>(v[VL - 1 - i]), t2 = pd_quad_perm<kQuadXor3>(v[i]);
       v[i] = pd_pick(hi2, v[i], t1);
-      v[63 - i] = pd_pick(hi2, v[63 - i], t2);
-      asm volatile("" : "+v"(v[i]), "+v"(v[63 - i]));
+      v[VL - 1 - i] = pd_pick(hi2, v[VL - 1 - i], t2);
+      asm volatile("" : "+v"(v[i]), "+v"(v[VL - 1 - i]));
     }
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {                                         // stride 64 of the 128-sequence
+    for (int i = 0; i < VL; ++i) {                                         // stride VL of the 2 VL-sequence
       v[i] = pd_pick(odd, v[i], pd_quad_perm<kQuadXor1>(v[i]));
       asm volatile("" : "+v"(v[i]));
     }
     merge_in_lane();
   }
-  // lane `sub` now holds ranks 64 sub .. 64 sub + 63 of the viewer's list; the histogram as in the one-lane kernel
+  if constexpr (LPV == 8) {
+    // runs of 4 VL: lanes 0..3 against lanes 7..4 (row_half_mirror: lane s <-> 7 - s), then the strides 2 VL and VL
+    const bool hi3 = (sub & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < VL / 2; ++i) {
+      const double t1 = pd_quad_perm<kRowHalfMirror>(v[VL - 1 - i]), t2 = pd_quad_perm<kRowHalfMirror>(v[i]);
+      v[i] = pd_pick(hi3, v[i], t1);
+      v[VL - 1 - i] = pd_pick(hi3, v[VL - 1 - i], t2);
+      asm volatile("" : "+v"(v[i]), "+v"(v[VL - 1 - i]));
+    }
+#pragma unroll
+    for (int i = 0; i < VL; ++i) {
+      v[i] = pd_pick(hi2, v[i], pd_quad_perm<kQuadXor2>(v[i]));
+      asm volatile("" : "+v"(v[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < VL; ++i) {
+      v[i] = pd_pick(odd, v[i], pd_quad_perm<kQuadXor1>(v[i]));
+      asm volatile("" : "+v"(v[i]));
+    }
+    merge_in_lane();
+  }
+  // lane `sub` now holds ranks VL sub .. VL sub + VL - 1 of the viewer's list; the histogram as in the one-lane kernel
   double* const col = s_c + vw;
   const int kUnsetHi = 0x7ff8dead;
   if (sub == 0)
-    for (int j = 0; j <= K + 1; ++j) col[j * kPd1Stride] = __hiloint2double(kUnsetHi, 0);
+    for (int j = 0; j <= K + 1; ++j) col[j * ST] = __hiloint2double(kUnsetHi, 0);
   const int nreal_all = dmax > 0.0 ? nvalid : 0;
-  const int nreal = nreal_all - 64 * sub;                                  // of this lane's 64 ranks (<= 0: none)
+  const int nreal = nreal_all - VL * sub;                                  // of this lane's VL ranks (<= 0: none)
   const double half_k = 0.5 * (double)K;
   // the slot of every value first, all lanes at once (four 8-bit slot numbers per register; the fillers get
   // the spare slot and the value 0) - the passes below only add and store
-  uint32_t cpk[16];
+  uint32_t cpk[VL / 4];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) cpk[q] = 0u;
+  for (int q = 0; q < VL / 4; ++q) cpk[q] = 0u;
 #pragma unroll
-  for (int i = 0; i < 64; ++i) {
+  for (int i = 0; i < VL; ++i) {
     const bool real = i < nreal;
     const double s = real ? v[i] : 0.0;
     v[i] = s;
@@ -601,36 +649,36 @@ __global__ __launch_bounds__(64, 2) void posdist_type1_lanes_kernel(const Posdis
   double acc = 0.0;
 #pragma unroll 1
   for (int ph = 0; ph < LPV; ++ph) {
-    const double before = pd_quad_perm<kQuadShr1>(acc);                    // the running sum of the lane below, complete by now
+    const double before = pd_quad_perm<kRowShr1>(acc);                     // the running sum of the lane below, complete by now
     const bool active = sub == ph;
     if (active) acc = ph > 0 ? before : 0.0;                               // (what a lane adds outside its own pass goes to the spare slot)
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < VL; ++i) {
       acc = acc + v[i];
       const int c = (int)((cpk[i >> 2] >> (8 * (i & 3))) & 255u);
-      col[(active ? c : K + 1) * kPd1Stride] = acc;
+      col[(active ? c : K + 1) * ST] = acc;
     }
   }
   if (sub == 0) {
     double cur = 0.0;
     for (int j = 0; j <= K; ++j) {
-      const double tt = col[j * kPd1Stride];
+      const double tt = col[j * ST];
       cur = __double2hiint(tt) == kUnsetHi ? cur : tt;
-      col[j * kPd1Stride] = cur;
+      col[j * ST] = cur;
     }
   }
   __syncthreads();
   for (int e = lane; e < VW * K; e += 64) {
     const int tv = e / K, j = e - tv * K, to = vb * VW + tv;
     if (to < N) {
-      const double out = s_c[(j + 1) * kPd1Stride + tv] - s_c[j * kPd1Stride + tv];
+      const double out = s_c[(j + 1) * ST + tv] - s_c[j * ST + tv];
       store_out(p.state_out, (bN + to) * (size_t)p.S + p.off_hist + j, out, p.out_f64);
     }
   }
 }
 
-__host__ __device__ inline uint32_t posdist_type1_lanes_lds_bytes(int K, int lpv) {
-  return posdist_type1_lds_bytes(K) + 8u * 64u * (uint32_t)lpv;
+__host__ __device__ inline uint32_t posdist_type1_lanes_lds_bytes(int K, int npad, int lpv) {
+  return 8u * (66u + (uint32_t)(K + 2) * (uint32_t)((64 / lpv) | 1) + (uint32_t)npad) + 4u * (uint32_t)npad;
 }
 
 __host__ inline uint32_t posdist_lds_bytes(int N, int K) {

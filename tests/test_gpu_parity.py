@@ -1381,7 +1381,7 @@ def test_secondary_observation_kernels_vs_oracle(N, A, L, K, state, vary):
     """State.add_positional_dist (sorted signed true distances / norm, network.py:409-430) and
     add_positional_dist_type 1 (weighted np.histogram of the table distances, network.py:432-471) on the
     kernels built for them (csrc/posdist_kernel.hpp): the step on a specialised RICH instantiation, the
-    columns from posdist_sorted_flat_kernel / posdist_type1_n64_kernel / posdist_type1_lanes_kernel<2 | 4>, bit for
+    columns from posdist_sorted_flat_kernel / posdist_type1_n64_kernel / posdist_type1_lanes_kernel<4 | 8, 32>, bit for
     bit against the oracle over rollouts with velocity changes; the xpos ring feeds the type-1 kernel."""
     from diral_amd.config import KERNEL_FAST64, KERNEL_WIDE
     cfg = bench_config(N, A, L, mobility_vary=vary, communication_range=250.0 if L < 5000 else 160.0,
