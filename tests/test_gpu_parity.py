@@ -1097,6 +1097,55 @@ def test_wide_long_run_in_and_out_of_the_rank_window():
     env.check()
 
 
+@pytest.mark.parametrize("N,A,L,form", [(128, 64, 4000.0, None), (128, 16, 4000.0, "packed"), (200, 32, 5000.0, "packed")])
+def test_packed_form_long_run_on_highways_that_break_apart(N, A, L, form, monkeypatch):
+    """The packed table form of step_wide on BASELINE configs[4]'s density, 650 slots with the velocities redrawn every 25:
+    some highways break into clusters that no longer hear each other, their passes leave the codes (flagged passes that read
+    and write the code words themselves, byte ranks), entries about the other cluster age past 254 stamps (the shared lowest
+    rank at N <= 128, the 32-bit path with its unpack / repack stages at N > 128) and come back when the clusters meet
+    again; those envs ask for the first blocks of the next launch.  Against the oracle: state and reward every 50 slots and
+    over the last 30, every table plane at the end."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    from diral_amd.config import KERNEL_PACKED, KERNEL_WIDE
+    if form:
+        monkeypatch.setenv("DIRAL_TABLE_FORM", form)
+    B, T = 6, 650
+    cfg = bench_config(N, A, L, mobility_vary=True)
+    rng = np.random.default_rng(N + A)
+    x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    x0[0] = np.concatenate([rng.integers(0, 1200, size=N // 2), rng.integers(2400, 3600, size=N - N // 2)])   # two clusters from the start
+    v0 = rng.uniform(1.1, 2.7, size=(B, N))
+    env = make_env(cfg, B, dtype=torch.float64)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=8)
+    env.reset_topology(x0, None, v0)
+    orc.reset(x0, np.zeros((B, N)), v0)
+    for t in range(T):
+        a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, _ = env.step(a, t)
+        assert env.last_kernel() & (15 | KERNEL_PACKED) == KERNEL_WIDE | KERNEL_PACKED, env.last_kernel()
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+        if t % 50 == 49 or t >= T - 30:
+            o_state = orc.obtain_state(a, o_chobs, o_rew)
+            torch.cuda.synchronize()
+            assert np.array_equal(obs.cpu().numpy(), o_state), t
+            assert np.array_equal(rew.cpu().numpy(), o_rew), t
+        if t % 25 == 24:
+            draws = rng.integers(1, 4, size=(B, N)).astype(np.uint8)
+            env.update_velocity(draws)
+            orc.update_velocity(draws)
+    st, oe = env.export_state(), orc.export()
+    seq = oe["seq"]
+    own = seq[:, np.arange(N), np.arange(N)]
+    lag = own[:, None, :] - seq
+    if N <= 128:
+        assert ((lag >= 254) & (seq > 0)).any(), "no entry ever fell 254 stamps behind"
+    assert ((lag >= 8) & (lag < 254) & (seq > 0)).any() and ((lag < 8) & (seq > 0)).any()
+    assert np.array_equal(st["seq"].cpu().numpy(), seq)
+    assert np.array_equal(st["age"].cpu().numpy(), np.minimum(oe["age"], 255))
+    assert np.array_equal(st["x"].cpu().numpy(), oe["x"])
+    env.check()
+
+
 @pytest.mark.parametrize("N,A,K", [(64, 32, 20), (64, 5, 10), (6, 3, 20), (40, 48, 20), (256, 64, 20), (128, 16, 10),
                                    (130, 33, 21), (70, 4, 8)])
 def test_specialised_kernels_run_my_step_design_like_the_general_kernel_and_the_oracle(N, A, K):
