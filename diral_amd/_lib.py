@@ -26,6 +26,7 @@ SYMBOLS = [
     "diral_env_export_entries", "diral_env_import_entries",
     "diral_env_set_clock", "diral_clock_add", "diral_sps_step_chobs_clocked", "diral_env_step_policy",
     "diral_env_set_capture_rotation", "diral_env_align_phase",
+    "diral_env_export_prev_obs", "diral_env_import_prev_obs",
 ]
 
 _lib = None
@@ -90,6 +91,8 @@ def load() -> ctypes.CDLL:
         "diral_env_step_policy": (I, [P, I, P, I64, P, P, P, P, I, P, P]),
         "diral_env_set_capture_rotation": (I, [P, I, P]),
         "diral_env_align_phase": (I, [P, I, P]),
+        "diral_env_export_prev_obs": (I, [P, P, P]),
+        "diral_env_import_prev_obs": (I, [P, P, P]),
     }
     for name in SYMBOLS:
         try:

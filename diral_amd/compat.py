@@ -7,7 +7,7 @@ the env only through ``get_total_users/get_state_space/get_action_space``
 ``reset_mobility_env`` and ``env.network.get_information_age`` (main_test.py:89-233).
 This class keeps those names, argument meaning and RETURN SHAPES:
 
-    obs, rews = env.my_step(actions, t)      # obs: dict user -> ndarray[A]; rews: ndarray[N]
+    obs, rews = env.my_step(actions, t)      # obs: dict user -> ndarray[A] (A * A with State.piggybacking); rews: ndarray[N]
     state = env.obtain_state(obs, actions, rews, episode, eps)   # list of N float64 vectors
 
 on top of a B=1 :class:`VecV2VEnv` (float64 outputs).  Every call synchronises
@@ -85,6 +85,16 @@ class TestEnv:
 
     def my_step(self, actions: Sequence[int], timestep: int):             # test_env.py:124-266
         chobs, rews = self._env.my_step(np.asarray(actions, dtype=np.int32), timestep)
+        if self.cfg.State.piggybacking:
+            # a receiver that hears nobody on a used resource: the reference's `self.prev_obs[tx_id]` with
+            # tx_id None raises KeyError inside my_step (test_env.py:243)
+            from .config import ERR_PIGGY_NO_TX
+            try:
+                self._env.check()
+            except RuntimeError as exc:
+                if getattr(exc, "status", 0) == ERR_PIGGY_NO_TX:
+                    raise KeyError(None) from exc
+                raise
         return self._obs_dict(chobs), self._to_np(rews)[0].astype(np.float64).copy()
 
     def my_step_ch(self, actions: Sequence[int], time_step: int):         # test_env.py:351-443

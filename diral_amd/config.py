@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1
@@ -32,6 +32,7 @@ F_ADD_POSDIST_PIGGY = 1 << 11
 F_FINGERPRINT = 1 << 12
 F_PROPORTIONAL_FAIR = 1 << 13
 F_DESIGN_TOPOLOGY = 1 << 14
+F_PIGGYBACKING = 1 << 15
 F_TRACK_ARRIVAL = 1 << 16
 F_TRACK_PRR = 1 << 17
 
@@ -75,6 +76,7 @@ ERR_ACTION_RANGE = -6
 ERR_SEQ_OVERFLOW = -7
 ERR_CAPTURE = -8
 ERR_TABLE_CONFLICT = -9
+ERR_PIGGY_NO_TX = -10
 
 
 class DiralCfg(ctypes.Structure):
@@ -147,7 +149,7 @@ class StateConfig:
     add_index: bool = False
     add_velocity: bool = False
     action_index: str = "binary"        # "binary" | "real"  (test_env.py:32)
-    piggybacking: bool = False          # must stay False (permanent divergence)
+    piggybacking: bool = False          # test_env.py:33, 71-79, 241-254: needs type 2 + add_channel_obs (validate())
     add_position: bool = False
     add_positional_dist: bool = False
     add_positional_dist_piggy: bool = False
@@ -250,11 +252,19 @@ class EnvConfig:
             s += 2
         if st.add_positional_dist:
             s += self.num_users - 1
+        if st.piggybacking:                 # test_env.py:71-72
+            s += self.num_channels * (self.num_channels - 1)
         if self.enable_fingerprint:
             s += 2
         if st.add_positional_dist_piggy:
             s += st.num_bins
         return s
+
+    @property
+    def chobs_width(self) -> int:
+        """Length of one agent's `obs` as my_step returns it: A, or A * A when State.piggybacking
+        inserts the closest transmitters' previous observations (test_env.py:241-254, 263-264)."""
+        return self.num_channels * self.num_channels if self.State.piggybacking else self.num_channels
 
     def flags(self) -> int:
         st = self.State
@@ -274,6 +284,7 @@ class EnvConfig:
         f |= F_FINGERPRINT if self.enable_fingerprint else 0
         f |= F_PROPORTIONAL_FAIR if self.proportional_fair else 0
         f |= F_DESIGN_TOPOLOGY if self.enable_design_topology else 0
+        f |= F_PIGGYBACKING if st.piggybacking else 0
         f |= F_TRACK_ARRIVAL if self.track_arrival else 0
         f |= F_TRACK_PRR if self.track_prr else 0
         return f
@@ -284,11 +295,13 @@ class EnvConfig:
         st = self.State
         if self.num_users < 1 or self.num_channels < 1:
             raise ConfigError("num_users and num_channels must be >= 1")
-        if st.piggybacking:
-            raise ConfigError("State.piggybacking=True (obs-insertion mode, test_env.py:71-79, 241-254) is a permanent "
-                              "divergence of this build: the reference's own branch builds observation vectors whose "
-                              "length depends on the slot's traffic and indexes prev_obs[None] when no transmitter is in "
-                              "range (DESIGN.md 6)")
+        if st.piggybacking and st.type != 2:
+            raise ConfigError("State.piggybacking with State.type 1: the reference inserts only on idle resources there "
+                              "(test_env.py:226-232 has no piggybacking branch, :250-254 has), so the length of an "
+                              "agent's observation depends on the slot's traffic - no fixed state vector exists")
+        if st.piggybacking and not st.add_channel_obs:
+            raise ConfigError("State.piggybacking without State.add_channel_obs: get_state_space() counts A*(A-1) columns "
+                              "(test_env.py:71-72) that obtain_state never writes (test_env.py:539-541)")
         if st.action_index not in ("binary", "real"):
             raise ConfigError("action_index must be 'binary' or 'real' (test_env.py:50-55)")
         if st.type not in (1, 2):

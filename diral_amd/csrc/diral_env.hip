@@ -18,6 +18,7 @@
 #include "step_fast64.hpp"
 #include "step_wide.hpp"
 #include "posdist_kernel.hpp"
+#include "piggyback_kernel.hpp"
 
 using namespace diral;
 
@@ -66,6 +67,11 @@ struct DiralEnv {
   int64_t hbm_bytes = 0;
   bool flat_y = true;      // every pos_y == 0 (random topologies, network.py:104): |dx| distance path
   uint32_t* yflag = nullptr;
+  // State.piggybacking (piggyback_kernel.hpp): TestEnv.prev_obs, and this slot's plain observation / closest transmitters
+  int off_chobs_pb = -1;       // column of the A * A section in a state row (the kernels are handed off_chobs = -1)
+  double* prev_obs = nullptr;
+  double* obs_new = nullptr;
+  int32_t* txid = nullptr;
   unsigned long long* dbg = nullptr;   // DIRAL_TIMING builds: [B][waves][8] timestamps
   bool capture_violation = false;   // a ring <-> plane switch was asked for inside a stream capture
   std::string last_hip_error;
@@ -120,7 +126,8 @@ Offsets state_offsets(const DiralCfg* c) {
   Offsets o{-1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
   int p = 0;
   if (has(c, DIRAL_F_ADD_ACTION)) { o.act = p; p += has(c, DIRAL_F_ACTION_REAL) ? 1 : c->num_channels; }
-  if (has(c, DIRAL_F_ADD_CHANNEL_OBS)) { o.chobs = p; p += c->num_channels; }
+  // (State.piggybacking: `obs[user_i]` is piggy_obs, A * A values - test_env.py:71-72, 263-264, 539-541)
+  if (has(c, DIRAL_F_ADD_CHANNEL_OBS)) { o.chobs = p; p += has(c, DIRAL_F_PIGGYBACKING) ? c->num_channels * c->num_channels : c->num_channels; }
   if (has(c, DIRAL_F_ADD_POSDIST)) { o.posdist = p; p += c->num_users - 1; }
   if (has(c, DIRAL_F_ADD_POSDIST_PIGGY)) { o.hist = p; p += c->num_bins; }
   if (has(c, DIRAL_F_ADD_REWARD)) { o.rew = p; p += 1; }
@@ -171,7 +178,7 @@ struct DeviceGuard {
 // State flags that only add OUTPUT columns to the state vector (test_env.py:527-583): served
 // by the RICH instantiations of the specialised kernels (rich_out.hpp)
 constexpr uint32_t kRichFlags = DIRAL_F_ACTION_REAL | DIRAL_F_ADD_CHANNEL_OBS | DIRAL_F_ADD_REWARD | DIRAL_F_ADD_INDEX |
-                                DIRAL_F_ADD_VELOCITY | DIRAL_F_ADD_POSITION | DIRAL_F_FINGERPRINT;
+                                DIRAL_F_ADD_VELOCITY | DIRAL_F_ADD_POSITION | DIRAL_F_FINGERPRINT | DIRAL_F_PIGGYBACKING;
 
 // Configurations the specialised kernels (step_fast64 / step_wide) serve: every step kind on a mobile
 // topology with piggybacked neighbour tables, any combination of outputs and State flags, proportional
@@ -272,8 +279,11 @@ RichParams rich_for(const DiralEnv* e, const StepParams& p) {
   // neighbours in the state vector, state_offsets): not written here at all
   const bool skip_full = (p.flags & DIRAL_F_ADD_POSDIST) && p.state_out && p.off_posdist >= 0 && p.N > 1;
   const bool skip_t1 = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) && p.posdist_type == 1 && p.state_out && p.off_hist >= 0;
-  r.off_skip = skip_full ? p.off_posdist : (skip_t1 ? p.off_hist : 0);
-  r.len_skip = (skip_full ? p.N - 1 : 0) + (skip_t1 ? p.K : 0);
+  // State.piggybacking: the A * A channel-observation section is piggy_emit_kernel's (piggyback_kernel.hpp); it sits
+  // right in front of the other two (state_offsets), so the skipped columns stay one range
+  const bool skip_pb = (e->cfg.flags & DIRAL_F_PIGGYBACKING) && p.state_out && e->off_chobs_pb >= 0;
+  r.off_skip = skip_pb ? e->off_chobs_pb : (skip_full ? p.off_posdist : (skip_t1 ? p.off_hist : 0));
+  r.len_skip = (skip_pb ? p.A * p.A : 0) + (skip_full ? p.N - 1 : 0) + (skip_t1 ? p.K : 0);
   r.pf = nullptr;
   return r;
 }
@@ -525,6 +535,15 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   return hipGetLastError();
 }
 
+PiggyParams piggy_params(const DiralEnv* e, const StepParams& p) {
+  PiggyParams q;
+  q.N = e->N; q.A = e->A; q.S = e->S; q.off_chobs = e->off_chobs_pb; q.out_f64 = p.out_f64; q.Rc = p.Rc;
+  q.actions = p.actions; q.pos_x = e->pos_x; q.pos_y = e->pos_y;
+  q.obs_new = e->obs_new; q.txid = e->txid; q.prev_obs = e->prev_obs;
+  q.chobs_out = p.chobs_out; q.state_out = p.state_out; q.chobs_in = p.chobs_in; q.err = e->err;
+  return q;
+}
+
 // Recompute DiralEnv::flat_y (all pos_y == 0) after pos_y was written by the
 // caller.  Synchronises the stream; only reset/import call it, never step.
 int refresh_flat_y(DiralEnv* e, hipStream_t s) {
@@ -556,6 +575,7 @@ const char* diral_env_strerror(int status) {
     case DIRAL_ERR_SEQ_OVERFLOW: return "more than DIRAL_MAX_SLOTS steps since reset";
     case DIRAL_ERR_CAPTURE: return "call needs a ring <-> plane conversion and the stream is being captured into a hipGraph";
     case DIRAL_ERR_TABLE_CONFLICT: return "imported tables hold entries about one subject with equal sequence numbers but different xpos";
+    case DIRAL_ERR_PIGGY_NO_TX: return "State.piggybacking: a receiver heard no transmitter on a used resource (the reference's prev_obs[None] KeyError)";
     default: return "unknown status";
   }
 }
@@ -593,6 +613,11 @@ int diral_env_validate(const DiralCfg* c) {
     if (c->posdist_type != 1 && c->posdist_type != 2) return DIRAL_ERR_BAD_CONFIG;  // test_env.py:555-560
     if (c->num_bins < 1 || !(c->bin_range > 0)) return DIRAL_ERR_BAD_CONFIG;
     if (c->num_bins > DIRAL_MAX_BINS) return DIRAL_ERR_UNSUPPORTED;
+  }
+  if (has(c, DIRAL_F_PIGGYBACKING)) {
+    // type 1 inserts on idle resources only (test_env.py:226-232, 250-254): ragged observations; without the
+    // channel-observation section obtain_state never reads what get_state_space() counts (test_env.py:71-72, 539-541)
+    if (c->state_type != 2 || !has(c, DIRAL_F_ADD_CHANNEL_OBS)) return DIRAL_ERR_BAD_CONFIG;
   }
   if (c->num_users > DIRAL_MAX_USERS || c->num_channels > DIRAL_MAX_CHANNELS) return DIRAL_ERR_UNSUPPORTED;
   const int vpl = vpl_for(c->num_users);
@@ -684,6 +709,12 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->inv_tab, 256 * 8));
   if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
   if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
+  if (has(cfg, DIRAL_F_PIGGYBACKING)) {
+    CREATE_TRY(alloc((void**)&e->prev_obs, bn * e->A * 8));
+    CREATE_TRY(alloc((void**)&e->obs_new, bn * e->A * 8));
+    CREATE_TRY(alloc((void**)&e->txid, bn * e->A * 4));
+    CREATE_TRY(hipMemset(e->prev_obs, 0, bn * e->A * 8));       // test_env.py:76-79
+  }
 
   std::vector<double> edges;
   np_linspace(-cfg->bin_range, cfg->bin_range, e->K + 1, edges);
@@ -730,6 +761,13 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   p.hist_inv_width = (double)e->K / (cfg->bin_range - (-cfg->bin_range));
   p.episode_interval = cfg->episode_interval;
   p.off_act = off.act; p.off_chobs = off.chobs; p.off_posdist = off.posdist; p.off_hist = off.hist;
+  if (has(cfg, DIRAL_F_PIGGYBACKING)) {
+    // the step / observe kernels build a state vector WITHOUT the channel-observation section and leave its A * A
+    // columns alone (rich_for); piggyback_kernel.hpp fills them
+    e->off_chobs_pb = off.chobs;
+    p.off_chobs = -1;
+    p.flags &= ~(uint32_t)DIRAL_F_ADD_CHANNEL_OBS;
+  }
   p.off_rew = off.rew; p.off_idx = off.idx; p.off_pos = off.pos; p.off_vel = off.vel; p.off_fp = off.fp;
   p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel = e->vel; p.tkey = e->tkey; p.tx = e->tx;
 #if defined(DIRAL_TIMING) || defined(DIRAL_DEBUG_XG)
@@ -740,7 +778,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   RichParams& r = e->rich;
   std::memset(&r, 0, sizeof(r));
   r.S = e->S; r.state_type = cfg->state_type;
-  r.off_act = off.act; r.off_chobs = off.chobs; r.off_hist = off.hist; r.off_rew = off.rew; r.off_idx = off.idx;
+  r.off_act = off.act; r.off_chobs = has(cfg, DIRAL_F_PIGGYBACKING) ? -1 : off.chobs; r.off_hist = off.hist; r.off_rew = off.rew; r.off_idx = off.idx;
   r.off_skip = 0; r.len_skip = 0;
   r.off_pos = off.pos; r.off_vel = off.vel; r.off_fp = off.fp;
   r.H = cfg->highway_height; r.vel = e->vel; r.pos_y = e->pos_y;
@@ -755,7 +793,7 @@ int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
   void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->slow, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
-                  e->dbg};
+                  e->prev_obs, e->obs_new, e->txid, e->dbg};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
   return DIRAL_OK;
@@ -806,6 +844,7 @@ int diral_env_reset(DiralEnv* e, const double* x0, const double* y0, const doubl
   HIP_TRY(e, hipMemsetAsync(e->metrics, 0, (size_t)e->B * DIRAL_M_COLUMNS * 8, s));
   if (e->la) HIP_TRY(e, hipMemsetAsync(e->la, 0xFF, bn * e->N * 4, s));
   if (e->pf) HIP_TRY(e, hipMemsetAsync(e->pf, 0, bn * 4, s));
+  if (e->prev_obs) HIP_TRY(e, hipMemsetAsync(e->prev_obs, 0, bn * e->A * 8, s));
   hipLaunchKernelGGL(reset_kernel, dim3(blocks(bn, 256)), dim3(256), 0, s, (int)bn, e->cfg.highway_length,
                      has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0, seed, (uint64_t)e->env_offset * (uint64_t)e->N, x0, y0, v0,
                      e->pos_x, e->pos_y, e->vel);
@@ -833,6 +872,20 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
   p.state_out = e->S > 0 ? state_out : nullptr;
   p.rew_out = rew_out; p.done_out = done_out; p.chobs_out = chobs_out;
   p.chobs_in = nullptr; p.rew_in = nullptr;
+  if (e->prev_obs) {
+    // State.piggybacking: my_step_ch / my_step_design hand obtain_state the plain A-wide observation (test_env.py:316,
+    // 443) - a state vector shorter than get_state_space()
+    if (mode != DIRAL_STEP_MY_STEP) return DIRAL_ERR_BAD_CONFIG;
+    PiggyParams q = piggy_params(e, p);
+    p.chobs_out = nullptr;                                       // (the A * A observation is piggy_emit_kernel's)
+    hipLaunchKernelGGL(piggy_search_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, q);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
+    HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
+    hipLaunchKernelGGL(piggy_emit_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, q);
+    HIP_TRY(e, hipGetLastError());
+    return DIRAL_OK;
+  }
   HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   return DIRAL_OK;
@@ -855,6 +908,7 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   if ((pol->shape_flags & ~5) != 0) return DIRAL_ERR_BAD_ARG;                // global_reward_avg | stuck-action penalty
   if (pol->shaped_out && (pol->shape_flags & 4) && (!pol->pen_counter || !pol->pen_prev_actions)) return DIRAL_ERR_BAD_ARG;
   if (e->A > kSpsWaveMaxA) return DIRAL_ERR_UNSUPPORTED;
+  if (e->prev_obs) return DIRAL_ERR_UNSUPPORTED;                // State.piggybacking: the SPS agents sense A values, not A * A
   DeviceGuard guard(e->device);
   if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
   StepParams p = e->base;
@@ -910,6 +964,12 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   if (e->kernel_path == DIRAL_PATH_GENERAL) HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));   // (tests: the general kernel's observe mode)
   else HIP_TRY(e, launch_observe_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
+  if (e->prev_obs && e->off_chobs_pb >= 0) {                    // `obs` = piggy_obs, A * A values per agent
+    const PiggyParams q = piggy_params(e, p);
+    const size_t total = (size_t)e->B * e->N * e->A * e->A;
+    hipLaunchKernelGGL(piggy_fill_kernel, dim3(blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, q, total);
+    HIP_TRY(e, hipGetLastError());
+  }
   return DIRAL_OK;
 }
 
@@ -999,6 +1059,24 @@ int diral_env_import_state(DiralEnv* e, const double* pos_x, const double* pos_y
     if (!e->la) return DIRAL_ERR_BAD_CONFIG;
     HIP_TRY(e, hipMemcpyAsync(e->la, last_arrival, bn * e->N * 4, hipMemcpyDeviceToDevice, s));
   }
+  return DIRAL_OK;
+}
+
+int diral_env_export_prev_obs(DiralEnv* e, double* prev_obs, void* stream) {
+  if (!e || !prev_obs) return DIRAL_ERR_BAD_ARG;
+  if (!e->prev_obs) return DIRAL_ERR_BAD_CONFIG;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  HIP_TRY(e, hipMemcpyAsync(prev_obs, e->prev_obs, (size_t)e->B * e->N * e->A * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DIRAL_OK;
+}
+
+int diral_env_import_prev_obs(DiralEnv* e, const double* prev_obs, void* stream) {
+  if (!e || !prev_obs) return DIRAL_ERR_BAD_ARG;
+  if (!e->prev_obs) return DIRAL_ERR_BAD_CONFIG;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  HIP_TRY(e, hipMemcpyAsync(e->prev_obs, prev_obs, (size_t)e->B * e->N * e->A * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return DIRAL_OK;
 }
 
@@ -1264,6 +1342,7 @@ int diral_env_check(DiralEnv* e, void* stream) {
   if (flags & kErrAction) return DIRAL_ERR_ACTION_RANGE;
   if (flags & kErrSeq) return DIRAL_ERR_SEQ_OVERFLOW;
   if (flags & kErrTable) return DIRAL_ERR_TABLE_CONFLICT;
+  if (flags & kErrPiggy) return DIRAL_ERR_PIGGY_NO_TX;
   return DIRAL_OK;
 }
 

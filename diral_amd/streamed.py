@@ -41,7 +41,7 @@ class StreamedVecEnv:
             self.obs = torch.zeros((self.B, self.N, self.S), dtype=out_dtype, device=self.device)
             self.rew = torch.zeros((self.B, self.N), dtype=out_dtype, device=self.device)
             self.done = torch.zeros((self.B,), dtype=torch.uint8, device=self.device)
-            self.chobs = torch.zeros((self.B, self.N, self.A), dtype=out_dtype, device=self.device) if want_chobs else None
+            self.chobs = torch.zeros((self.B, self.N, cfg.chobs_width), dtype=out_dtype, device=self.device) if want_chobs else None
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.G)]
         self.slices: List[Tuple[int, int]] = []
         self.envs: List[VecV2VEnv] = []

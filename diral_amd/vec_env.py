@@ -99,6 +99,7 @@ class VecV2VEnv:
         self.N = cfg.num_users
         self.A = cfg.num_channels
         self.S = cfg.state_space
+        self.CW = cfg.chobs_width            # A, or A * A with State.piggybacking (test_env.py:263-264)
         self.out_dtype = out_dtype
         self._dt = DT_F64 if out_dtype == torch.float64 else DT_F32
         self.step_mode = _MODES[step_mode]
@@ -124,7 +125,7 @@ class VecV2VEnv:
             if self.io_ring != 1:
                 raise ValueError("out_buffers needs io_ring == 1")
             want = dict(obs=((self.B, self.N, self.S), out_dtype), rew=((self.B, self.N), out_dtype),
-                        done=((self.B,), torch.uint8), chobs=((self.B, self.N, self.A), out_dtype))
+                        done=((self.B,), torch.uint8), chobs=((self.B, self.N, self.CW), out_dtype))
             for k, (shape, dt) in want.items():
                 tns = out_buffers.get(k)
                 if tns is None and k == "chobs":
@@ -303,7 +304,7 @@ class VecV2VEnv:
             self._ri = (self._ri + 1) % self.io_ring
         slot = self._ring[self._ri]
         if want_chobs and slot["chobs"] is None:
-            slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+            slot["chobs"] = torch.zeros((self.B, self.N, self.CW), dtype=self.out_dtype, device=self.device)
         self._obs, self._rew, self._done, self._chobs = slot["obs"], slot["rew"], slot["done"], slot["chobs"]
         self._spec = None
         st = self.lib.diral_env_step(self._h, mode, _ptr(actions), int(t),
@@ -364,7 +365,7 @@ class VecV2VEnv:
         # is launched, and is repeated with the buffer from then on)
         fusable = (self.N <= 64 and self.N >= 8 and self.A <= 64) and not getattr(self, "_policy_needs_chobs", False)
         if (want_chobs or not fusable) and slot["chobs"] is None:
-            slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+            slot["chobs"] = torch.zeros((self.B, self.N, self.CW), dtype=self.out_dtype, device=self.device)
         self._obs, self._rew, self._done, self._chobs = slot["obs"], slot["rew"], slot["done"], slot["chobs"]
         self._spec = None
         q = DiralSlotPolicy()
@@ -395,7 +396,7 @@ class VecV2VEnv:
         if st == ERR_UNSUPPORTED and use_chobs is None and K == 1:  # not a fused configuration, nothing launched
             self._policy_needs_chobs = True
             if slot["chobs"] is None:
-                slot["chobs"] = torch.zeros((self.B, self.N, self.A), dtype=self.out_dtype, device=self.device)
+                slot["chobs"] = torch.zeros((self.B, self.N, self.CW), dtype=self.out_dtype, device=self.device)
             self._chobs = slot["chobs"]
             st = call(self._chobs)
         self._ok(st, "diral_env_step_policy")
@@ -489,7 +490,7 @@ class VecV2VEnv:
             return hit
         self._spec = None
         a = self._actions(acts)
-        chobs = None if obs is None else self._f64(obs, (self.B, self.N, self.A))
+        chobs = None if obs is None else self._f64(obs, (self.B, self.N, self.CW))
         rew = None if rewards is None else self._f64(rewards, (self.B, self.N))
         st = self.lib.diral_env_observe(self._h, _ptr(a), _ptr(chobs), _ptr(rew), _ptr(self._obs), self._dt,
                                         float(episode_number), float(epsilon), self._stream())
@@ -589,6 +590,18 @@ class VecV2VEnv:
         self._ok(self.lib.diral_env_import_entries(self._h, _ptr(rec), self._stream()), "diral_env_import_entries")
         torch.cuda.current_stream(self.device).synchronize()   # `rec` may be a temporary
 
+    def prev_obs(self) -> torch.Tensor:
+        """State.piggybacking: TestEnv.prev_obs (test_env.py:76-79, 260-261), [B, N, A] float64."""
+        out = torch.empty((self.B, self.N, self.A), dtype=torch.float64, device=self.device)
+        self._ok(self.lib.diral_env_export_prev_obs(self._h, _ptr(out), self._stream()), "diral_env_export_prev_obs")
+        return out
+
+    def set_prev_obs(self, prev_obs) -> None:
+        p = self._f64(prev_obs, (self.B, self.N, self.A))
+        self._spec = None
+        self._ok(self.lib.diral_env_import_prev_obs(self._h, _ptr(p), self._stream()), "diral_env_import_prev_obs")
+        torch.cuda.current_stream(self.device).synchronize()   # `p` may be a temporary
+
     def info_age(self, t: int) -> torch.Tensor:
         """network.py:560-574 (`env.network.get_information_age(t)`), [B, 100] int32."""
         out = torch.empty((self.B, 100), dtype=torch.int32, device=self.device)
@@ -602,6 +615,6 @@ class VecV2VEnv:
         return out
 
     def check(self) -> None:
-        """Raise if a kernel flagged an out-of-range action or a sequence
-        overflow since the last check (synchronises the stream)."""
+        """Raise if a kernel flagged an out-of-range action, a sequence overflow or (State.piggybacking) a receiver
+        without a transmitter in range since the last check (synchronises the stream)."""
         self._ok(self.lib.diral_env_check(self._h, self._stream()), "diral_env_check")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 6
+#define DIRAL_ABI_VERSION 7
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -52,11 +52,15 @@ typedef enum DiralStatus {
                                   (first step after a kernel-path switch, export /
                                   observe after ring steps) while `stream` is being
                                   captured into a hipGraph: do it outside the capture */
-  DIRAL_ERR_TABLE_CONFLICT = -9 /* imported tables: two entries about one subject carry
+  DIRAL_ERR_TABLE_CONFLICT = -9, /* imported tables: two entries about one subject carry
                                   the same sequence number but different xpos - no
                                   run of the reference produces that (an entry IS the
                                   subject's stamp at that number, vehicle.py:35-63);
                                   raised by diral_env_check after an import      */
+  DIRAL_ERR_PIGGY_NO_TX = -10  /* State.piggybacking: a receiver found no transmitter in range
+                                  on a used resource - the reference's `self.prev_obs[tx_id]`
+                                  with tx_id None, a KeyError (test_env.py:243; sticky flag
+                                  raised by the step, reported by diral_env_check)      */
 } DiralStatus;
 
 /* ---- config flags: the booleans of the `EnvironmentTest` YAML block -------- */
@@ -76,6 +80,14 @@ enum {
   DIRAL_F_FINGERPRINT       = 1u << 12, /* enable_fingerprint  test_env.py:19  */
   DIRAL_F_PROPORTIONAL_FAIR = 1u << 13, /* proportional_fair   test_env.py:22  */
   DIRAL_F_DESIGN_TOPOLOGY   = 1u << 14, /* enable_design_topology test_env.py:16 */
+  DIRAL_F_PIGGYBACKING      = 1u << 15, /* State.piggybacking  test_env.py:33, 71-79, 241-254, 260-264: my_step returns,
+                                           per agent, its observation with the previous observation of each resource's
+                                           closest transmitter inserted (np.insert at the resource's index): A * A values.
+                                           Needs State.type 2 and State.add_channel_obs (DIRAL_ERR_BAD_CONFIG otherwise:
+                                           type 1 makes the vector's length depend on the slot's traffic, and without the
+                                           channel-observation section obtain_state never reads what get_state_space()
+                                           counts); my_step_ch / my_step_design return DIRAL_ERR_BAD_CONFIG on such a handle
+                                           (they hand obtain_state the plain A-wide observation, test_env.py:316, 443) */
   /* build extensions (no reference counterpart) */
   DIRAL_F_TRACK_ARRIVAL     = 1u << 16, /* keep last_arrival_time[N][N] (network.py:39-42)
                                            so diral_env_info_age() works        */
@@ -84,8 +96,7 @@ enum {
 
 /* One env configuration = the `EnvironmentTest` block (test_env.py:12-48) plus
  * its nested `State` block (test_env.py:26-41) and the driver's
- * `episode_interval` (main_test.py:226).  `State.piggybacking` (test_env.py:33)
- * is not representable: it must be False (out of scope). */
+ * `episode_interval` (main_test.py:226). */
 typedef struct DiralCfg {
   uint32_t struct_bytes;        /* = sizeof(DiralCfg); ABI guard               */
   uint32_t flags;               /* DIRAL_F_*                                   */
@@ -224,7 +235,10 @@ int diral_env_reset(DiralEnv* env, const double* x0, const double* y0,
  * rew_out   [B][N]    (dtype `out_dtype`), NULL allowed
  * done_out  [B] uint8, NULL allowed: t % episode_interval == episode_interval-1
  * chobs_out [B][N][A] (dtype `out_dtype`), NULL allowed: the `obs` dict of the
- *           reference step (test_env.py:143, 206, 228, 240)
+ *           reference step (test_env.py:143, 206, 228, 240).  With DIRAL_F_PIGGYBACKING
+ *           [B][N][A * A]: the `piggy_obs` dict my_step returns instead (test_env.py:263-264),
+ *           and the env keeps this slot's plain observation as the next slot's `prev_obs`
+ *           (test_env.py:260-261)
  * episode, epsilon: only used with DIRAL_F_FINGERPRINT (test_env.py:577-579) */
 int diral_env_step(DiralEnv* env, int mode, const int32_t* actions, int64_t t,
                    void* state_out, void* rew_out, uint8_t* done_out,
@@ -233,8 +247,9 @@ int diral_env_step(DiralEnv* env, int mode, const int32_t* actions, int64_t t,
 
 /* Observation only, no state change: replaces a stand-alone
  * TestEnv.obtain_state(obs, acts, rewards, episode, eps) (test_env.py:527-583)
- * on the CURRENT tables/positions.  chobs_in [B][N][A] and rew_in [B][N] are
- * float64 device arrays (NULL allowed when the State flags do not use them). */
+ * on the CURRENT tables/positions.  chobs_in [B][N][A] ([B][N][A * A] with
+ * DIRAL_F_PIGGYBACKING) and rew_in [B][N] are float64 device arrays (NULL allowed
+ * when the State flags do not use them). */
 int diral_env_observe(DiralEnv* env, const int32_t* actions,
                       const double* chobs_in, const double* rew_in,
                       void* state_out, int out_dtype, double episode,
@@ -293,6 +308,12 @@ int diral_env_import_state(DiralEnv* env, const double* pos_x,
                            const double* tab_x, const int32_t* last_arrival,
                            void* stream);
 
+/* DIRAL_F_PIGGYBACKING: TestEnv.prev_obs (test_env.py:76-79, 260-261), the plain channel
+ * observation of the last my_step, [B][N][A] float64 device arrays; zeros after a reset.
+ * Handles without the flag return DIRAL_ERR_BAD_CONFIG. */
+int diral_env_export_prev_obs(DiralEnv* env, double* prev_obs, void* stream);
+int diral_env_import_prev_obs(DiralEnv* env, const double* prev_obs, void* stream);
+
 /* The same tables as 16-byte records in the field order of the RealNeS bridge's
  * MA_NeighborTableEntry message (envs/ma_messages_pb2.py:195-230: float pos_x,
  * float pos_y, int32 seq_num, int32 last_update - what
@@ -315,7 +336,7 @@ int diral_env_import_entries(DiralEnv* env, const DiralNeighborEntry* entries, v
  * accumulators afterwards. */
 int diral_env_metrics(DiralEnv* env, double* out, int clear, void* stream);
 
-/* Sticky device-side error flags (action range, sequence overflow) raised by
+/* Sticky device-side error flags (action range, sequence overflow, piggybacking without a transmitter) raised by
  * kernels since the last call.  SYNCHRONISES `stream`.  Returns DIRAL_OK or the
  * first error. */
 int diral_env_check(DiralEnv* env, void* stream);

@@ -40,12 +40,14 @@ typedef struct {
   double *tx, *ty;            /* [N][N] xpos / ypos                                 */
   int64_t *la;                /* [N][N] last_arrival_time[tx][rx] network.py:39-42  */
   int32_t *pf;                /* [N]   pf_counter test_env.py:87-92                 */
+  double *prev_obs;           /* [N][A] TestEnv.prev_obs test_env.py:76-79, 260-261 (State.piggybacking) */
   double metrics[DIRAL_M_COLUMNS];
 } OEnv;
 
 typedef struct {
   DiralCfg cfg;
   int B, N, A, K, S, sq_mode, threads;
+  int piggy_keyerror;         /* a step hit `self.prev_obs[None]` (test_env.py:243): the reference raises KeyError */
   double *edges;              /* [K+1] np.linspace(-Rb, Rb, K+1) */
   double *edges1;             /* [K+1] np.linspace(-1, 1, K+1)   */
   double *trace;              /* [T][N] Network.x_positions (network.py:171-178), NULL = none */
@@ -218,16 +220,35 @@ static void update_mobility(const Oracle *o, OEnv *e, int64_t timestep) {
 
 /* one env, one slot: my_step / my_step_ch / my_step_design
  * (test_env.py:124-266 / 351-443 / 269-349) */
-static void step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
-                     int64_t t, double *rews, double *chobs) {
+/* np.insert(arr, i, vals) for 1-D arrays (test_env.py:247, 254): `m` values in front of index i */
+static void np_insert(double *arr, int *len, int i, const double *vals, int m) {
+  memmove(arr + i + m, arr + i, sizeof(double) * (size_t)(*len - i));
+  if (vals) memcpy(arr + i, vals, sizeof(double) * (size_t)m);
+  else for (int j = 0; j < m; ++j) arr[i + j] = 0.0;
+  *len += m;
+}
+
+/* `chobs_out`: the dict my_step* returns, [N][A] - or, with State.piggybacking in my_step, piggy_obs [N][A * A]
+ * (test_env.py:263-264).  Returns 1 when the reference would have raised KeyError (prev_obs[None], :243). */
+static int step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
+                    int64_t t, double *rews, double *chobs_out) {
   const int N = o->N, A = o->A;
   const int rd = o->cfg.reward_design;
   const int piggy = has(o, DIRAL_F_ADD_POSDIST_PIGGY);
+  const int pb = has(o, DIRAL_F_PIGGYBACKING) && mode == DIRAL_STEP_MY_STEP;
+  int keyerror = 0;
   int *txs = (int *)malloc(sizeof(int) * (size_t)N);
   char *is_tx = (char *)malloc((size_t)N);
   double *r_tx = (double *)malloc(sizeof(double) * (size_t)N);
+  /* piggybacking: `obs` (plain, what becomes prev_obs) and `piggy_obs` (returned) are two dicts (test_env.py:134-135);
+   * a piggy_obs[user] array grows by A per insert, A * A at most */
+  double *chobs = pb ? (double *)malloc(sizeof(double) * (size_t)N * A) : chobs_out;
+  double *pobs = pb ? (double *)calloc((size_t)N * (A * A + A), sizeof(double)) : NULL;
+  int *plen = pb ? (int *)malloc(sizeof(int) * (size_t)N) : NULL;
+  const size_t pstride = (size_t)A * A + A;
   for (int u = 0; u < N; ++u) rews[u] = 0.0;
   for (size_t j = 0; j < (size_t)N * A; ++j) chobs[j] = 0.0;
+  if (pb) for (int u = 0; u < N; ++u) plen[u] = A;    /* np.zeros((action_space,)) test_env.py:145 */
 
   if (piggy) periodic_update(o, e);                    /* test_env.py:138-139 */
 
@@ -278,6 +299,7 @@ static void step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
     for (int u = 0; u < N; ++u) {
       if (is_tx[u]) {
         chobs[(size_t)u * A + i] = 0.0;                 /* half duplex */
+        if (pb) pobs[u * pstride + i] = 0.0;            /* test_env.py:209: index i of the GROWN array */
         if (mode == DIRAL_STEP_MY_STEP) {               /* test_env.py:211-222 */
           if (tot > 1) {
             rews[u] = rewards;
@@ -325,6 +347,14 @@ static void step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
           } else if (o->cfg.state_type == 2) {
             if (piggy && tx_id >= 0) received_update(o, e, u, tx_id);
             chobs[(size_t)u * A + i] = tx_dist;
+            if (pb) {                                   /* test_env.py:241-247 */
+              if (tx_id < 0) { keyerror = 1; break; }   /* self.prev_obs[None]: KeyError */
+              else {
+                const double *tmp_a = e->prev_obs + (size_t)tx_id * A;
+                pobs[u * pstride + i] = tx_dist;
+                np_insert(pobs + u * pstride, &plen[u], i, tmp_a, A);
+              }
+            }
           }
         } else if (mode == DIRAL_STEP_MY_STEP_CH) {     /* test_env.py:431-439 */
           chobs[(size_t)u * A + i] = 1.0;
@@ -336,13 +366,28 @@ static void step_env(const Oracle *o, OEnv *e, int mode, const int32_t *act,
           chobs[(size_t)u * A + i] = 1.0;
           if (piggy && tx_id >= 0) received_update(o, e, u, tx_id);
         }
+      } else if (pb) {
+        /* no transmission on i: A zeros at index i (test_env.py:250-254) */
+        np_insert(pobs + u * pstride, &plen[u], i, NULL, A);
       }
     }
+    if (keyerror) break;                                /* the exception leaves my_step here */
   }
-  update_mobility(o, e, t);                             /* test_env.py:259 */
-  e->metrics[DIRAL_M_SLOTS] += 1;
-  for (int u = 0; u < N; ++u) e->metrics[DIRAL_M_SUM_REWARD] += rews[u];
+  if (!keyerror) {
+    update_mobility(o, e, t);                           /* test_env.py:259 */
+    e->metrics[DIRAL_M_SLOTS] += 1;
+    for (int u = 0; u < N; ++u) e->metrics[DIRAL_M_SUM_REWARD] += rews[u];
+  }
+  if (pb) {
+    if (!keyerror) {
+      memcpy(e->prev_obs, chobs, sizeof(double) * (size_t)N * A);   /* self.prev_obs = obs, test_env.py:260-261 */
+      for (int u = 0; u < N; ++u)                                    /* every array ends A * A long: A - 1 inserts of A */
+        memcpy(chobs_out + (size_t)u * A * A, pobs + u * pstride, sizeof(double) * (size_t)A * A);
+    }
+    free(chobs); free(pobs); free(plen);
+  }
   free(txs); free(is_tx); free(r_tx);
+  return keyerror;
 }
 
 /* Network.dist_piggy (network.py:538-558) */
@@ -468,8 +513,10 @@ static void obtain_state_env(const Oracle *o, const OEnv *e, const int32_t *act,
       if (has(o, DIRAL_F_ACTION_REAL)) s[p++] = (double)act[u];
       else { for (int i = 0; i < A; ++i) s[p++] = (act[u] == i) ? 1.0 : 0.0; }
     }
-    if (has(o, DIRAL_F_ADD_CHANNEL_OBS))
-      for (int i = 0; i < A; ++i) s[p++] = chobs[(size_t)u * A + i];
+    if (has(o, DIRAL_F_ADD_CHANNEL_OBS)) {            /* `obs[user_i]`: A values, A * A with piggybacking */
+      const int CW = has(o, DIRAL_F_PIGGYBACKING) ? A * A : A;
+      for (int i = 0; i < CW; ++i) s[p++] = chobs[(size_t)u * CW + i];
+    }
     if (has(o, DIRAL_F_ADD_POSDIST)) { posdist_full(o, e, u, s + p); p += N - 1; }
     if (has(o, DIRAL_F_ADD_POSDIST_PIGGY)) {
       if (o->cfg.posdist_type == 1) posdist_piggy1(o, e, u, s + p);
@@ -489,7 +536,7 @@ static void obtain_state_env(const Oracle *o, const OEnv *e, const int32_t *act,
 
 /* ------------------------------------------------------------------ API ---- */
 
-/* state-space sizing, test_env.py:49-85 (piggybacking excluded) */
+/* state-space sizing, test_env.py:49-85 */
 int oracle_state_space(const DiralCfg *c) {
   int S = 0;
   if (c->flags & DIRAL_F_ADD_ACTION) S += (c->flags & DIRAL_F_ACTION_REAL) ? 1 : c->num_channels;
@@ -499,6 +546,7 @@ int oracle_state_space(const DiralCfg *c) {
   if (c->flags & DIRAL_F_ADD_VELOCITY) S += 1;
   if (c->flags & DIRAL_F_ADD_POSITION) S += 2;
   if (c->flags & DIRAL_F_ADD_POSDIST) S += c->num_users - 1;
+  if (c->flags & DIRAL_F_PIGGYBACKING) S += c->num_channels * (c->num_channels - 1);   /* test_env.py:71-72 */
   if (c->flags & DIRAL_F_FINGERPRINT) S += 2;
   if (c->flags & DIRAL_F_ADD_POSDIST_PIGGY) S += c->num_bins;
   return S;
@@ -529,6 +577,7 @@ void *oracle_create(const DiralCfg *cfg, int B, int sq_mode, int threads) {
     e->ty = (double *)calloc(N * N, sizeof(double));
     e->la = (int64_t *)malloc(N * N * sizeof(int64_t));
     e->pf = (int32_t *)calloc(N, sizeof(int32_t));
+    e->prev_obs = (double *)calloc(N * (size_t)o->A, sizeof(double));   /* test_env.py:76-79 */
     for (size_t j = 0; j < N * N; ++j) e->la[j] = -1;
   }
   return o;
@@ -540,7 +589,7 @@ void oracle_destroy(void *h) {
   for (int b = 0; b < o->B; ++b) {
     OEnv *e = &o->envs[b];
     free(e->px); free(e->py); free(e->vel); free(e->seq); free(e->age);
-    free(e->tx); free(e->ty); free(e->la); free(e->pf);
+    free(e->tx); free(e->ty); free(e->la); free(e->pf); free(e->prev_obs);
   }
   free(o->envs); free(o->edges); free(o->edges1); free(o->trace); free(o);
 }
@@ -559,20 +608,33 @@ void oracle_reset(void *h, const double *x0, const double *y0, const double *v0)
     memset(e->tx, 0, N * N * sizeof(double));
     memset(e->ty, 0, N * N * sizeof(double));
     memset(e->pf, 0, N * sizeof(int32_t));
+    memset(e->prev_obs, 0, N * (size_t)o->A * sizeof(double));
     memset(e->metrics, 0, sizeof(e->metrics));
     for (size_t j = 0; j < N * N; ++j) e->la[j] = -1;
   }
 }
 
-void oracle_step(void *h, int mode, const int32_t *actions, int64_t t,
-                 double *rews, double *chobs) {
+/* chobs: [B][N][A], or [B][N][A * A] for my_step on a State.piggybacking config.  Returns 0, or 1 when some env hit the
+ * reference's KeyError (test_env.py:243: the state of that env is then whatever the exception left behind). */
+int oracle_step(void *h, int mode, const int32_t *actions, int64_t t,
+                double *rews, double *chobs) {
   Oracle *o = (Oracle *)h;
   size_t N = (size_t)o->N, A = (size_t)o->A;
+  const size_t CW = (has(o, DIRAL_F_PIGGYBACKING) && mode == DIRAL_STEP_MY_STEP) ? A * A : A;
+  int err = 0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(o->threads)
+#pragma omp parallel for schedule(static) num_threads(o->threads) reduction(|:err)
 #endif
   for (int b = 0; b < o->B; ++b)
-    step_env(o, &o->envs[b], mode, actions + b * N, t, rews + b * N, chobs + b * N * A);
+    err |= step_env(o, &o->envs[b], mode, actions + b * N, t, rews + b * N, chobs + b * N * CW);
+  if (err) o->piggy_keyerror = 1;
+  return err;
+}
+
+void oracle_prev_obs(void *h, double *out) {
+  Oracle *o = (Oracle *)h;
+  size_t n = (size_t)o->N * o->A;
+  for (int b = 0; b < o->B; ++b) memcpy(out + b * n, o->envs[b].prev_obs, n * sizeof(double));
 }
 
 void oracle_obtain_state(void *h, const int32_t *actions, const double *chobs,
@@ -580,6 +642,7 @@ void oracle_obtain_state(void *h, const int32_t *actions, const double *chobs,
                          double *state) {
   Oracle *o = (Oracle *)h;
   size_t N = (size_t)o->N, A = (size_t)o->A, S = (size_t)o->S;
+  if (has(o, DIRAL_F_PIGGYBACKING)) A = A * A;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(o->threads)
 #endif

@@ -45,6 +45,8 @@ def _load():
     lib.oracle_destroy.argtypes = [P]
     lib.oracle_reset.argtypes = [P, P, P, P]
     lib.oracle_step.argtypes = [P, ctypes.c_int, P, ctypes.c_int64, P, P]
+    lib.oracle_step.restype = ctypes.c_int
+    lib.oracle_prev_obs.argtypes = [P, P]
     lib.oracle_obtain_state.argtypes = [P, P, P, P, ctypes.c_double, ctypes.c_double, P]
     lib.oracle_update_velocity.argtypes = [P, P]
     lib.oracle_info_age.argtypes = [P, ctypes.c_int64, P]
@@ -91,13 +93,22 @@ class Oracle:
     def step(self, mode: int, actions, t: int) -> Tuple[np.ndarray, np.ndarray]:
         a = np.ascontiguousarray(np.broadcast_to(actions, (self.B, self.N)), dtype=np.int32)
         rews = np.empty((self.B, self.N), np.float64)
-        chobs = np.empty((self.B, self.N, self.A), np.float64)
-        self.lib.oracle_step(self.h, mode, _p(a), int(t), _p(rews), _p(chobs))
+        # State.piggybacking: my_step returns piggy_obs, A * A values per agent (test_env.py:263-264)
+        cw = self.cfg.chobs_width if mode == 0 else self.A
+        chobs = np.empty((self.B, self.N, cw), np.float64)
+        if self.lib.oracle_step(self.h, mode, _p(a), int(t), _p(rews), _p(chobs)):
+            raise KeyError(None)            # the reference's `self.prev_obs[tx_id]` with tx_id None (test_env.py:243)
         return rews, chobs
+
+    def prev_obs(self) -> np.ndarray:
+        """TestEnv.prev_obs (test_env.py:76-79, 260-261), [B, N, A]."""
+        out = np.empty((self.B, self.N, self.A), np.float64)
+        self.lib.oracle_prev_obs(self.h, _p(out))
+        return out
 
     def obtain_state(self, actions, chobs, rews, episode: float = 0, eps: float = 1) -> np.ndarray:
         a = np.ascontiguousarray(np.broadcast_to(actions, (self.B, self.N)), dtype=np.int32)
-        chobs = np.ascontiguousarray(chobs, dtype=np.float64).reshape(self.B, self.N, self.A)
+        chobs = np.ascontiguousarray(chobs, dtype=np.float64).reshape(self.B, self.N, self.cfg.chobs_width)
         rews = np.ascontiguousarray(rews, dtype=np.float64).reshape(self.B, self.N)
         state = np.empty((self.B, self.N, self.S), np.float64)
         self.lib.oracle_obtain_state(self.h, _p(a), _p(chobs), _p(rews), float(episode),

@@ -112,7 +112,7 @@ def sha(a):
 
 
 def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
-             full_tables=True, episode_eps=None, trace=None, trace_after=None):
+             full_tables=True, episode_eps=None, trace=None, trace_after=None, extra=None):
     """steps: list of (mode, actions, t).  vel_updates: {step_index: draws[N]}
     applied AFTER that step (main_test.py:226-233 order)."""
     if trace is not None:
@@ -194,6 +194,11 @@ def run_case(name, cfg, init, steps, vel_updates=None, table_every=1,
         out[k] = np.array(v)
     for k, v in tab.items():
         out["tab_" + k] = np.array(v)
+    if getattr(env, "piggybacking", False):
+        # TestEnv.prev_obs after the last step (test_env.py:260-261): dict user -> ndarray[A]
+        out["prev_obs"] = np.array([env.prev_obs[u] for u in range(N)], dtype=np.float64)
+    for k, v in (extra or {}).items():
+        out[k] = np.asarray(v)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-28s N=%-3d A=%-2d steps=%-3d  %7.1f KB" % (
@@ -430,6 +435,58 @@ def main():
              rand_steps(rng, "step", 4, 33, 1), full_tables=False)
 
 
+def main_piggyback():
+    # ---- P: State.piggybacking (test_env.py:71-79, 241-254, 260-264): my_step returns each agent's observation
+    # with the previous observation of every resource's closest transmitter np.insert-ed at the resource's index -
+    # A * A values, the channel-observation section of the state vector; defined while every receiver hears a
+    # transmitter on every used resource (communication_range >= highway_length), a KeyError otherwise
+    toy_actions = [[0, 1, 2, 0], [0, 0, 0, 0], [1, 1, 2, 2], [2, 2, 2, 1]]
+    pb = dict(piggybacking=True, add_channel_obs=True)
+    rng = np.random.default_rng(501)
+    run_case("g1_piggyback", cfg_with(state=pb), "fixed4",
+             [("step", a, t) for t, a in enumerate(toy_actions)] +
+             [("step", rng.integers(0, 3, size=4), t) for t in range(4, 30)], table_every=29)
+    rng = np.random.default_rng(502)
+    run_case("g1_piggyback_flags",
+             cfg_with(state=dict(pb, add_reward=True, add_index=True, add_position=True, add_velocity=True,
+                                 add_positional_dist=True), reward_design=3, enable_fingerprint=True),
+             "fixed4", rand_steps(rng, "step", 12, 4, 3, sticky=0.4), table_every=11,
+             episode_eps=[(t // 5, 0.99 ** t) for t in range(12)])
+    rng = np.random.default_rng(503)
+    run_case("g8_piggyback_n6_a4", big_cfg(6, 4, 400, communication_range=500, state=dict(pb, num_bins=10)),
+             rand_init(rng, 6, 400, False), rand_steps(rng, "step", 25, 6, 4), table_every=24)
+    rng = np.random.default_rng(504)
+    run_case("g8_piggyback_n9_a5_type1hist",
+             big_cfg(9, 5, 300, communication_range=300, mobility_vary=True,
+                     state=dict(pb, add_positional_dist_type=1, num_bins=8)),
+             rand_init(rng, 9, 300, True), rand_steps(rng, "step", 30, 9, 5, sticky=0.5),
+             vel_updates={24: rng.integers(1, 4, size=9)}, table_every=29)
+    # a highway longer than the communication range: the slot in which a receiver hears nobody on a used
+    # resource raises KeyError (`self.prev_obs[None]`, test_env.py:243).  Recorded: the slots before it, and the
+    # actions of the slot that raised
+    rng = np.random.default_rng(505)
+    cfg = big_cfg(8, 3, 1000, communication_range=250, state=pb)
+    # (the vehicles start within range of one another just short of the end of the highway; the first to wrap
+    # around to x = 0 (network.py:189-206) is 900 m from the rest: network.py:318-332 has no ring distance)
+    init = (np.arange(8) * 7.0 + 930.0, np.zeros(8), rng.uniform(1.1, 2.7, size=8))
+    steps = rand_steps(rng, "step", 40, 8, 3)
+    env = make_env(cfg)
+    set_init(env, *init)
+    raised_at = -1
+    for si, (_, acts, t) in enumerate(steps):
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                env.my_step(np.asarray(acts, dtype=np.int32), t)
+        except KeyError as ex:
+            assert ex.args == (None,)
+            raised_at = si
+            break
+    assert raised_at >= 0
+    run_case("g8_piggyback_keyerror", cfg, init, steps[:raised_at], table_every=max(raised_at - 1, 1),
+             extra=dict(keyerror_actions=np.asarray(steps[raised_at][1], dtype=np.int32),
+                        keyerror_t=np.int64(steps[raised_at][2])))
+
+
 def main_trace():
     # ---- T: trace replay (load_positions, network.py:171-178, 194-199) ----------
     rng = np.random.default_rng(91)
@@ -553,8 +610,11 @@ if __name__ == "__main__":
         main_sps()
     elif len(sys.argv) > 1 and sys.argv[1] == "trace":
         main_trace()
+    elif len(sys.argv) > 1 and sys.argv[1] == "piggyback":
+        main_piggyback()
     else:
         main()
+        main_piggyback()
         main_trace()
         main_driver()
         main_sps()

@@ -73,3 +73,6 @@ class OracleBackend:
 
     def info_age(self, t):
         return self.o.info_age(t)
+
+    def check(self):
+        pass            # (the oracle raises inside step itself, like the reference)

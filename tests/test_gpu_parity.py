@@ -83,9 +83,10 @@ def test_golden_replay_on_gpu(name):
             if cfg.State.add_positional_dist_piggy:
                 K = cfg.State.num_bins
                 off = (cfg.num_channels if cfg.State.action_index == "binary" else 1) if cfg.State.add_action else 0
-                off += cfg.num_channels if cfg.State.add_channel_obs else 0
+                off += cfg.chobs_width if cfg.State.add_channel_obs else 0
                 off += cfg.num_users - 1 if cfg.State.add_positional_dist else 0
-                assert np.array_equal(obs[b][:, off:off + K], ref_state[:, off:off + K]), "histogram bins"
+                if cfg.State.add_positional_dist_type == 2:
+                    assert np.array_equal(obs[b][:, off:off + K], ref_state[:, off:off + K]), "histogram bins"
             assert done[b] == ((t % cfg.episode_interval) == cfg.episode_interval - 1)
         if i in g.vel_updates:
             env.update_velocity(g.vel_updates[i])
@@ -113,6 +114,20 @@ def test_golden_replay_on_gpu(name):
                 assert np.array_equal(st["y"][b], g["tab_y"][j])
                 assert np.array_equal(st["la"][b], g["tab_la"][j])
     env.check()
+    if cfg.State.piggybacking:
+        # TestEnv.prev_obs after the last slot (test_env.py:260-261): distances, within 1 ulp of the reference's pow()
+        po = env.prev_obs().cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(po[b], orc.prev_obs()[0]) and ulp_diff(po[b], g["prev_obs"]) <= DIST_ULP
+        if "keyerror_actions" in g.d.files:
+            # the slot the reference left with KeyError (`self.prev_obs[None]`, test_env.py:243): the sticky device flag
+            from diral_amd.config import ERR_PIGGY_NO_TX
+            from diral_amd.vec_env import DiralError
+            gpu_step(env, STEP_MY_STEP, g["keyerror_actions"], int(g["keyerror_t"]))
+            with pytest.raises(DiralError) as ei:
+                env.check()
+            assert ei.value.status == ERR_PIGGY_NO_TX
+            env.check()                                             # reported once, then cleared
 
 
 def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8, track_prr=False,
@@ -157,7 +172,7 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
             # diral_env_observe -> observe_kernel.hpp (the general kernel's observe mode when forced)
             from diral_amd.config import KERNEL_GENERAL, KERNEL_OBSERVE
             fa = rng.integers(0, A, size=(B, N)).astype(np.int32)
-            fc = rng.uniform(0.0, 300.0, size=(B, N, A))
+            fc = rng.uniform(0.0, 300.0, size=(B, N, cfg.chobs_width))
             fr = rng.uniform(-3.0, 1.0, size=(B, N))
             s1 = env.obtain_state(fc, fa, fr, 3.0, 0.25).cpu().numpy()
             assert (env.last_kernel() & 15) == (KERNEL_GENERAL if force_general else KERNEL_OBSERVE)

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     from diral_amd.config import ABI_VERSION
     src = open(os.path.join(ROOT, "include", "diral_env.h")).read()
-    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 6
+    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 7
 
 
 def test_cfg_struct_layout_matches_header():
@@ -117,10 +117,42 @@ def test_config_accepts_reference_dict_verbatim():
     d = dict(g.cfg_dict); d["State"] = dict(d["State"]); del d["State"]["num_bins"]
     with pytest.raises(ConfigError):
         EnvConfig.from_dict(d)                                    # reference: KeyError
+    # State.piggybacking (test_env.py:71-79, 241-254): defined with State.type 2 + add_channel_obs only
     for bad in (dict(reward_design=0), dict(State=dict(piggybacking=True)), dict(State=dict(type=3)),
+                dict(State=dict(piggybacking=True, add_channel_obs=True, type=1)),
                 dict(mobility=False), dict(State=dict(action_index="hex"))):
         with pytest.raises(ConfigError):
             bench_config(8, 4, 100.0, **bad).validate()
+    pb = bench_config(8, 4, 100.0, State=dict(piggybacking=True, add_channel_obs=True))
+    pb.validate()
+    assert pb.chobs_width == 16 and pb.state_space == 4 + 4 + 4 * 3 + 20        # test_env.py:49-85
+    from diral_amd.config import F_PIGGYBACKING
+    assert pb.to_c().flags & F_PIGGYBACKING
+
+
+def test_piggybacking_fixture_config_and_the_oracle_backed_shim():
+    """State.piggybacking through the reference-shaped shim on the CPU-backed test backend: obs[user] holds A * A
+    values, the state vector get_state_space() columns (g1_piggyback: 32), and the slot in which a receiver hears
+    nobody raises KeyError like the reference (test_env.py:243)."""
+    from diral_amd.compat import TestEnv
+    from tests.oracle_backend import OracleBackend
+    g = Golden("g1_piggyback")
+    assert g.cfg.State.piggybacking and g.cfg.state_space == int(g["state_space"]) == 32
+    env = TestEnv(backend=OracleBackend(g.cfg), **g.cfg_dict)
+    env.reset_mobility_env()
+    for i, mode, acts, t, (ep, eps) in g.steps():
+        obs, rews = env.my_step(acts, t)
+        assert sorted(obs) == list(range(4)) and all(obs[u].shape == (9,) for u in obs)
+        st = env.obtain_state(obs, acts, rews, ep, eps)
+        assert np.array_equal(np.array([obs[u] for u in range(4)]), g["chobs"][i])
+        assert np.array_equal(np.array(st), g["state"][i])
+    gk = Golden("g8_piggyback_keyerror")
+    envk = TestEnv(backend=OracleBackend(gk.cfg), **gk.cfg_dict)
+    envk._env.reset_topology(gk["x0"], gk["y0"], gk["v0"])
+    for i, mode, acts, t, _ in gk.steps():
+        envk.my_step(acts, t)
+    with pytest.raises(KeyError):
+        envk.my_step(gk["keyerror_actions"], int(gk["keyerror_t"]))
 
 
 def test_config_from_yaml(tmp_path):

@@ -67,6 +67,13 @@ def test_oracle_reproduces_reference_bit_exact(name):
             assert np.array_equal(e["x"][0], g["tab_x"][j])
             assert np.array_equal(e["y"][0], g["tab_y"][j])
             assert np.array_equal(e["la"][0], g["tab_la"][j])
+    if g.cfg.State.piggybacking:
+        # TestEnv.prev_obs after the last slot (test_env.py:260-261)
+        assert np.array_equal(o.prev_obs()[0], g["prev_obs"])
+        if "keyerror_actions" in g.d.files:
+            # the slot the reference left with KeyError (`self.prev_obs[None]`, test_env.py:243)
+            with pytest.raises(KeyError):
+                o.step(0, g["keyerror_actions"], int(g["keyerror_t"]))
 
 
 @pytest.mark.parametrize("name", ["g4_c2_step", "g4_c2_ch", "g4_c2_vary_rd1", "g6_c5_vary",
@@ -183,11 +190,14 @@ def test_fixtures_carry_the_keys_the_generator_writes():
     sps_keys = {"A", "threshold", "tie_step", "init_prev", "init_counter", "codes", "draw_counter", "draw_keep",
                 "draw_choice", "actions", "counters", "prev_actions", "reselections"}
     names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(gdir, "*.npz")))
-    assert len([n for n in names if n[0] == "g"]) == 33 and len([n for n in names if n[0] == "s"]) == 7
+    assert len([n for n in names if n[0] == "g"]) == 38 and len([n for n in names if n[0] == "s"]) == 7
     for n in names:
         keys = set(np.load(os.path.join(gdir, n + ".npz")).files)
         if n[0] == "g":
-            assert keys == case_keys, (n, keys ^ case_keys)
+            # State.piggybacking fixtures also hold TestEnv.prev_obs; the KeyError one the slot that raised
+            more = {"prev_obs"} if "piggyback" in n else set()
+            more |= {"keyerror_actions", "keyerror_t"} if n.endswith("keyerror") else set()
+            assert keys == case_keys | more, (n, keys ^ (case_keys | more))
         elif n[0] == "s":
             assert keys == sps_keys, (n, keys ^ sps_keys)
             g = np.load(os.path.join(gdir, n + ".npz"))
