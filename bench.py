@@ -88,13 +88,13 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def _time_oracle(cfg, threads: int, seconds_target: float):
+def _time_oracle(cfg, threads: int, seconds_target: float, native: bool = False):
     import numpy as np
     from oracle.oracle import Oracle, SQ_POW
     N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
     B = max(threads * 16, 16)
     rng = np.random.default_rng(GLOBAL_SEED)
-    o = Oracle(cfg, batch=B, sq_mode=SQ_POW, threads=threads)
+    o = Oracle(cfg, batch=B, sq_mode=SQ_POW, threads=threads, native=native)
     o.reset(rng.integers(0, int(L), size=(B, N)).astype(np.float64), np.zeros((B, N)),
             rng.uniform(1.1, 2.7, size=(B, N)))
     warm, slots = 25, 0
@@ -115,25 +115,60 @@ def _time_oracle(cfg, threads: int, seconds_target: float):
     return B * N * slots / el, B, slots, warm, el
 
 
+def _native_oracle_agrees(cfg) -> bool:
+    """The -O3 -march=native build of oracle/diral_oracle.c (compiled here, on the box it runs on) against the checker
+    build (-O2, generic): rewards, channel observation and state vectors of a short seeded run, bit for bit."""
+    import numpy as np
+    from oracle.oracle import Oracle, SQ_POW
+    N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
+    runs = []
+    for native in (False, True):
+        rng = np.random.default_rng(77)
+        o = Oracle(cfg, batch=4, sq_mode=SQ_POW, threads=2, native=native)
+        o.reset(rng.integers(0, int(L), size=(4, N)).astype(np.float64), np.zeros((4, N)), rng.uniform(1.1, 2.7, size=(4, N)))
+        out = []
+        for t in range(30):
+            a = rng.integers(0, A, size=(4, N)).astype(np.int32)
+            r, c = o.step(0, a, t)
+            out += [r.copy(), c.copy(), o.obtain_state(a, c, r).copy()]
+        runs.append(out)
+    return all(np.array_equal(x, y) for x, y in zip(*runs))
+
+
 def cpu_baseline(cfg):
-    """Time the CPU oracle (oracle/diral_oracle.c, the reference restated in C,
-    reference-faithful pow() mode) on this host: at ONE thread and on every usable
-    core, on a bounded sample of the same workload.  A reported
-    baseline, not the target."""
-    from oracle.oracle import has_openmp
+    """Time the CPU restatement (oracle/diral_oracle.c, reference-faithful pow() mode) on this host: at ONE thread and
+    on every usable core, on a bounded sample of the same workload.  BASELINE.md section 4 asks for an
+    `-O3 -march=native` build: that build is compiled HERE (oracle/Makefile: libdiral_oracle_native.so), held to the
+    checker build (-O2, generic: what tests/ use) bit for bit on a short run, and is what gets timed; the checker
+    build is timed beside it (`checker_build`).  A reported baseline, not the target."""
+    from oracle.oracle import CHECKER_FLAGS, NATIVE_FLAGS, has_openmp
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     cores = usable_cores()
     threads = min(cores, 64) if has_openmp() else 1
-    v1, b1, s1, warm, e1 = _time_oracle(cfg, 1, 6.0)
-    vn, bn, sn, _, en = _time_oracle(cfg, threads, 10.0) if threads > 1 else (v1, b1, s1, warm, e1)
+    native, why = True, ""
+    try:
+        if not _native_oracle_agrees(cfg):
+            native, why = False, "the native build disagreed with the checker build"
+    except Exception as exc:            # no compiler on this box: time the checker build and say so
+        native, why = False, "native build failed (%s)" % type(exc).__name__
+    v1, b1, s1, warm, e1 = _time_oracle(cfg, 1, 6.0, native)
+    vn, bn, sn, _, en = _time_oracle(cfg, threads, 10.0, native) if threads > 1 else (v1, b1, s1, warm, e1)
+    chk = None
+    if native:
+        c1 = _time_oracle(cfg, 1, 3.0, False)
+        cn = _time_oracle(cfg, threads, 4.0, False) if threads > 1 else c1
+        chk = {"flags": "gcc " + CHECKER_FLAGS, "value": cn[0], "value_1thread": c1[0]}
     N, A = cfg.num_users, cfg.num_channels
+    flags = "gcc " + (NATIVE_FLAGS if native else CHECKER_FLAGS)
     return {
         "value": vn, "unit": "agent-steps/s", "cores": threads, "kind": "port",
         "value_1thread": v1, "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": cores,
+        "build_flags": flags, "checker_build": chk,
         "sample": "the same %d-UE/%d-res workload after %d warm-up slots, oracle/diral_oracle.c (C restatement "
-                  "pinned to the reference goldens), my_step + obtain_state per slot: %d envs x %d slots on %d "
+                  "pinned to the reference goldens) built with `%s`%s, my_step + obtain_state per slot: %d envs x %d slots on %d "
                   "OpenMP threads (%.1f s); %d envs x %d slots on 1 thread (%.1f s)" % (
-                      N, A, warm, bn, sn, threads, en, b1, s1, e1),
+                      N, A, warm, flags, (" [" + why + "]") if why else " on this box and checked against the -O2 checker build",
+                      bn, sn, threads, en, b1, s1, e1),
     }
 
 
@@ -262,6 +297,11 @@ def roofline_object(res, pmc):
                              else [res["layout_rate_GBps"] / HBM_PEAK_GBPS] * 2) if res.get("memory") else None,
         "model_bytes_per_launch": res["algorithmic_bytes_per_launch"],
         "model_throughput_TBps": res["algorithmic_bytes_per_launch"] / k_s / 1e12,
+        # SURVEY 8d's figure as the contract words it (algorithmic bytes per unit x units per launch / launch time / peak):
+        # a BYTE-MODEL ratio, not physical - `frac` / `counter_frac` are the bytes that move
+        "model_frac": res["algorithmic_bytes_per_launch"] / k_s / 1e9 / HBM_PEAK_GBPS,
+        "model_frac_note": "byte model (SURVEY 8d: 16-byte table entries), not physical: > 1 because the layout stores an entry "
+                           "in 2 bytes; frac / counter_frac are physical",
         "model_note": "SURVEY 8d's canonical byte model (16-byte table entry read + written) over the kernel time: a throughput "
                       "in the MODEL's units - this layout moves 2 bytes per entry, so the figure can exceed the 8 TB/s "
                       "peak without the HBM being near it; not a roofline fraction",

@@ -53,6 +53,7 @@ struct DiralEnv {
   uint64_t slow_launches = 0;   // launches that rotated the sets
   bool slow_first = true;       // DIRAL_NO_SLOW_FIRST=1 at create: blocks = envs in order (A/B timing, tests)
   bool capture_rotates = false; // diral_env_set_capture_rotation: captured launches rotate the sets too (graphs of 3 k launches)
+  bool type1_wide_lanes = false; // DIRAL_TYPE1_LANES=wide at create: rounds 3-4's 64 values per lane in posdist_type1_lanes_kernel (A/B)
   int f32_margin = -1;          // DIRAL_F32_MARGIN=<n> at create: 0 = no float32 screening of the bin, n > 0 = a band of at
                                 //   least n / 65536 bin widths (tests: a wide band sends many entries to float64); -1 = the bound
   int32_t* la = nullptr;
@@ -507,9 +508,7 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
     q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   if (type1_lanes) {
-    // (DIRAL_TYPE1_LANES=wide: rounds 3-4's 64 values per lane, for A/B)
-    const char* const tl = std::getenv("DIRAL_TYPE1_LANES");
-    const bool wide_lanes = tl && std::strcmp(tl, "wide") == 0;
+    const bool wide_lanes = e->type1_wide_lanes;               // (read once at create: never an env lookup on the step path)
     const int npad = p.N <= 128 ? 128 : 256;
     const int lpv = npad / (wide_lanes ? 64 : 32), vw = 64 / lpv, nvb = (p.N + vw - 1) / vw;
     q.do_type1 = 1;
@@ -783,6 +782,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   r.off_pos = off.pos; r.off_vel = off.vel; r.off_fp = off.fp;
   r.H = cfg->highway_height; r.vel = e->vel; r.pos_y = e->pos_y;
   // test hooks, read ONCE here (never on the step path): force the general kernel
+  if (const char* tl = std::getenv("DIRAL_TYPE1_LANES")) e->type1_wide_lanes = std::strcmp(tl, "wide") == 0;
   if (std::getenv("DIRAL_NO_FAST64") && e->vpl == 1) e->kernel_path = DIRAL_PATH_GENERAL;
   if (std::getenv("DIRAL_NO_WIDE") && e->vpl > 1) e->kernel_path = DIRAL_PATH_GENERAL;
   *out = e;

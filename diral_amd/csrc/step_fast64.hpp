@@ -162,7 +162,7 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
 }
 
 struct FastLds {
-  uint32_t rv, edges, mask, act, hist, cnt, slow, inv, mtab, rtx, inr, px, py, npx, rew, stage, nact, total;
+  uint32_t rv, edges, mask, act, hist, cnt, slow, inv, mtab, rtx, inr, px, py, npx, rew, stage, nact, kvel, total;
 };
 // row stride (elements) of the channel-observation staging array [vehicle][resource] of the RICH
 // instantiations: a multiple of 4 elements, so that the write-out reads a 16-byte piece of a row
@@ -204,6 +204,8 @@ __host__ __device__ inline FastLds fast_lds_layout(int K, int A, bool rich, bool
     l.stage = o; o += (out64 ? 8u : 4u) * 64 * fast_stage_stride(A);   // channel observation [vehicle][resource]
   }
   l.nact = o;  o += pol ? 4u * 64 : 0u;     // POL: the agents' actions of the next slot (K slots per launch)
+  o = align_up(o, 8);
+  l.kvel = o;  o += pol ? 8u * 64 : 0u;     // K slots per launch: the velocities the last slot's state vector reports (they live in registers)
   l.total = align_up(o, 16);
   return l;
 }

@@ -24,7 +24,13 @@ def reduce_metric_sums(local: torch.Tensor, group: Optional[dist.ProcessGroup] =
     # env count rides along so means can be formed without a second collective
     packed = torch.cat([sums, torch.tensor([float(local.shape[0])], dtype=torch.float64, device=sums.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        if packed.is_cuda and dist.get_backend(group) == "gloo":
+            # (a gloo group - CPU tests, or ranks that share one GPU: 7 doubles through host memory)
+            host = packed.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            packed = host.to(packed.device)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
 
 

@@ -28,9 +28,11 @@ def rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def make_sharded_env(cfg, total_envs: int, **kw):
+def make_sharded_env(cfg, total_envs: int, device=None, **kw):
     """This rank's VecV2VEnv slice of a `total_envs` batch (e.g. BASELINE
-    configs[3]: 262144 envs over 8 GPUs = 32768 per GPU).  Returns (env, start)."""
+    configs[3]: 262144 envs over 8 GPUs = 32768 per GPU).  Returns (env, start).
+    `device`: default cuda:LOCAL_RANK (one process per GPU); a box with fewer GPUs than ranks names one
+    (tests/test_gpu_shard.py runs two ranks on cuda:0)."""
     import torch
     from .vec_env import VecV2VEnv
     rank, local_rank, world = rank_world()
@@ -39,5 +41,5 @@ def make_sharded_env(cfg, total_envs: int, **kw):
     # (seed, global env index), so every rank can use the SAME seed and the job draws what one
     # handle holding all `total_envs` envs would draw
     kw.setdefault("env_offset", start)
-    env = VecV2VEnv(cfg, batch=count, device=torch.device("cuda", local_rank), **kw)
+    env = VecV2VEnv(cfg, batch=count, device=torch.device("cuda", local_rank) if device is None else device, **kw)
     return env, start

@@ -318,7 +318,7 @@ class VecV2VEnv:
     def step_policy(self, actions: torch.Tensor, t: int, policy, actions_out: torch.Tensor, shaped_out=None, sum_r_out=None,
                     collision_out=None, global_reward_avg: bool = True, want_chobs: bool = False, clock=None,
                     seed_offset: Optional[int] = None, mode: Optional[int] = None, slots: int = 1, vel_seed: int = 0,
-                    want_obs: bool = True):
+                    want_obs: bool = True, stuck_penalty: Optional[tuple] = None):
         """One slot of a policy-only rollout as ONE launch (`diral_env_step_policy`): env step (state, reward, done,
         optionally the channel observation) + the driver's reward shaping (main_test.py:171-206 without the
         information-age terms) + the SPS agents' decisions for the next slot (algorithms/v2x_sps.py:76-104), the
@@ -329,6 +329,10 @@ class VecV2VEnv:
         whatever `want_chobs` says).  `clock`: a rollout.SlotClock / int64 device tensor added to the policy's seed
         (`step_from_chobs_clocked` semantics, `seed_offset` as its `offset`); without it the policy's own step counter
         advances as in `step_from_chobs`.
+
+        `stuck_penalty` = (threshold, value, counter, prev_actions): the driver's penalty for an agent that repeats an
+        unsuccessful action more than `threshold` times (main_test.py:194-203; `counter`, `prev_actions` [B, N] int32,
+        updated in place - diral_driver_shape's flag bit 2); needs `shaped_out`.
 
         `slots` = K > 1: K slots in ONE launch, the env kept on the chip from slot to slot (include/diral_env.h,
         DiralSlotPolicy::slots): `actions` are slot t's, the policy decides the later ones; obs / reward / done / the channel
@@ -371,6 +375,18 @@ class VecV2VEnv:
         q = DiralSlotPolicy()
         q.struct_bytes = ctypes.sizeof(DiralSlotPolicy)
         q.shape_flags = 1 if global_reward_avg else 0
+        if stuck_penalty is not None:
+            thr, val, cnt, prev = stuck_penalty
+            for name, a in (("counter", cnt), ("prev_actions", prev)):
+                if not isinstance(a, torch.Tensor) or a.dtype != torch.int32 or tuple(a.shape) != (self.B, self.N) \
+                        or not a.is_contiguous() or a.device != self.device:
+                    raise ValueError("step_policy: stuck_penalty %s must be a contiguous int32 tensor [%d, %d] on %s" %
+                                     (name, self.B, self.N, self.device))
+            if shaped_out is None:
+                raise ValueError("step_policy: stuck_penalty needs shaped_out")
+            q.shape_flags |= 4
+            q.pen_threshold, q.pen_value = int(thr), float(val)
+            q.pen_counter, q.pen_prev_actions = _ptr(cnt), _ptr(prev)
         q.shaped_out = _ptr(shaped_out); q.sum_r_out = _ptr(sum_r_out); q.collision_out = _ptr(collision_out)
         q.sps_prev_action = _ptr(policy.prev_action); q.sps_counter = _ptr(policy.counter)
         q.rssi_threshold, q.inc_db, q.keep_prob = policy.threshold, policy.inc_db, policy.keep_prob
@@ -379,13 +395,10 @@ class VecV2VEnv:
             q.seed = (int(policy.seed) * 1000003 + int(seed_offset or 0)) & (2**64 - 1)
             q.seed_clock = _ptr(ct)
         else:
-            policy._t += 1
-            q.seed = (int(policy.seed) * 1000003 + policy._t) & (2**64 - 1)
+            q.seed = (int(policy.seed) * 1000003 + policy._t + 1) & (2**64 - 1)
         q.actions_out = _ptr(actions_out)
         q.slots = K
         q.vel_seed = int(vel_seed) & (2**64 - 1)
-        if K > 1 and clock is None:
-            policy._t += K - 1                                   # slot k draws with seed + k: what K one-slot calls would be given
         use_chobs = self._chobs if (want_chobs or not fusable) else None
 
         def call(chobs):
@@ -399,8 +412,13 @@ class VecV2VEnv:
                 slot["chobs"] = torch.zeros((self.B, self.N, self.CW), dtype=self.out_dtype, device=self.device)
             self._chobs = slot["chobs"]
             st = call(self._chobs)
+        if st != OK and self.io_ring > 1:
+            self._ri = (self._ri - 1) % self.io_ring            # nothing was launched: the ring slot is not consumed either
         self._ok(st, "diral_env_step_policy")
-        self._keep_policy = (q, actions, actions_out, shaped_out, sum_r_out, collision_out, clock)
+        if clock is None:
+            policy._t += K        # only once the call is in: slot k drew with seed + k, what K one-slot calls are given; a
+                                  # refused call (DIRAL_ERR_UNSUPPORTED: nothing launched) leaves the draw counter alone
+        self._keep_policy = (q, actions, actions_out, shaped_out, sum_r_out, collision_out, clock, stuck_penalty)
         return self._obs, self._rew, self._done
 
     def step(self, actions, t: Optional[int] = None, episode: float = 0.0, epsilon: float = 1.0

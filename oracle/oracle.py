@@ -16,7 +16,11 @@ from diral_amd.config import DiralCfg, EnvConfig, M_COLUMNS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libdiral_oracle.so")
+_NATIVE_PATH = os.path.join(_HERE, "libdiral_oracle_native.so")
+NATIVE_FLAGS = "-O3 -march=native -fPIC -ffp-contract=off -fno-fast-math -std=c11 -fopenmp"
+CHECKER_FLAGS = "-O2 -fPIC -ffp-contract=off -fno-fast-math -std=c11 -fopenmp"
 _lib = None
+_native = None
 
 SQ_POW = 0    # reference-faithful: v**2 == libm pow(v, 2.0)
 SQ_IEEE = 1   # v*v, what the HIP kernels compute
@@ -33,12 +37,27 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-def _load():
-    global _lib
+def build_native() -> str:
+    """The -O3 -march=native build of the same source (oracle/Makefile): what bench.py's `cpu_baseline` leg times
+    (BASELINE.md section 4).  -march=native: always recompiled on the box it runs on."""
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libdiral_oracle_native.so"], stdout=subprocess.DEVNULL)
+    return _NATIVE_PATH
+
+
+def _load(native: bool = False):
+    global _lib, _native
+    if native:
+        if _native is None:
+            _native = _bind(ctypes.CDLL(build_native()))
+        return _native
     if _lib is not None:
         return _lib
     build()
-    lib = ctypes.CDLL(_LIB_PATH)
+    _lib = _bind(ctypes.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(lib):
     P = ctypes.c_void_p
     lib.oracle_create.restype = P
     lib.oracle_create.argtypes = [ctypes.POINTER(DiralCfg), ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -58,7 +77,6 @@ def _load():
     lib.oracle_state_space.argtypes = [ctypes.POINTER(DiralCfg)]
     lib.oracle_state_space.restype = ctypes.c_int
     lib.oracle_has_openmp.restype = ctypes.c_int
-    _lib = lib
     return lib
 
 
@@ -69,8 +87,8 @@ def _p(a: Optional[np.ndarray]):
 class Oracle:
     """B independent reference-faithful envs on the CPU."""
 
-    def __init__(self, cfg: EnvConfig, batch: int = 1, sq_mode: int = SQ_POW, threads: int = 1):
-        self.lib = _load()
+    def __init__(self, cfg: EnvConfig, batch: int = 1, sq_mode: int = SQ_POW, threads: int = 1, native: bool = False):
+        self.lib = _load(native)                # native: the -O3 -march=native build (bench.py's timed CPU leg only)
         self.cfg = cfg
         self.ccfg = cfg.to_c()
         self.B, self.N, self.A = batch, cfg.num_users, cfg.num_channels

@@ -2091,3 +2091,104 @@ def test_k_slots_in_one_launch_equal_k_one_slot_launches(vary, K, t0, want_obs):
         assert not torch.equal(sa["vel"], torch.full_like(sa["vel"], 1.7))      # an episode ended inside the launches
     e1.check()
     e2.check()
+
+
+@pytest.mark.parametrize("case", ["rich_vel", "rich_vel_last_ends", "f64_chobs", "stuck_penalty", "prop_fair", "slot_clock",
+                                  "sorted_distances"])
+def test_k_slots_in_one_launch_on_the_other_code_paths_of_the_slot_loop(case):
+    """The K-slot kernel's separate code beside the plain float32 state: the RICH output tail (add_position / add_reward /
+    add_index / add_velocity - with mobility_vary the velocity column must show the velocities update_velocity left
+    INSIDE the launch, also when the last slot itself ends an episode -, the channel observation written out), float64
+    outputs, the stuck-action penalty (pen_counter / pen_prev_actions read-modify-written every slot), the
+    proportional-fair counters, the device slot clock, and the secondary observation launch behind a K-slot step - each
+    against K one-slot calls, bit for bit."""
+    from diral_amd.config import KERNEL_POLICY
+    from diral_amd.rollout import SlotClock
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    N, A, B = 64, 32, 48
+    kw, dt, K, t0, vary = {}, torch.float32, 6, 21, False
+    if case in ("rich_vel", "rich_vel_last_ends"):
+        vary = True
+        kw = dict(State=dict(add_velocity=True, add_reward=True, add_position=True, add_index=True, add_channel_obs=True))
+        K, t0 = (6, 21) if case == "rich_vel" else (4, 21)        # episode ends at t = 24: inside the launch / its last slot
+    elif case == "f64_chobs":
+        dt, kw = torch.float64, dict(State=dict(add_channel_obs=True))
+    elif case == "prop_fair":
+        kw = dict(proportional_fair=True)
+    elif case == "sorted_distances":
+        kw = dict(State=dict(add_positional_dist=True))
+    cfg = bench_config(N, A, 30.0 * N + 100, reward_design=2, mobility_vary=vary, **kw)
+    vel_seed = 4242
+    want_chobs = case in ("f64_chobs", "rich_vel")
+    runs = []
+    for fused_k in (False, True):
+        env = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=dt)
+        env.reset_topology(seed=13)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=9)
+        pol.keep_prob = 0.95 if case in ("stuck_penalty", "prop_fair") else 0.8
+        clock = SlotClock("cuda:0", 0) if case == "slot_clock" else None
+        if clock is not None:
+            env.set_clock(clock.t)
+        pen = None
+        if case == "stuck_penalty":
+            pen = (2, -10.0, torch.zeros((B, N), dtype=torch.int32, device="cuda:0"),
+                   torch.full((B, N), -1, dtype=torch.int32, device="cuda:0"))
+        a = pol.prev_action.clone()
+        nxt = torch.empty_like(a)
+        t = 0
+
+        def one(sh=None, sr=None, co=None):
+            nonlocal a, nxt, t
+            # (with a device clock the by-value slot number is an offset: 0)
+            env.step_policy(a, 0 if clock is not None else t, pol, nxt, shaped_out=sh, sum_r_out=sr, collision_out=co,
+                            clock=clock, seed_offset=0, want_chobs=want_chobs, stuck_penalty=pen if sh is not None else None)
+            if vary and t % cfg.episode_interval == cfg.episode_interval - 1:
+                env.update_velocity(seed=vel_seed + t // cfg.episode_interval)
+            if clock is not None:
+                env.lib.diral_clock_add(clock.ptr(), 1, env._stream())
+            a, nxt = nxt, a
+            t += 1
+        sh0 = torch.zeros((B, N), dtype=dt, device="cuda:0")
+        for _ in range(t0):
+            one(sh0 if pen else None)
+        outs = []
+        for rep in range(2):
+            sh = torch.zeros((K, B, N), dtype=dt, device="cuda:0")
+            sr = torch.zeros((K, B), dtype=dt, device="cuda:0")
+            co = torch.zeros((K, B), dtype=dt, device="cuda:0")
+            if fused_k:
+                env.step_policy(a, 0 if clock is not None else t, pol, nxt, shaped_out=sh, sum_r_out=sr, collision_out=co, slots=K,
+                                vel_seed=vel_seed, clock=clock, seed_offset=0, want_chobs=want_chobs, stuck_penalty=pen)
+                assert env.last_kernel() & KERNEL_POLICY
+                if clock is not None:
+                    env.lib.diral_clock_add(clock.ptr(), K, env._stream())
+                a, nxt = nxt, a
+                t += K
+            else:
+                for k in range(K):
+                    one(sh[k], sr[k], co[k])
+            outs.append((sh, sr, co, env._obs.clone(), env._rew.clone(), env._done.clone(), a.clone(),
+                         env._chobs.clone() if want_chobs else None))
+        torch.cuda.synchronize()
+        runs.append((env, pol, outs, pen))
+    (e1, p1, o1, pen1), (e2, p2, o2, pen2) = runs
+    for rep in range(2):
+        for i, name in enumerate(("shaped", "sum_r", "collisions", "state", "reward", "done", "actions")):
+            assert torch.equal(o1[rep][i], o2[rep][i]), (rep, name, (o1[rep][i] != o2[rep][i]).nonzero()[:4])
+        if want_chobs:
+            assert torch.equal(o1[rep][7], o2[rep][7]), rep
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.equal(p1.counter, p2.counter)
+    sa, sb = e1.export_state(), e2.export_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(e1.metrics(), e2.metrics())
+    if pen1 is not None:
+        assert torch.equal(pen1[2], pen2[2]) and torch.equal(pen1[3], pen2[3]) and int(pen1[2].max()) > 2
+        assert float((o1[1][0] == -10.0 + o1[1][1][:, :, None] / N).sum()) > 0           # the penalty branch ran
+    if vary:
+        vcol = cfg.state_space - 1                                                   # add_velocity: the last column
+        assert torch.equal(o1[1][3][:, :, vcol].double(), sa["vel"].to(o1[1][3].dtype).double()) or case == "rich_vel_last_ends"
+        assert not torch.equal(sa["vel"], torch.full_like(sa["vel"], 1.7))
+    e1.check()
+    e2.check()

@@ -253,20 +253,26 @@ def test_byte_models_of_the_roofline_bookkeeping():
     from diral_amd.roofline import (algorithmic_bytes_per_env_slot as alg, layout_bytes_per_env_slot as lay,
                                     packed_table)
     assert alg(64, 32, 52) == 155136 and alg(256, 64, 84) == 2258944 and alg(128, 64, 84) == 605184
-    assert packed_table(64) and packed_table(256) and packed_table(128)
+    # the form a handle takes by density (csrc/diral_env.hip use_packed_table): BASELINE configs[1], [2], [4] packed,
+    # sparse highways at N > 64 on the (seq, age) plane
+    assert packed_table(64, 250, 2000) and packed_table(256, 250, 4000) and packed_table(128, 250, 4000)
+    assert packed_table(64, 10, 9000) and not packed_table(128, 250, 5000) and not packed_table(256, 250, 8000)
+    with pytest.raises(TypeError):
+        lay(128, 64, 84, False)                    # the form is the caller's to state
     # entries read + written, ring rows read + one stamp written (+ own sequence numbers r/w), per-vehicle arrays,
     # reward, state (+ channel observation)
-    assert lay(64, 32, 52, False) == 2 * 2 * 64 * 64 + 80 * 64 + 36 * 64 + 4 * 64 + 4 * 64 * 52
-    assert lay(64, 32, 52, True) - lay(64, 32, 52, False) == 4 * 64 * 32
+    assert lay(64, 32, 52, False, packed=True) == 2 * 2 * 64 * 64 + 80 * 64 + 36 * 64 + 4 * 64 + 4 * 64 * 52
+    assert lay(64, 32, 52, True, packed=True) - lay(64, 32, 52, False, packed=True) == 4 * 64 * 32
     assert lay(128, 64, 84, False, packed=False) == 2 * 4 * 128 * 128 + 72 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
-    assert lay(128, 64, 84, False) == 2 * 2 * 128 * 128 + 80 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
-    assert lay(256, 64, 84, False) == 2 * 2 * 256 * 256 + 80 * 256 + 36 * 256 + 4 * 256 + 4 * 256 * 84
-    assert 5 * lay(256, 64, 84, False) < alg(256, 64, 84)
+    assert lay(128, 64, 84, False, packed=True) == 2 * 2 * 128 * 128 + 80 * 128 + 36 * 128 + 4 * 128 + 4 * 128 * 84
+    assert lay(256, 64, 84, False, packed=True) == 2 * 2 * 256 * 256 + 80 * 256 + 36 * 256 + 4 * 256 + 4 * 256 * 84
+    assert 5 * lay(256, 64, 84, False, packed=True) < alg(256, 64, 84)
     # where a launch's reads can come from (`roofline.memory`): the state C2's 4096 envs re-read every launch fits the
     # 256 MiB Infinity Cache (the counters then see fabric bytes), the C4 shard's and C3's do not
     from diral_amd.roofline import INFINITY_CACHE_BYTES, memory_level, resident_bytes_per_env
-    assert resident_bytes_per_env(64) == 2 * 64 * 64 + 64 * 64 + 4 * 64 + 28 * 64
-    m2, m4, m3 = memory_level(64, 32, 52, 4096, True), memory_level(64, 32, 52, 32768, True), memory_level(256, 64, 84, 8192, True)
+    assert resident_bytes_per_env(64, packed=True) == 2 * 64 * 64 + 64 * 64 + 4 * 64 + 28 * 64
+    m2, m4, m3 = (memory_level(64, 32, 52, 4096, True, packed=True), memory_level(64, 32, 52, 32768, True, packed=True),
+                  memory_level(256, 64, 84, 8192, True, packed=True))
     assert m2["resident_bytes"] < INFINITY_CACHE_BYTES < m4["resident_bytes"] < m3["resident_bytes"]
     assert m2["reads_served_by"].startswith("infinity cache") and m4["reads_served_by"].startswith("hbm")
     assert m2["output_bytes"] == 4096 * (4 * 64 + 4 * 64 * 52 + 4 * 64 * 32)
