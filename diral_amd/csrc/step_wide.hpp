@@ -298,6 +298,16 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_FLAG_UNROLL
 #define DIRAL_WIDE_FLAG_UNROLL 1         // column loops of a flagged pass's unpack / repack stages (4 - the four loads of a word in flight together - measured C5 + 4 %: registers)
 #endif
+#ifndef DIRAL_WIDE_P4V2
+#define DIRAL_WIDE_P4V2 1                // the output tail: channel observation written by each wave right behind its P3 (branch-free, the LDS reads of a
+                                         // piece in flight together), neighbour counts + 1 / n per WAVE for the rows it writes (one barrier less, no table load)
+#endif
+#ifndef DIRAL_WIDE_FIN_FMA
+#define DIRAL_WIDE_FIN_FMA 1             // packed form's finalize: the fixed-point bin as one v_fma_f64 per entry, the histogram word from its bits
+#endif
+#ifndef DIRAL_WIDE_FIN_UNROLL
+#define DIRAL_WIDE_FIN_UNROLL 0          // packed form's finalize: the quad loop of a viewer slot unrolled (static indices instead of rotating the words)
+#endif
 #ifndef DIRAL_WIDE_MINWAVES2P
 #define DIRAL_WIDE_MINWAVES2P 6          // N <= 128, packed form: 84 VGPRs, three workgroups per CU (43 KB of LDS each)
 #endif
@@ -568,7 +578,8 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       if constexpr (PACKED) {
         // the row is ready (a wave's LDS operations execute in order: whoever sees the flag sees the row)
         wave_lds_order();
-        if (lane == 0) reinterpret_cast<volatile unsigned int*>(smem + kClFlag)[i] = 1u;
+        // (through an LDS-address-space pointer: the generic one compiled to flat_store + s_waitcnt vmcnt(0) per resource)
+        if (lane == 0) *(volatile __attribute__((address_space(3))) unsigned int*)(size_t)(lds_addr(smem) + kClFlag + 4u * (unsigned int)i) = 1u;
       }
       if (CH || (EXTRA && p.prr)) {
         if (c > 1) {
@@ -1013,9 +1024,83 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     for (int j = 0; j < VPL; ++j)
       if (mycnt[j]) atomicAdd(&s_cnt[lane + 64 * j], mycnt[j]);
   }
+  // `obs[user][i]` of the reference step (test_env.py:143, 206, 228, 240), rebuilt from the gather sources P1 left in LDS.
+  // It depends on nothing behind P1: every wave writes its share right behind its own P3, in front of the barrier that
+  // waits for the slowest one.  16 bytes per lane, consecutive lanes on consecutive pieces of a row; branch-free - the
+  // gather-source words of a piece's resources in flight together, then the sources' positions (the divergent form
+  // paid two dependent LDS round trips per VALUE); the distance is |dx| outright when the env's positions allow it
+  // (p1_fast: decided once per env, as in P1).
+  bool chobs_done = false;
+  if constexpr (RICH && DIRAL_WIDE_P4V2) {
+    const LateRichArgs lr0 = (LateRichArgs)(late_kernarg_base() + kRichArgOffset);
+    void* const chobs_out0 = lr0->chobs_out;
+    constexpr int CV = OUT64 ? 2 : 4;
+    if (chobs_out0 && (A % CV) == 0) {
+      typedef typename std::conditional<OUT64, double, float>::type out_t;
+      const bool dist_obs = !CH && !(EXTRA && p.design) && lr0->state_type == 2;
+      out_t* const co = static_cast<out_t*>(chobs_out0) + bN * A;
+      const int qpr = A / CV, total = N * qpr;
+      const int du = THREADS / qpr, dq = THREADS - du * qpr;
+      auto run = [&](auto fast_tag) {
+        constexpr bool ABS = decltype(fast_tag)::value;
+        int u = tid / qpr, qr = tid - u * qpr;
+        for (int q = tid; q < total; q += THREADS) {
+          const int i0 = qr * CV;
+          const int a = s_act[u];
+          const double xu = s_px[u];
+          const unsigned int tx_bits = (unsigned int)(actw >> i0);
+          const unsigned int sh = 8u * (unsigned int)(u >> 6);
+          const mword_t* const mrow = s_mtab + (u & 63) + i0 * MT;
+          unsigned int srcv[CV];
+#pragma unroll
+          for (int d = 0; d < CV; ++d) srcv[d] = (unsigned int)mrow[d * MT];
+          double xv[CV];
+#pragma unroll
+          for (int d = 0; d < CV; ++d) { srcv[d] = (srcv[d] >> sh) & 255u; xv[d] = s_px[srcv[d]]; }
+          out_t o[CV];
+#pragma unroll
+          for (int d = 0; d < CV; ++d) {
+            double dd;
+            if constexpr (ABS) dd = __builtin_fabs(xu - xv[d]);
+            else dd = fast_dist<true>(xv[d], 0.0, xu, 0.0);
+            double val = dist_obs ? ((int)srcv[d] == u ? 100000.0 : dd) : 1.0;                 // network.py:385
+            if (a == i0 + d || ((tx_bits >> d) & 1u) == 0u) val = 0.0;
+            o[d] = (out_t)val;
+          }
+          if constexpr (OUT64) stream_store2(co + 2 * q, make_double2(o[0], o[1]));
+          else stream_store4(co + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+          u += du; qr += dq;
+          if (qr >= qpr) { qr -= qpr; u += 1; }
+        }
+      };
+      if (p1_fast) run(std::true_type{});
+      else run(std::false_type{});
+      chobs_done = true;
+    }
+  }
   __syncthreads();
   // neighbours counted per viewer (network.py:497-501 `count`) = the row sum of its histogram
-  if constexpr (!REGCNT) {
+  // P4V2: where the plain state writer runs, every wave counts the NPAD / WAVES viewers whose rows it writes itself and
+  // leaves count and 1 / n (one IEEE division: the value the host's table holds) in LDS for its own lanes - no second
+  // barrier, no table load whose s_waitcnt vmcnt would wait for the streaming stores in front of it
+  constexpr int RPW = NPAD / WAVES;              // state rows a wave writes
+  bool rows_by_wave = false;
+  if constexpr (!REGCNT && DIRAL_WIDE_P4V2) {
+    bool plain_writer = true;
+    if constexpr (RICH) plain_writer = ((LateRichArgs)(late_kernarg_base() + kRichArgOffset))->plain_state != 0;
+    rows_by_wave = plain_writer && ((LateFastArgs)late_kernarg_base())->state_out != nullptr;
+    if (rows_by_wave) {
+      if (lane < RPW) {
+        const int u = wave * RPW + lane;
+        unsigned int n = 0u;
+        for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[u * KP + q]; n += (w & 0xffffu) + (w >> 16); }
+        s_cnt[u] = n;
+        if constexpr (!OUT64) reinterpret_cast<double*>(smem + lay.scratch)[u] = n ? 1.0 / (double)n : 0.0;
+      }
+      wave_lds_order();
+    }
+  }
+  if (!REGCNT && !rows_by_wave) {
     if (tid < NPAD) {
       unsigned int n = 0u;
       for (int q = 0; q < (K + 1) / 2; ++q) { const unsigned int w = s_hist[tid * KP + q]; n += (w & 0xffffu) + (w >> 16); }
@@ -1079,7 +1164,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       return fast_dist<true>(s_px[src], 0.0, xu, 0.0);
     };
     auto chv = [&](int u, int i) -> double { return chv_row(u, s_act[u], s_px[u], i); };
-    if (rr.chobs_out) {
+    if (rr.chobs_out && !chobs_done) {
       // 16 bytes per lane, consecutive lanes on consecutive pieces of a row; the per-row values
       // (action, position) are loaded once per piece
       constexpr int CV = OUT64 ? 2 : 4;
@@ -1140,14 +1225,19 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     if (!(state_out && rr.plain_state)) { DIRAL_WSTAMP(7); return; }
   }
   const int S = A + K;
+  // who writes which rows: all threads interleaved over the env's rows, or (rows_by_wave) each wave the RPW rows it counted
+  const int T4 = rows_by_wave ? 64 : THREADS, t4 = rows_by_wave ? lane : tid;
+  const int row0 = rows_by_wave ? wave * RPW : 0;
+  const int row1 = rows_by_wave ? (row0 + RPW < N ? row0 + RPW : N) : N;
   if constexpr (OUT64) {
     double* out = static_cast<double*>(state_out) + bN * S;
     if (((A | K) & 1) == 0) {
-      const int q_per_row = S >> 1, total = N * q_per_row;
+      const int q_per_row = S >> 1, total = row1 * q_per_row;
       // (row, piece) advance incrementally: one integer division per thread instead of one per store
-      const int du = THREADS / q_per_row, dq = THREADS - du * q_per_row;
-      int u = tid / q_per_row, qr = tid - u * q_per_row;
-      for (int q = tid; q < total; q += THREADS, u += du, qr += dq) {
+      const int du = T4 / q_per_row, dq = T4 - du * q_per_row;
+      int u = t4 / q_per_row, qr = t4 - u * q_per_row;
+      u += row0;
+      for (int q = row0 * q_per_row + t4; q < total; q += T4, u += du, qr += dq) {
         if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
         const int s0 = qr << 1;
         double2 v;
@@ -1163,7 +1253,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
         reinterpret_cast<double2*>(out)[q] = v;
       }
     } else {
-      for (int e = tid; e < N * S; e += THREADS) {
+      for (int e = row0 * S + t4; e < row1 * S; e += T4) {
         const int u = e / S, s = e - u * S;
         double val;
         if (s < A) val = (s_act[u] == s) ? 1.0 : 0.0;
@@ -1178,10 +1268,11 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     float* out = static_cast<float*>(state_out) + bN * S;
     const double* const inv_tab = lp->inv_tab;
     if (((A | K) & 3) == 0) {
-      const int q_per_row = S >> 2, total = N * q_per_row;
-      const int du = THREADS / q_per_row, dq = THREADS - du * q_per_row;
-      int u = tid / q_per_row, qr = tid - u * q_per_row;
-      for (int q = tid; q < total; q += THREADS, u += du, qr += dq) {
+      const int q_per_row = S >> 2, total = row1 * q_per_row;
+      const int du = T4 / q_per_row, dq = T4 - du * q_per_row;
+      int u = t4 / q_per_row, qr = t4 - u * q_per_row;
+      u += row0;
+      for (int q = row0 * q_per_row + t4; q < total; q += T4, u += du, qr += dq) {
         if (qr >= q_per_row) { qr -= q_per_row; u += 1; }
         const int s0 = qr << 2;
         float4 v;
@@ -1200,7 +1291,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
         reinterpret_cast<float4*>(out)[q] = v;
       }
     } else {
-      for (int e = tid; e < N * S; e += THREADS) {
+      for (int e = row0 * S + t4; e < row1 * S; e += T4) {
         const int u = e / S, s = e - u * S;
         float val;
         if (s < A) val = (s_act[u] == s) ? 1.f : 0.f;
