@@ -298,6 +298,12 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #ifndef DIRAL_WIDE_FLAG_UNROLL
 #define DIRAL_WIDE_FLAG_UNROLL 1         // column loops of a flagged pass's unpack / repack stages (4 - the four loads of a word in flight together - measured C5 + 4 %: registers)
 #endif
+#ifndef DIRAL_WIDE_EARLY_P3
+#define DIRAL_WIDE_EARLY_P3 0            // packed form, my_step: 1 = the P1 waves run P3's prologue + the A operand of pass 0 in front of the P1 barrier;
+                                         // 2 = the two walking waves too, before their walk.  Measured on C3 (one box, interleaved): 0: 1.247 ms,
+                                         // 1: 1.290, 2: 1.242 - the work costs in front of the barrier what it saves behind it (the kernel is paced
+                                         // by the instructions it issues, not by who waits where): off
+#endif
 #ifndef DIRAL_WIDE_P4V2
 #define DIRAL_WIDE_P4V2 1                // the output tail: channel observation written by each wave right behind its P3 (branch-free, the LDS reads of a
                                          // piece in flight together), neighbour counts + 1 / n per WAVE for the rows it writes (one barrier less, no table load)
@@ -472,6 +478,130 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
 #pragma unroll
   for (int j = 0; j < VPL; ++j) myact[j] = s_act[lane + 64 * j];
 
+  // ---- (PACKED) the prologue of P3 - step_wide_closure.inc - as two pieces that depend on nothing this slot computes
+  // after P0: the wave's columns (which passes are clean, fresh sequence numbers stamped, the [column][lag] -> xpos
+  // table from the ring rows, the ring stamped) and the product's A operand of a pass (the raw code words of the pass's
+  // 16 subjects over all sources, as bf16 powers of two with the stamp folded in).  DIRAL_WIDE_EARLY_P3: the P1 waves run
+  // both in front of the barrier that ends P1, where they otherwise wait for the closure walk; the two walking waves build
+  // theirs before the first rows of the gather table are ready.  (my_step without the run-time extras only: my_step_ch /
+  // the EXTRA switches park per-transmitter values in the merge scratch until P2.)
+  typedef __attribute__((ext_vector_type(4))) unsigned int cl_u32x4;
+  constexpr int CL_KS = NPAD / 32;
+  cl_u32x4 cl_a[CL_KS];
+  unsigned int cl_passbits = 0u, cl_tkov = 0u;
+  bool cl_ovf = false, cl_done = false, cl_a_ready = false;
+  auto cl_prologue = [&]() {
+    const int kbase = wave * CPW;
+    const unsigned int ul = (unsigned int)lane;
+    cl_done = true;
+    if (kbase >= NRows) return;                            // (uniform) waves past the last subject row only help with the closure
+    const LateFastArgs la = (LateFastArgs)late_kernarg_base();
+    const global_ptr<double> ringp = uniform_ptr(la->ring, 0);
+    unsigned char* const xt2 = smem + lay.scratch + wide_scratch(VPL) * wave + 64;   // [column][lag] -> xpos, 8 doubles per column
+    const size_t qrow0 = (size_t)b * (NRows >> 2) + (kbase >> 2);
+    unsigned int passbits = 0u;
+    const global_ptr<const unsigned int> tof = uniform_ptr<const unsigned int>(la->told, qrow0);
+#pragma unroll
+    for (int pch = 0; pch < CPW / PC; ++pch) {
+      unsigned int anyold = 0u;
+      if (FULL || kbase + pch * PC < NRows) anyold = tof[2 * pch] | tof[2 * pch + 1];
+      passbits |= (__builtin_amdgcn_readfirstlane((int)anyold) != 0 ? 1u : 0u) << pch;
+    }
+    const global_ptr<unsigned int> tsrow = uniform_ptr(la->tseq, bR + kbase);
+    const bool cv = ul < (unsigned int)CPW && (FULL || kbase + (int)ul < NRows);
+    const unsigned int ts = tsrow[cv ? ul : 0u];
+    const unsigned int tkov = cv ? ts + 1u : 0u;
+    if (cv && ((passbits >> (ul >> 3)) & 1u) == 0u) tsrow[ul] = tkov;      // (flagged passes stamp their own)
+    cl_ovf = cv && tkov >= (1u << 24) - 1u;
+#pragma unroll
+    for (int i = 0; i < CPW / 8; ++i) {
+      const unsigned int c = 8u * i + (ul >> 3), lag = ul & 7u;
+      const int k = kbase + (int)c;
+      const bool kvalid = FULL || k < N;
+      const bool krow = FULL || k < NRows;
+      const unsigned int tkc = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)tkov);
+      const double rg = ringp[(size_t)(bR + (krow ? k : kbase)) * 8 + ((tkc - lag) & 7u)];
+      const double pxk = s_px[kvalid ? k : 0];
+      // lag 0 is this slot's stamp (vehicle.py:61-63: the pre-move position under the fresh number)
+      reinterpret_cast<double*>(xt2)[c * 8u + lag] = (lag == 0u) ? pxk : rg;
+      if (lag == 0u && kvalid && ((passbits >> i) & 1u) == 0u) ringp[(size_t)(bR + k) * 8 + (tkc & 7u)] = pxk;
+    }
+    cl_passbits = passbits;
+    cl_tkov = tkov;
+  };
+  auto cl_build_a = [&](int pass) {
+    const int kbase = wave * CPW;
+    const int c16 = lane & 15, g4 = lane >> 4;             // product: lane = (subject or viewer of the tile, K group)
+    const int NQ = NRows >> 2;
+    const int kk = kbase + 16 * pass + c16;                        // this lane's subject (row of the product)
+    const int qa = (kk >> 2) < NQ ? (kk >> 2) : NQ - 1;            // (rows past the table: any row, never used)
+    const unsigned int sh = 8u * (unsigned int)(kk & 3);
+    const global_ptr<const unsigned int> trow0 =
+        uniform_ptr<const unsigned int>(((LateFastArgs)late_kernarg_base())->tcode, (size_t)b * NQ * NV);
+    const unsigned int off0 = (unsigned int)qa * (unsigned int)NV + 8u * (unsigned int)g4;
+    // sources 32 s + 8 g + (0 .. 7): eight consecutive words of the subject's quad row (a row shorter than 256
+    // viewers: the words behind it, inside the allocation - their P bits are 0).  Four K steps = eight 16-byte loads
+    // in flight at a time
+    typedef const __attribute__((address_space(1))) cl_u32x4* gv4;
+#pragma unroll
+    for (int s0 = 0; s0 < CL_KS; s0 += 4) {
+      cl_u32x4 w[8];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        w[2 * s] = *(gv4)(trow0 + off0 + 32u * (s0 + s));
+        w[2 * s + 1] = *(gv4)(trow0 + off0 + 32u * (s0 + s) + 4u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        // Vehicle.periodic_update folded in: every lag + 1 = the code shifted, its popcount that of (raw & 0x7f)
+        auto bf = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+          return ((unsigned int)__popc((lo >> sh) & 0x7fu) << 11) | ((unsigned int)__popc((hi >> sh) & 0x7fu) << 27);
+        };
+        const cl_u32x4 w0 = w[2 * s], w1 = w[2 * s + 1];
+        cl_a[s0 + s][0] = bf(w0.x, w0.y); cl_a[s0 + s][1] = bf(w0.z, w0.w); cl_a[s0 + s][2] = bf(w1.x, w1.y); cl_a[s0 + s][3] = bf(w1.z, w1.w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the own entry of the subject (source == subject): lag 0.  Subject kbase + 16 pass + c: K step (kbase + 16 pass) / 32,
+    // lane group ((kbase + 16 pass) / 8) % 4 + (c >> 3), element c & 7 - a switch over the K step (static register indices)
+    const int kk0 = kbase + 16 * pass;
+    unsigned int om[4];
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi)
+      om[vi] = (g4 == ((kk0 >> 3) & 3) + (c16 >> 3) && ((c16 & 7) >> 1) == vi) ? (0xffffu << (16 * (c16 & 1))) : 0u;
+    auto fix_own = [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
+#pragma unroll
+      for (int vi = 0; vi < 4; ++vi) cl_a[W][vi] = (cl_a[W][vi] & ~om[vi]) | (0x40004000u & om[vi]);
+    };
+    if constexpr (CL_KS == 8) {
+      switch (kk0 >> 5) {
+        case 0: fix_own(std::integral_constant<int, 0>{}); break;
+        case 1: fix_own(std::integral_constant<int, 1>{}); break;
+        case 2: fix_own(std::integral_constant<int, 2>{}); break;
+        case 3: fix_own(std::integral_constant<int, 3>{}); break;
+        case 4: fix_own(std::integral_constant<int, 4>{}); break;
+        case 5: fix_own(std::integral_constant<int, 5>{}); break;
+        case 6: fix_own(std::integral_constant<int, 6>{}); break;
+        default: fix_own(std::integral_constant<int, 7>{}); break;
+      }
+    } else {
+      switch (kk0 >> 5) {
+        case 0: fix_own(std::integral_constant<int, 0>{}); break;
+        case 1: fix_own(std::integral_constant<int, 1>{}); break;
+        case 2: fix_own(std::integral_constant<int, 2>{}); break;
+        default: fix_own(std::integral_constant<int, 3>{}); break;
+      }
+    }
+  };
+  constexpr bool CL_EARLY = PACKED && !CH && !EXTRA && DIRAL_WIDE_EARLY_P3 != 0;
+  auto cl_early = [&]() {
+    if (lds_addr(smem) != 0u) return;                       // (the scratch carve below assumes what the P3 code checks)
+    cl_prologue();
+    if (wave * CPW < NRows && (FULL || wave * CPW < NRows)) { cl_build_a(0); cl_a_ready = true; }
+  };
+
   // ---- P1: per owned resource: transmitter set, closest in-range transmitter
   // per viewer (network.py:378-398: ascending id, strict '<'), gather sources,
   // collision reward --------------------------------------------------------------
@@ -626,6 +756,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       }
     }
   }
+  if constexpr (CL_EARLY) {
+    if (wave < P1W) cl_early();                              // (the P1 waves: in front of the barrier, beside the closure walk)
+  }
   if constexpr (PACKED) {
     // ---- the reachability closure of the slot (step_wide_closure.inc: final = P . stamped, P = (I + E_A) ... (I + E_1)),
     //      walked ONCE per env, BESIDE P1: waves 6 and 7 - 128 source bits each, rows of P in LDS, gather the source's 16
@@ -653,6 +786,9 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
         reinterpret_cast<rowv_t*>(rows)[u] = id;
       }
       wave_lds_order();
+#if DIRAL_WIDE_EARLY_P3 >= 2
+      if constexpr (CL_EARLY) cl_early();                     // (the walking waves: before the first rows of the gather table are ready)
+#endif
       const volatile unsigned int* const flag = reinterpret_cast<const volatile unsigned int*>(smem + kClFlag);
       // (the flag and the row of step i + 1 are requested in front of step i's gathers - flag first: in-order LDS queue, a
       // set flag vouches for the row read behind it - so that a walk that lags the P1 waves pays no LDS round trip per
