@@ -239,6 +239,21 @@ def csrc_digest() -> str:
     return source_digest()
 
 
+def issue_roofline(pmc, kernel_ms):
+    pw = (pmc or {}).get("per_wave") or {}
+    if not pw.get("valu") or not pw.get("waves") or not pmc.get("clock_GHz"):
+        return None
+    insts = pw["valu"] * pw["waves"]
+    need = insts * 4.0
+    have = 256 * 4 * pmc["clock_GHz"] * 1e9 * kernel_ms * 1e-3
+    return {"pipe": "valu", "valu_insts_per_launch": insts, "cycles_per_inst": 4, "simds": 1024,
+            "needed_simd_cycles": need, "available_simd_cycles": have, "frac": need / have,
+            "floor_ms": kernel_ms * need / have,
+            "salu_insts_per_launch": pw.get("salu", 0) * pw["waves"], "lds_insts_per_launch": pw.get("lds", 0) * pw["waves"],
+            "note": "instruction counts from the committed rocprofv3 --pmc passes (pmc_current says whether they describe the "
+                    "kernels this run timed); kernel time of THIS run"}
+
+
 def roofline_object(res, pmc):
     """The `roofline` object of a measurement: what bounds the kernel and how far it is from it.
 
@@ -278,6 +293,12 @@ def roofline_object(res, pmc):
         "lds_busy": pmc.get("lds_busy") if pmc else None,
         "cu_busy": pmc.get("cu_busy") if pmc else None,
         "clock_GHz": pmc.get("clock_GHz") if pmc else None,
+        # the roofline of the pipe that bounds the kernel (`bound`): the VALU cycles its instruction mix NEEDS - vector
+        # instructions per launch (SQ_INSTS_VALU of the committed passes) x 4 cycles each (a 64-lane wave on a 16-lane SIMD;
+        # the float64 instructions of this path issue at that rate on gfx950 too) - over the SIMD-cycles the chip HAS
+        # during the kernel (256 CUs x 4 SIMDs x shader clock x kernel time of this run).  1.0 = no launch with this
+        # instruction count can be faster; floor_ms = the kernel time at which it would be 1.0
+        "issue": issue_roofline(pmc, res["kernel_ms"]),
         "pmc_source": pmc.get("source") if pmc else None,
         "pmc_commit": pmc.get("commit") if pmc else None,
         "pmc_csrc_sha": pmc.get("csrc_sha") if pmc else None,

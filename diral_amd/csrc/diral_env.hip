@@ -404,7 +404,10 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
       // constant and the fma at t <= K - with a factor of two on top; as 1 / 65536ths, rounded up, + 1
       const double w = (p.Rb - (-p.Rb)) / (double)p.K;
       const double xmax = p.L;
-      const double lost = 2.0 * (((2.0 * xmax + p.Rb) * 0x1p-24) / w + 2.0 * (double)p.K * 0x1p-23);
+      // (the kernel computes t = fma(float(xpos), float(inv_w 2^16), float((Rb - npx) inv_w 2^16)): the conversion of the
+      // stamp and of the factor lose 2 |xpos| 2^-24 / w bin widths, the addend's |Rb - npx| 2^-24 / w <= (xmax + Rb) 2^-24 / w,
+      // the fma's own rounding K 2^-24)
+      const double lost = 2.0 * (((3.0 * xmax + p.Rb) * 0x1p-24) / w + 2.0 * (double)p.K * 0x1p-23);
       const double m = std::ceil(lost * 65536.0) + 1.0;
       const bool on = use_fast64 && m <= 64.0 && xmax < 1e6 && e->f32_margin != 0;
       f.f32_m16 = on ? std::max((int)m, std::min(e->f32_margin, 16384)) : 0;

@@ -161,6 +161,9 @@ __device__ inline RichParams load_rich_args(unsigned long long kernarg_base) {
   return r;
 }
 
+#ifndef DIRAL_FAST_F32_FMA
+#define DIRAL_FAST_F32_FMA 1             // float32 screening of the bin: the own position folded into the fma's addend (one VALU instruction less per entry)
+#endif
 struct FastLds {
   uint32_t rv, edges, mask, act, hist, cnt, slow, inv, mtab, rtx, inr, px, py, npx, rew, stage, nact, kvel, total;
 };
