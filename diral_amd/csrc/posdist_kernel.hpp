@@ -418,6 +418,9 @@ __device__ inline double pd_quad_perm(double x) {
 }
 constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B, kQuadShr1 = 0x90;   // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0] [0,0,1,2]
 constexpr int kRowHalfMirror = 0x141, kRowShr1 = 0x111;                                 // lane s <-> 7 - s within a row half; lane s <- s - 1 within a row of 16
+#ifndef DIRAL_TYPE1_CUMSUM_INPLACE
+#define DIRAL_TYPE1_CUMSUM_INPLACE 1     // posdist_type1_lanes_kernel: the sequential sum by the lane whose turn it is only, one store per slot boundary
+#endif
 #ifndef DIRAL_TYPE1_MINWAVES
 #define DIRAL_TYPE1_MINWAVES 4           // posdist_type1_lanes_kernel<LPV, 32>: waves per SIMD the register allocation is held to
 #endif
@@ -646,6 +649,40 @@ __global__ __launch_bounds__(64, VL == 64 ? 2 : DIRAL_TYPE1_MINWAVES) void posdi
     const int c = est + 1 - (s < e0 ? 1 : 0) + ((est + 1 < K && !(s < e1)) ? 1 : 0);
     cpk[i >> 2] |= (uint32_t)(real ? c : K + 1) << (8 * (i & 3));
   }
+#if DIRAL_TYPE1_CUMSUM_INPLACE
+  // NumPy's cumsum in its own order (cw[j + 1] = cw[j] + sa[j], numpy/lib/_histograms_impl.py): a viewer's LPV lanes take
+  // turns, lowest ranks first, each continuing from the total the lane below ended with.  The histogram needs the running
+  // sum behind the LAST value of every slot only (searchsorted + diff): that value - and no other, and only in its lane's
+  // own pass - stores its sum; the wave used to store every value's sum in every pass (the other passes' into a spare
+  // slot: four instructions and an LDS store per value and pass).  Last of its slot = the slot number changes behind it;
+  // behind a lane's last value comes the first of the lane above (the viewer's top lane: the end of the list).
+  // (the sums are not kept: in-place updates of the values - behind a lane test or as selects - cost 172 spilled registers)
+  unsigned int chg[VL / 4];                                                // byte i != 0: value i is the last of its slot
+  {
+    const unsigned int nxt0 = (unsigned int)__builtin_amdgcn_mov_dpp((int)cpk[0], 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+    const unsigned int next_first = sub == LPV - 1 ? 0xffu : (nxt0 & 255u);
+#pragma unroll
+    for (int q = 0; q < VL / 4; ++q) {
+      const unsigned int nb = q + 1 < VL / 4 ? cpk[q + 1 < VL / 4 ? q + 1 : q] : next_first;
+      chg[q] = cpk[q] ^ ((cpk[q] >> 8) | (nb << 24));
+    }
+  }
+  double acc = 0.0;
+#pragma unroll 1
+  for (int ph = 0; ph < LPV; ++ph) {
+    const double before = pd_quad_perm<kRowShr1>(acc);                     // the running sum of the lane below, complete by now
+    const bool active = sub == ph;
+    if (active) acc = ph > 0 ? before : 0.0;
+#pragma unroll
+    for (int i = 0; i < VL; ++i) {
+      acc = acc + v[i];
+      if (active && ((chg[i >> 2] >> (8 * (i & 3))) & 255u) != 0u) {
+        const int c = (int)((cpk[i >> 2] >> (8 * (i & 3))) & 255u);
+        col[c * ST] = acc;
+      }
+    }
+  }
+#else
   double acc = 0.0;
 #pragma unroll 1
   for (int ph = 0; ph < LPV; ++ph) {
@@ -659,6 +696,7 @@ __global__ __launch_bounds__(64, VL == 64 ? 2 : DIRAL_TYPE1_MINWAVES) void posdi
       col[(active ? c : K + 1) * ST] = acc;
     }
   }
+#endif
   if (sub == 0) {
     double cur = 0.0;
     for (int j = 0; j <= K; ++j) {
