@@ -270,6 +270,97 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
   return (c == 2 && wgt == 1) ? 0.0 : -1.0;
 }
 
+// The far-entry guard of a flagged pass of the packed form at N <= 128 (step_wide_kernel, `cl_far_guard`: what it decides and
+// why that is exact).  `rows`: the closure walk's rows of P in LDS, [half][viewer] 8 bytes - sources 0 .. 63 / 64 .. 127 of
+// each viewer; `tcq`: the code words of the wave's four quads [quad][NV]; `tkw`: the env's `tkey` rows [subject][NV];
+// `flagged`: bit pch = pass pch (8 columns) is flagged.  Returns the passes whose far entries cannot move this slot.
+template <bool FULL>
+__device__ __attribute__((noinline)) unsigned int wide_far_guard(const unsigned char* rows, int npad, const unsigned int* tcq,
+                                                                 const unsigned int* tkw, int kbase, int N, int NV,
+                                                                 unsigned int flagged, int lane) {
+  constexpr int VPL = 2, PC = 8;
+  typedef __attribute__((ext_vector_type(2))) unsigned int g_u32x2;
+  const unsigned int ul = (unsigned int)lane;
+  g_u32x2 plo[VPL], phi[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    plo[j] = *reinterpret_cast<const g_u32x2*>(rows + 8u * (ul + 64u * j));
+    phi[j] = *reinterpret_cast<const g_u32x2*>(rows + 8u * (unsigned int)npad + 8u * (ul + 64u * j));
+  }
+  unsigned int stable = 0u;
+#pragma unroll 1
+  for (int pch = 0; pch < 2; ++pch) {
+    if (((flagged >> pch) & 1u) == 0u) continue;
+    bool viol = false;
+    unsigned int qfar = 0u;                     // bit w: quad w of the pass holds an entry beyond the codes (a sequence number in `tkey`)
+    unsigned int cw[2][VPL];                   // the pass's raw code words (two quads x VPL slots)
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) cw[w][j] = tcq[(unsigned int)((2 * pch + w) * NV) + ul + 64u * j];
+    // the sequence numbers of the pass's far entries, all 16 loads in flight together (a column at a time the guard paid a
+    // round trip to HBM per column: 110 k cycles for a workgroup with two flagged passes)
+    unsigned int seqa[PC][VPL];
+    bool isfa[PC][VPL];
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const int k = kbase + pch * PC + c;
+      const unsigned int* const tkrow = tkw + (size_t)(FULL || k < N ? k : kbase) * NV;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        const unsigned int u = ul + 64u * j;
+        const unsigned int rc = (cw[c >> 2][j] >> (8 * (c & 3))) & 255u;
+        // beyond the codes once this slot's stamp is taken: raw code 0 (8 or more behind, or never heard) or 0x80 (7 behind:
+        // handed over to `tkey` when it got there, vehicle.py:56-70 makes it 8 now)
+        isfa[c][j] = (rc & 0x7fu) == 0u && (FULL || (u < (unsigned int)N && k < N));
+        seqa[c][j] = tkrow[u] >> 8;              // (unconditional: a padded viewer reads inside the allocation, its value is masked)
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PC; ++c)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) seqa[c][j] = isfa[c][j] ? seqa[c][j] : 0u;
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      unsigned int seqv[VPL];
+      unsigned long long farm[VPL];
+      bool isf[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) { isf[j] = isfa[c][j]; seqv[j] = seqa[c][j]; farm[j] = __ballot(isf[j]); }
+      if ((farm[0] | farm[1]) == 0ull) continue;
+      if ((__ballot(isf[0] && seqv[0] != 0u) | __ballot(isf[1] && seqv[1] != 0u)) != 0ull) qfar |= 1u << (c >> 2);
+      unsigned long long rem[VPL];
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) rem[j] = farm[j];
+      while ((rem[0] | rem[1]) != 0ull) {          // over the distinct far numbers of the column (one, as a rule: nothing to propagate)
+        const int js = rem[0] != 0ull ? 0 : 1;
+        const unsigned int d = (unsigned int)__builtin_amdgcn_readlane((int)(js == 0 ? seqv[0] : seqv[1]), __builtin_ctzll(rem[js]));
+        unsigned long long g[VPL];
+        bool lower[VPL];
+        bool anylower = false;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          g[j] = __ballot(isf[j] && seqv[j] == d);
+          rem[j] &= ~g[j];
+          lower[j] = isf[j] && seqv[j] < d;
+          anylower = anylower || lower[j];
+        }
+        if (__ballot(anylower) == 0ull) continue;  // (uniform) nobody holds an older number than d
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const unsigned int hit = (plo[j][0] & (unsigned int)g[0]) | (plo[j][1] & (unsigned int)(g[0] >> 32)) |
+                                   (phi[j][0] & (unsigned int)g[1]) | (phi[j][1] & (unsigned int)(g[1] >> 32));
+          viol = viol || (lower[j] && hit != 0u);
+        }
+      }
+    }
+    // a stable pass: bit pch; its quads without a far entry any more (refreshed since they were flagged): bits 8 + quad -
+    // the caller takes their flags down (the coded path only ever raises them: at a hand-over)
+    if (__ballot(viol) == 0ull) stable |= (1u << pch) | ((~qfar & 3u) << (8 + 2 * pch));
+  }
+  return stable;
+}
+
 // (uniform_ptr / global_ptr: step_fast64.hpp)
 #ifdef DIRAL_TIMING
 #define DIRAL_WSTAMP(i) do { if (lane == 0 && p.dbg) p.dbg[((size_t)b * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -297,6 +388,9 @@ __device__ DIRAL_OUTLINE double wide_collision_reward(int rd, uint32_t flags, do
 #endif
 #ifndef DIRAL_WIDE_FLAG_UNROLL
 #define DIRAL_WIDE_FLAG_UNROLL 1         // column loops of a flagged pass's unpack / repack stages (4 - the four loads of a word in flight together - measured C5 + 4 %: registers)
+#endif
+#ifndef DIRAL_WIDE_FAR_GUARD
+#define DIRAL_WIDE_FAR_GUARD 1           // packed form at N <= 128: a flagged pass whose far entries provably stay put this slot runs on the coded path
 #endif
 #ifndef DIRAL_WIDE_EARLY_P3
 #define DIRAL_WIDE_EARLY_P3 0            // packed form, my_step: 1 = the P1 waves run P3's prologue + the A operand of pass 0 in front of the P1 barrier;
@@ -490,6 +584,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
   cl_u32x4 cl_a[CL_KS];
   unsigned int cl_passbits = 0u, cl_tkov = 0u;
   bool cl_ovf = false, cl_done = false, cl_a_ready = false;
+  unsigned int cl_stable = 0u;                             // bit pch: a flagged pass the guard below found stable this slot
   auto cl_prologue = [&]() {
     const int kbase = wave * CPW;
     const unsigned int ul = (unsigned int)lane;
@@ -507,6 +602,7 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
       if (FULL || kbase + pch * PC < NRows) anyold = tof[2 * pch] | tof[2 * pch + 1];
       passbits |= (__builtin_amdgcn_readfirstlane((int)anyold) != 0 ? 1u : 0u) << pch;
     }
+    passbits &= ~cl_stable;                                // (a flagged pass whose far entries cannot move this slot runs coded: cl_far_guard)
     const global_ptr<unsigned int> tsrow = uniform_ptr(la->tseq, bR + kbase);
     const bool cv = ul < (unsigned int)CPW && (FULL || kbase + (int)ul < NRows);
     const unsigned int ts = tsrow[cv ? ul : 0u];
@@ -528,6 +624,46 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
     }
     cl_passbits = passbits;
     cl_tkov = tkov;
+  };
+  // ---- (PACKED, N <= 128) the far-entry guard of a flagged pass.  A pass is flagged while one of its quads holds an entry
+  // beyond the codes (8 or more stamps behind its subject: code 0, the sequence number in `tkey`); the coded merge -
+  // closure + product - cannot carry such values, so a flagged pass used to run the 64-step chain on byte ranks
+  // (step_wide_pass.inc) at 2.5 x the cost of a coded pass.  But far values almost never MOVE: on a highway that broke into
+  // clusters, the viewers of one cluster hold stale entries about the vehicles of another, all of them the last stamp that
+  // crossed, and they hear nobody who knows better - of the flagged passes of BASELINE configs[4] 3 in 10 000 see a far
+  // value propagate in a slot (profiles/r06/far_propagation.txt: counted on the oracle).  Vehicle.received_update moves
+  // a far value into viewer v's entry about k only if some source s whose entries reach v within this slot - bit s of row
+  // v of the closure P, which the walk beside P1 has just computed for the whole env - holds a far entry about k with a
+  // HIGHER sequence number than v's own far (or never-heard) one.  The guard asks exactly that, per column, over the
+  // distinct far numbers of the column (1-2 as a rule: G = the viewers holding number d, as two ballots; a viewer below d
+  // with P[v] & G != 0 would receive it); if no column of the pass has such a pair, every entry that is far and stays
+  // uncoded keeps its number, xpos and (incremented) age, every other entry is what the coded merge makes it - the pass
+  // runs on the coded path, its quads stay flagged.  A viewer that ends the slot with a coded entry makes the test
+  // conservative, never wrong; a failed guard costs the pass its old price plus the test.
+  auto cl_far_guard = [&]() -> unsigned int {
+    if constexpr (PACKED && VPL == 2 && DIRAL_WIDE_FAR_GUARD) {
+      const int kbase = wave * CPW;
+      if (kbase >= NRows) return 0u;
+      const LateFastArgs la = (LateFastArgs)late_kernarg_base();
+      const size_t qrow0 = (size_t)b * (NRows >> 2) + (kbase >> 2);
+      const global_ptr<const unsigned int> tof = uniform_ptr<const unsigned int>(la->told, qrow0);
+      unsigned int flagged = 0u;
+#pragma unroll
+      for (int pch = 0; pch < CPW / PC; ++pch) {
+        unsigned int anyold = 0u;
+        if (FULL || kbase + pch * PC < NRows) anyold = tof[2 * pch] | tof[2 * pch + 1];
+        flagged |= (__builtin_amdgcn_readfirstlane((int)anyold) != 0 ? 1u : 0u) << pch;
+      }
+      if (flagged == 0u) return 0u;
+      // (out of line: inlined, its registers cost every workgroup - also the nine in ten that never get here - spills in the
+      // output tail behind it: + 35 k cycles per workgroup)
+      const unsigned int g = wide_far_guard<FULL>(smem + kClRows, NPAD, la->tcode + qrow0 * NV, la->tkey + bR * NV, kbase, N, NV, flagged, lane);
+      // (quads of a stable pass that hold no far entry any more: unflagged here - a hand-over in this slot's finalize raises
+      // the flag again, behind this store in the wave's own order)
+      if ((g >> 8) != 0u && lane < CPW / 4 && (((g >> 8) >> lane) & 1u) != 0u) la->told[qrow0 + lane] = 0u;
+      return g & 0xffu;
+    }
+    return 0u;
   };
   auto cl_build_a = [&](int pass) {
     const int kbase = wave * CPW;
@@ -1194,14 +1330,18 @@ __global__ __launch_bounds__(64 * wide_waves(VPL), VPL == 2 ? (PACKED ? DIRAL_WI
 #pragma unroll
           for (int d = 0; d < CV; ++d) { srcv[d] = (srcv[d] >> sh) & 255u; xv[d] = s_px[srcv[d]]; }
           out_t o[CV];
+          // (the value is selected in the OUTPUT type: float32(d) for the one float64 subtraction, then 100000 / 1 / 0 as
+          // float32 constants - the same bits as float32 of the float64 selection, half the select instructions)
+          const unsigned int zm = (~tx_bits) | ((unsigned int)(a - i0) < (unsigned int)CV ? 1u << (a - i0) : 0u);   // bit d: obs[u][i0 + d] = 0
 #pragma unroll
           for (int d = 0; d < CV; ++d) {
             double dd;
             if constexpr (ABS) dd = __builtin_fabs(xu - xv[d]);
             else dd = fast_dist<true>(xv[d], 0.0, xu, 0.0);
-            double val = dist_obs ? ((int)srcv[d] == u ? 100000.0 : dd) : 1.0;                 // network.py:385
-            if (a == i0 + d || ((tx_bits >> d) & 1u) == 0u) val = 0.0;
-            o[d] = (out_t)val;
+            out_t val = (out_t)dd;
+            val = (int)srcv[d] == u ? (out_t)100000.0 : val;                                    // network.py:385
+            val = dist_obs ? val : (out_t)1.0;
+            o[d] = ((zm >> d) & 1u) ? (out_t)0.0 : val;
           }
           if constexpr (OUT64) stream_store2(co + 2 * q, make_double2(o[0], o[1]));
           else stream_store4(co + 4 * q, make_float4(o[0], o[1], o[2], o[3]));

@@ -16,7 +16,7 @@
 void *oracle_create(const DiralCfg *cfg, int B, int sq_mode, int threads);
 void oracle_destroy(void *h);
 void oracle_reset(void *h, const double *x0, const double *y0, const double *v0);
-void oracle_step(void *h, int mode, const int32_t *actions, int64_t t, double *rews, double *chobs);
+int oracle_step(void *h, int mode, const int32_t *actions, int64_t t, double *rews, double *chobs);
 void oracle_obtain_state(void *h, const int32_t *actions, const double *chobs, const double *rews,
                          double episode, double eps, double *state);
 void oracle_update_velocity(void *h, const uint8_t *draws);
@@ -36,13 +36,17 @@ static int run(int N, int A, int K, int rd, int mode, uint32_t extra_flags, int 
   c.posdist_type = posdist_type; c.episode_interval = 25; c.info_age_limit = 20; c.pf_threshold = 10;
   c.pf_penalty = -10; c.highway_length = 30.0 * N + 60; c.highway_height = 2; c.communication_range = 120;
   c.bin_range = 500;
+  /* State.piggybacking: A * A values per agent; every receiver in range (run A) or the KeyError path (run B: rc 1, the env abandoned) */
+  const int pb = (extra_flags & DIRAL_F_PIGGYBACKING) != 0;
+  if (pb && N <= 16) c.communication_range = c.highway_length + 1;
+  const int CW = pb ? A * A : A;
   const int S = oracle_state_space(&c);
   void *h = oracle_create(&c, B, 0, 1);
   double *x0 = malloc(sizeof(double) * B * N), *y0 = calloc((size_t)B * N, sizeof(double)), *v0 = malloc(sizeof(double) * B * N);
   for (int i = 0; i < B * N; ++i) { x0[i] = rnd() % (int)c.highway_length; v0[i] = 1.1 + (rnd() % 1600) / 1000.0; }
   oracle_reset(h, x0, y0, v0);
   int32_t *act = malloc(sizeof(int32_t) * B * N);
-  double *rews = malloc(sizeof(double) * B * N), *chobs = malloc(sizeof(double) * B * N * A), *state = malloc(sizeof(double) * B * N * (S + 1));
+  double *rews = malloc(sizeof(double) * B * N), *chobs = malloc(sizeof(double) * B * N * CW), *state = malloc(sizeof(double) * B * N * (S + 1));
   uint8_t *draws = malloc((size_t)B * N);
   int32_t *ia = malloc(sizeof(int32_t) * B * 100);
   double *trace = malloc(sizeof(double) * 5 * N);
@@ -50,7 +54,7 @@ static int run(int N, int A, int K, int rd, int mode, uint32_t extra_flags, int 
   double acc = 0;
   for (int t = 0; t < T; ++t) {
     for (int i = 0; i < B * N; ++i) act[i] = (int32_t)(rnd() % (uint32_t)A);
-    oracle_step(h, mode, act, t, rews, chobs);
+    if (oracle_step(h, mode, act, t, rews, chobs)) break;   /* the reference's KeyError (piggybacking, nobody in range) */
     oracle_obtain_state(h, act, chobs, rews, t / 25, 0.5, state);
     oracle_info_age(h, t, ia);
     if (t % 25 == 24) { for (int i = 0; i < B * N; ++i) draws[i] = 1 + rnd() % 3; oracle_update_velocity(h, draws); }
@@ -74,6 +78,8 @@ int main(void) {
   bad |= run(1, 1, 3, 2, DIRAL_STEP_MY_STEP, DIRAL_F_ADD_POSDIST, 1, 2, 10);
   bad |= run(2, 1, 3, 2, DIRAL_STEP_MY_STEP_CH, all, 2, 2, 10);
   bad |= run(130, 64, 20, 2, DIRAL_STEP_MY_STEP, DIRAL_F_TOY_WEIGHTS, 2, 1, 12);
+  bad |= run(12, 5, 10, 2, DIRAL_STEP_MY_STEP, all | DIRAL_F_PIGGYBACKING, 2, 3, 50);
+  bad |= run(40, 9, 10, 3, DIRAL_STEP_MY_STEP, DIRAL_F_ADD_CHANNEL_OBS | DIRAL_F_PIGGYBACKING | DIRAL_F_ADD_POSDIST, 1, 2, 30);
   printf("san_check %s\n", bad ? "FAILED" : "ok");
   return bad;
 }

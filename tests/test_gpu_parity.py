@@ -2192,3 +2192,69 @@ def test_k_slots_in_one_launch_on_the_other_code_paths_of_the_slot_loop(case):
         assert not torch.equal(sa["vel"], torch.full_like(sa["vel"], 1.7))
     e1.check()
     e2.check()
+
+
+@pytest.mark.parametrize("N,A", [(128, 64), (100, 16)])
+def test_flagged_passes_whose_far_entries_stay_put_run_coded_and_propagation_falls_back(N, A, monkeypatch):
+    """The far-entry guard of the packed form at N <= 128 (csrc/step_wide.hpp `wide_far_guard`): a highway that is one
+    cluster for a dozen slots, then two clusters 2 km apart (positions imported) - every entry about the other cluster ages
+    beyond the codes, every pass is flagged, and no far value can move: the guard sends those passes down the coded path.
+    Then single vehicles are moved into the gap as relays (stale stamps start to travel from viewer to viewer: the guard
+    must refuse and the chain pass run), then everything is one cluster again.  State, reward, channel observation every
+    slot and the exported tables at every phase change against the oracle, bit for bit."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    from diral_amd.config import KERNEL_PACKED, KERNEL_WIDE
+    B, L = 6, 4000.0
+    monkeypatch.setenv("DIRAL_TABLE_FORM", "packed")               # (N = 100 on 4 km is below the density the packed form is chosen at)
+    cfg = bench_config(N, A, L).replace(track_arrival=True)
+    rng = np.random.default_rng(77 + N)
+    x0 = rng.uniform(1000.0, 1400.0, size=(B, N))
+    v0 = rng.uniform(1.1, 1.3, size=(B, N))
+    env = make_env(cfg, B)
+    env.reset_topology(x0, np.zeros((B, N)), v0)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=4)
+    orc.reset(x0, np.zeros((B, N)), v0)
+
+    def run(t0, t1):
+        for t in range(t0, t1):
+            a = rng.integers(0, A, size=(B, N)).astype(np.int32)
+            obs, rew, chobs, _ = gpu_step(env, STEP_MY_STEP, a, t)
+            o_rew, o_chobs = orc.step(STEP_MY_STEP, a, t)
+            o_state = orc.obtain_state(a, o_chobs, o_rew)
+            assert np.array_equal(rew, o_rew) and np.array_equal(chobs, o_chobs), t
+            assert np.array_equal(obs, o_state), (t, np.argwhere(obs != o_state)[:4])
+        assert (env.last_kernel() & 15) == KERNEL_WIDE and (env.last_kernel() & KERNEL_PACKED)
+
+    def tables_equal(tag):
+        st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        oe = orc.export()
+        for k in ("pos_x", "seq", "x"):
+            assert np.array_equal(st[k], oe[k]), (tag, k)
+        assert np.array_equal(st["age"], np.minimum(oe["age"], 255)), tag
+        return oe
+
+    def move(fn):
+        oe = orc.export()
+        px = oe["pos_x"].copy()
+        fn(px)
+        env.import_state(pos_x=px)
+        orc.import_state(pos_x=px)
+
+    run(0, 12)                                                     # one cluster: everybody hears everybody, codes only
+    half = N // 2
+    move(lambda px: px.__setitem__((slice(None), slice(half, None)), px[:, half:] + 2000.0))
+    run(12, 60)                                                    # two clusters: the entries across age beyond the codes and stay put
+    oe = tables_equal("split")
+    own = np.einsum("bkk->bk", oe["seq"])
+    assert ((own[:, None, :] - oe["seq"]) >= 8).mean() > 0.3       # ... nearly half of all entries by now
+    # relays: a few vehicles of the first cluster in the gap, 240 m apart - stale stamps about the far cluster start to travel
+    def relays(px):
+        for i in range(8):
+            px[:, i] = 1500.0 + 230.0 * i
+    move(relays)
+    run(60, 90)
+    tables_equal("relays")
+    move(lambda px: px.__setitem__((slice(None), slice(half, None)), px[:, half:] - 2000.0))
+    run(90, 120)                                                   # one cluster again: everything comes back within the codes
+    oe = tables_equal("merged")
+    env.check()
