@@ -44,7 +44,7 @@ if [ -f variants_tmp/lib_timing.so ]; then
 fi
 # the round's switches, interleaved on this box (variants_tmp/lib_*.so: profiles/ab_r06_build.sh in the build container)
 if [ -f variants_tmp/lib_w4old.so ]; then
-  (bash profiles/ab_libs_kernel.sh c3 3 w4old w4fma product; bash profiles/ab_libs_kernel.sh c5 3 w2old product; bash profiles/ab_libs_kernel.sh c2 3 f64old product) > gpurun_out/ab_switches_r06.txt 2>&1
+  (bash profiles/ab_libs_kernel.sh c3 3 w4old w4fma product; bash profiles/ab_libs_kernel.sh c5 3 w2old w2noguard product; bash profiles/ab_libs_kernel.sh c2 3 f64old product) > gpurun_out/ab_switches_r06.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_secondary -o t -- env WORKLOADS=c2,c5,c3 python $GRAFT_REPO_ROOT/profiles/secondary_modes.py > /dev/null 2>&1
