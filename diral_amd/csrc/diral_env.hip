@@ -53,6 +53,7 @@ struct DiralEnv {
   uint64_t slow_launches = 0;   // launches that rotated the sets
   bool slow_first = true;       // DIRAL_NO_SLOW_FIRST=1 at create: blocks = envs in order (A/B timing, tests)
   bool capture_rotates = false; // diral_env_set_capture_rotation: captured launches rotate the sets too (graphs of 3 k launches)
+  bool wide_slow_first = false;  // DIRAL_WIDE_SLOW_FIRST=1 at create: step_wide's packed form at N <= 128 dispatches its slow envs first (round 5's default)
   bool type1_wide_lanes = false; // DIRAL_TYPE1_LANES=wide at create: rounds 3-4's 64 values per lane in posdist_type1_lanes_kernel (A/B)
   int f32_margin = -1;          // DIRAL_F32_MARGIN=<n> at create: 0 = no float32 screening of the bin, n > 0 = a band of at
                                 //   least n / 65536 bin widths (tests: a wide band sends many entries to float64); -1 = the bound
@@ -421,7 +422,11 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     const bool kslots = pol && d.pol_ok && pol->K > 1;
     // (step_wide: the packed form at N <= 128 only - its slow envs are 4 x the others; the plane form's are 1.6 x and measured
     // 4 % SLOWER dispatched first, N > 128 packed runs on dense topologies without any: - 0.7 % for the bookkeeping)
-    const bool wide_slow = use_wide && vpl == 2 && e->tcode != nullptr;
+    // Round 6: with the far-entry guard (step_wide.hpp `wide_far_guard`) the flagged passes of a highway that broke apart run
+    // on the coded path - those envs are no longer 3 x the others, and the slow-first grid (B / 4 more blocks, a flag load per
+    // block) now costs more than it orders: C5 0.930 ms with it, 0.875 in batch order (one box, interleaved, profiles/r06).
+    // DIRAL_WIDE_SLOW_FIRST=1 at create brings it back (A/B).
+    const bool wide_slow = use_wide && vpl == 2 && e->tcode != nullptr && e->wide_slow_first;
     if ((use_fast64 || wide_slow) && e->slow && e->slow_first && !kslots) {
       const size_t w = slow_set_words(e);
       uint32_t* const set_r = e->slow + (e->slow_launches % 3) * w;
@@ -785,6 +790,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   r.off_pos = off.pos; r.off_vel = off.vel; r.off_fp = off.fp;
   r.H = cfg->highway_height; r.vel = e->vel; r.pos_y = e->pos_y;
   // test hooks, read ONCE here (never on the step path): force the general kernel
+  if (const char* ws = std::getenv("DIRAL_WIDE_SLOW_FIRST")) e->wide_slow_first = ws[0] == '1';
   if (const char* tl = std::getenv("DIRAL_TYPE1_LANES")) e->type1_wide_lanes = std::strcmp(tl, "wide") == 0;
   if (std::getenv("DIRAL_NO_FAST64") && e->vpl == 1) e->kernel_path = DIRAL_PATH_GENERAL;
   if (std::getenv("DIRAL_NO_WIDE") && e->vpl > 1) e->kernel_path = DIRAL_PATH_GENERAL;
