@@ -59,9 +59,15 @@ __device__ inline void piggy_store(void* base, size_t idx, double v, int f64) {
 __global__ void piggy_search_kernel(PiggyParams p) {
   const int b = blockIdx.x, N = p.N, A = p.A;
   const size_t bN = (size_t)b * N;
-  const int32_t* const act = p.actions + bN;
-  const double* const px = p.pos_x + bN;
-  const double* const py = p.pos_y + bN;
+  // the env's actions and positions once into LDS (N <= DIRAL_MAX_USERS): every (receiver, resource) pair walks all of them
+  __shared__ int32_t act[DIRAL_MAX_USERS];
+  __shared__ double px[DIRAL_MAX_USERS], py[DIRAL_MAX_USERS];
+  for (int u = threadIdx.x; u < N; u += blockDim.x) {
+    act[u] = p.actions[bN + u];
+    px[u] = p.pos_x[bN + u];
+    py[u] = p.pos_y[bN + u];
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < N * A; e += blockDim.x) {
     const int u = e / A, i = e - u * A;
     double best = 100000.0;                                      // network.py:385
