@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiral_env.so")
 # one translation unit per kernel family: hipcc compiles them in parallel
-SOURCES = ["diral_env.hip", "k_fast64.hip", "k_wide2.hip", "k_wide4.hip", "k_general.hip", "k_observe.hip"]
+SOURCES = ["diral_env.hip", "k_fast64.hip", "k_wide2.hip", "k_wide4.hip", "k_general.hip", "k_observe.hip", "k_large.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc")))
 
 # -ffp-contract=off: the reference (CPython floats) never fuses a*b+c; the bin

@@ -15,7 +15,7 @@ from typing import Any, Dict, Mapping, Optional
 
 # ---- C-ABI mirror (include/diral_env.h) ------------------------------------
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F_MOBILITY = 1 << 0
 F_MOBILITY_VARY = 1 << 1
@@ -47,11 +47,13 @@ OPT_ENV_OFFSET = 1
 OPT_KERNEL_PATH = 2
 PATH_AUTO = 0
 PATH_GENERAL = 1
+PATH_LARGE = 2
 
 KERNEL_GENERAL = 0
 KERNEL_FAST64 = 1
 KERNEL_WIDE = 2
 KERNEL_OBSERVE = 3
+KERNEL_LARGE = 4
 KERNEL_RICH = 16
 KERNEL_EXTRA = 32
 KERNEL_CH = 64
@@ -59,9 +61,12 @@ KERNEL_RING = 128
 KERNEL_PACKED = 256
 KERNEL_POLICY = 512
 
-MAX_USERS = 256
-MAX_CHANNELS = 256
-MAX_BINS = 64
+MAX_USERS = 4096
+MAX_CHANNELS = 4096
+MAX_BINS = 1024
+SMALL_MAX_USERS = 256        # the one-workgroup kernels; beyond: csrc/step_large.hpp (KERNEL_LARGE)
+SMALL_MAX_CHANNELS = 256
+SMALL_MAX_BINS = 64
 
 M_SLOTS, M_SUM_REWARD, M_TX_SOLE, M_TX_COLLIDED, M_PRR_SUM, M_PRR_CNT = range(6)
 M_COLUMNS = 6

@@ -75,6 +75,15 @@ struct StepParams {
   unsigned long long* dbg;   // phase timestamps (DIRAL_TIMING builds only)
 };
 
+// per-handle scratch of the large path (step_large.hpp; diral_env.hip allocates it)
+struct LargeScratch {
+  unsigned short* src;   // [B][A][N] gather source of (resource, viewer): the closest in-range transmitter, or the viewer itself
+  uint32_t* cnt;         // [B][A] transmitters per resource
+  double* px0;           // [B][N] positions the slot started with (the own stamp of periodic_update, vehicle.py:63)
+  double* rew;           // [B][N] reward per vehicle
+  double* rtx;           // [B][N] reception ratio per colliding transmitter (test_env.py:402-405)
+};
+
 // LDS carve of the fused step kernel; byte offsets, doubles first.
 struct LdsLayout {
   uint32_t px, py, npx, vel, rv, rtx, rew, edges, red, mask, act, inr, hist, cnt, mtab, scratch, total;

@@ -74,6 +74,9 @@ struct DiralEnv {
   double* prev_obs = nullptr;
   double* obs_new = nullptr;
   int32_t* txid = nullptr;
+  // num_users > 256 / num_channels > 256 / num_bins > 64 (step_large.hpp): no one-workgroup kernel holds such an env
+  bool large = false;
+  LargeScratch lg = {nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long* dbg = nullptr;   // DIRAL_TIMING builds: [B][waves][8] timestamps
   bool capture_violation = false;   // a ring <-> plane switch was asked for inside a stream capture
   std::string last_hip_error;
@@ -142,6 +145,18 @@ Offsets state_offsets(const DiralCfg* c) {
 }
 
 int vpl_for(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 4); }
+
+// sizes no one-workgroup kernel holds: the three launches of step_large.hpp
+bool is_large_cfg(const DiralCfg* c) {
+  if (c->num_users > DIRAL_SMALL_MAX_USERS || c->num_channels > DIRAL_SMALL_MAX_CHANNELS ||
+      (has(c, DIRAL_F_ADD_POSDIST_PIGGY) && c->num_bins > DIRAL_SMALL_MAX_BINS))
+    return true;
+  // ... and the combinations below those sizes whose env does not fit the general kernel's workgroup (e.g. 200 vehicles,
+  // 200 resources, 64 bins): every handle can fall back on that kernel, so they run here as well
+  const int vpl = vpl_for(c->num_users);
+  return lds_layout(64 * vpl, c->num_channels, c->num_bins > 0 ? c->num_bins : 1, vpl, 4 * vpl).total > 160u * 1024u;
+}
+bool runs_large(const DiralEnv* e) { return e->large || e->kernel_path == DIRAL_PATH_LARGE; }
 
 // The table form of a handle (fixed at create): packed thermometer codes + ages + own sequence numbers, or the (seq, age)
 // plane `tkey` of round 2.  N <= 64: always packed (step_fast64 has no other form).  64 < N <= 256 (step_wide): packed
@@ -321,6 +336,24 @@ hipError_t verify_ring(DiralEnv* e, hipStream_t s) {
   return hipGetLastError();
 }
 
+// scratch of the three-launch form (step_large.hpp), and its kernels' LDS attributes: at create for a large handle,
+// at diral_env_set_option(DIRAL_OPT_KERNEL_PATH, DIRAL_PATH_LARGE) for any other
+hipError_t alloc_large_scratch(DiralEnv* e) {
+  if (e->lg.src) return hipSuccess;
+  const size_t bn = (size_t)e->B * e->N, ba = (size_t)e->B * e->A;
+  struct { void** p; size_t bytes; } bufs[] = {
+    {(void**)&e->lg.src, ba * e->N * 2}, {(void**)&e->lg.cnt, ba * 4}, {(void**)&e->lg.px0, bn * 8},
+    {(void**)&e->lg.rew, bn * 8}, {(void**)&e->lg.rtx, bn * 8}};
+  for (auto& q : bufs) {
+    hipError_t r = hipMalloc(q.p, q.bytes);
+    if (r != hipSuccess) return r;
+    e->hbm_bytes += (int64_t)q.bytes;
+    r = hipMemset(*q.p, 0, q.bytes);
+    if (r != hipSuccess) return r;
+  }
+  return set_attr_large(e->N, e->A, e->K);
+}
+
 size_t slow_set_words(const DiralEnv* e) { return 16 + (size_t)fast_slow_max(e->B) + (size_t)e->B; }
 hipError_t clear_slow_sets(DiralEnv* e, hipStream_t s) {
   if (!e->slow) return hipSuccess;
@@ -341,7 +374,7 @@ struct StepDispatch {
 };
 StepDispatch step_dispatch(const DiralEnv* e, const StepParams& p) {
   StepDispatch d;
-  d.spec = is_specialised_cfg(p) && e->kernel_path != DIRAL_PATH_GENERAL;
+  d.spec = is_specialised_cfg(p) && e->kernel_path == DIRAL_PATH_AUTO && !e->large;
   d.plain = d.spec && is_plain_cfg(p);
   d.ch = p.mode == DIRAL_STEP_MY_STEP_CH;
   // the wide kernels read the reward column of a RICH state back from rew_out
@@ -365,6 +398,14 @@ StepDispatch step_dispatch(const DiralEnv* e, const StepParams& p) {
 hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, const PolParams* pol = nullptr, bool* fused = nullptr) {
   const int vpl = e->vpl;
   const bool flat_y = e->flat_y;
+  if (runs_large(e)) {
+    // (and diral_env_observe: the search kernel's observe mode + the histogram launch)
+    const hipError_t st = ensure_plane(e, s);
+    if (st != hipSuccess) return st;
+    if (p.mode != kModeObserve) e->ring_valid = false;
+    e->last_kernel = DIRAL_KERNEL_LARGE;
+    return launch_large(p, e->lg, s);
+  }
   const StepDispatch d = step_dispatch(e, p);
   const bool plain = d.plain, ch = d.ch, use_fast64 = d.use_fast64, use_wide = d.use_wide;
   // xpos ring (step_fast64.hpp): the N <= 64 kernel keeps the plane only for entries older than the ring reaches
@@ -501,8 +542,9 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
   q.do_full = 0; q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   q.flat_y = e->flat_y ? 1 : 0;
   const bool full_flat = full && e->flat_y;                     // one ranking of the env's x serves every viewer
-  const bool type1_n64 = type1 && p.NV == 64;                   // lane = viewer, sort in registers
-  const bool type1_lanes = type1 && !type1_n64;                 // 2 / 4 lanes per viewer (N <= 128 / 256)
+  const bool type1_n64 = type1 && p.NV == 64 && p.K <= DIRAL_SMALL_MAX_BINS;   // lane = viewer, sort in registers
+  const bool type1_lanes = type1 && !type1_n64 && p.N <= DIRAL_SMALL_MAX_USERS && p.K <= DIRAL_SMALL_MAX_BINS;   // 2 / 4 lanes per viewer (N <= 128 / 256)
+  const bool type1_generic = type1 && !type1_n64 && !type1_lanes;   // beyond: posdist_kernel's literal statement
   if (full_flat) {
     q.do_full = 1;
     hipLaunchKernelGGL(posdist_sorted_flat_kernel, dim3(p.B), dim3(256), posdist_flat_lds_bytes(p.N), s, q);
@@ -531,12 +573,13 @@ hipError_t launch_posdist_if_needed(DiralEnv* e, const StepParams& p, hipStream_
     q.do_type1 = 0; q.ring = nullptr; q.tcode = nullptr; q.tage = nullptr; q.tseq = nullptr;
   }
   q.do_full = (full && !full_flat) ? 1 : 0;
-  q.do_type1 = 0;
+  q.do_type1 = type1_generic ? 1 : 0;
   if (q.do_full || q.do_type1) {
     if (q.do_type1) {                                           // (the sorted true distances read no table)
       const hipError_t st = ensure_plane(e, s);
       if (st != hipSuccess) return st;
     }
+    if (posdist_lds_bytes(p.N, p.K) > 160u * 1024u) return hipErrorInvalidValue;   // (off-lane vehicles at N >~ 1400: one env's values do not fit)
     hipLaunchKernelGGL(posdist_kernel, dim3(p.B), dim3(64 * kPdWaves), posdist_lds_bytes(p.N, p.K), s, q);
   }
   return hipGetLastError();
@@ -627,8 +670,20 @@ int diral_env_validate(const DiralCfg* c) {
     if (c->state_type != 2 || !has(c, DIRAL_F_ADD_CHANNEL_OBS)) return DIRAL_ERR_BAD_CONFIG;
   }
   if (c->num_users > DIRAL_MAX_USERS || c->num_channels > DIRAL_MAX_CHANNELS) return DIRAL_ERR_UNSUPPORTED;
+  const int kbins = c->num_bins > 0 ? c->num_bins : 1;
+  if (is_large_cfg(c)) {
+    // step_large.hpp: the env's vehicles and resource lists in one workgroup's LDS, a table column in a wave's
+    if (large_lds_bytes(c->num_users, c->num_channels, kbins) > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
+    // piggyback_kernel.hpp stages one env in static LDS
+    if (c->num_users > DIRAL_SMALL_MAX_USERS && has(c, DIRAL_F_PIGGYBACKING)) return DIRAL_ERR_UNSUPPORTED;
+    // the type-1 histogram at these sizes is posdist_kernel's literal statement: one env's values in LDS (N <~ 1400)
+    if (has(c, DIRAL_F_ADD_POSDIST_PIGGY) && c->posdist_type == 1 && posdist_lds_bytes(c->num_users, kbins) > 160u * 1024u)
+      return DIRAL_ERR_UNSUPPORTED;
+    if (has(c, DIRAL_F_ADD_POSDIST) && posdist_flat_lds_bytes(c->num_users) > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
+    return DIRAL_OK;
+  }
   const int vpl = vpl_for(c->num_users);
-  const LdsLayout l = lds_layout(64 * vpl, c->num_channels, c->num_bins > 0 ? c->num_bins : 1, vpl, 4 * vpl);
+  const LdsLayout l = lds_layout(64 * vpl, c->num_channels, kbins, vpl, 4 * vpl);
   if (l.total > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
   return DIRAL_OK;
 }
@@ -655,6 +710,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   e->NV = e->N <= 64 ? 64 : (int)align_up((uint32_t)e->N, 16);   // one wave lane per viewer, no lane predicate
   e->NR = (int)align_up((uint32_t)e->N, 16);   // every wave owns 16 existing subject rows
   e->vpl = vpl_for(e->N);
+  e->large = is_large_cfg(cfg);
   e->device = device;
   const Offsets off = state_offsets(cfg);
   e->S = off.S;
@@ -682,7 +738,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   CREATE_TRY(alloc((void**)&e->tkey, (tab + 512 + 64 * 256) * 4));
   CREATE_TRY(alloc((void**)&e->tx, (tab + 512 + 64 * 256) * 8));
   // the xpos ring of the specialised kernels
-  if ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA)) {
+  if (!e->large && ((e->vpl == 1 && e->NV == 64 && e->A <= kFastMaxA) || (e->vpl > 1 && e->A <= kWideMaxA))) {
     CREATE_TRY(alloc((void**)&e->ring, (size_t)e->B * e->NR * 8 * 8));
     CREATE_TRY(hipMemset(e->ring, 0, (size_t)e->B * e->NR * 8 * 8));
     if (use_packed_table(e)) {                                  // the packed table of step_fast64 and of step_wide at N > 128
@@ -735,10 +791,15 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
     for (int n = 1; n < 256; ++n) { volatile double d = (double)n; inv[n] = 1.0 / d; }
     CREATE_TRY(hipMemcpy(e->inv_tab, inv.data(), 256 * 8, hipMemcpyHostToDevice));
   }
-  CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)posdist_lds_bytes(e->N, e->K)));
-  CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_type1_n64_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)posdist_type1_lds_bytes(e->K)));
+  if (posdist_lds_bytes(e->N, e->K) <= 160u * 1024u)
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)posdist_lds_bytes(e->N, e->K)));
+  if (posdist_flat_lds_bytes(e->N) > 48u * 1024u && posdist_flat_lds_bytes(e->N) <= 160u * 1024u)
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_sorted_flat_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)posdist_flat_lds_bytes(e->N)));
+  if (!e->large)
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(posdist_type1_n64_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)posdist_type1_lds_bytes(e->K)));
   CREATE_TRY(hipMemset(e->pos_x, 0, bn * 8));
   CREATE_TRY(hipMemset(e->pos_y, 0, bn * 8));
   CREATE_TRY(hipMemset(e->vel, 0, bn * 8));
@@ -749,12 +810,16 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if (e->la) CREATE_TRY(hipMemset(e->la, 0xFF, bn * e->N * 4));
   if (e->pf) CREATE_TRY(hipMemset(e->pf, 0, bn * 4));
 
-  const LdsLayout l = lds_layout(64 * e->vpl, e->A, e->K, e->vpl, 4 * e->vpl);
-  e->lds_bytes = l.total;
-  CREATE_TRY(set_attr_general(e->vpl, l.total));
-  if (e->vpl == 2 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide2(e->A, e->K));
-  if (e->vpl == 4 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide4(e->A, e->K));
-  CREATE_TRY(set_attr_observe(e->N, e->K));
+  if (e->large) {
+    CREATE_TRY(alloc_large_scratch(e));
+  } else {
+    const LdsLayout l = lds_layout(64 * e->vpl, e->A, e->K, e->vpl, 4 * e->vpl);
+    e->lds_bytes = l.total;
+    CREATE_TRY(set_attr_general(e->vpl, l.total));
+    if (e->vpl == 2 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide2(e->A, e->K));
+    if (e->vpl == 4 && e->A <= kWideMaxA) CREATE_TRY(set_attr_wide4(e->A, e->K));
+    CREATE_TRY(set_attr_observe(e->N, e->K));
+  }
 #undef CREATE_TRY
 
   StepParams& p = e->base;
@@ -793,7 +858,7 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if (const char* ws = std::getenv("DIRAL_WIDE_SLOW_FIRST")) e->wide_slow_first = ws[0] == '1';
   if (const char* tl = std::getenv("DIRAL_TYPE1_LANES")) e->type1_wide_lanes = std::strcmp(tl, "wide") == 0;
   if (std::getenv("DIRAL_NO_FAST64") && e->vpl == 1) e->kernel_path = DIRAL_PATH_GENERAL;
-  if (std::getenv("DIRAL_NO_WIDE") && e->vpl > 1) e->kernel_path = DIRAL_PATH_GENERAL;
+  if (std::getenv("DIRAL_NO_WIDE") && e->vpl > 1 && !e->large) e->kernel_path = DIRAL_PATH_GENERAL;
   *out = e;
   return DIRAL_OK;
 }
@@ -802,7 +867,7 @@ int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
   void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->slow, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
-                  e->prev_obs, e->obs_new, e->txid, e->dbg};
+                  e->prev_obs, e->obs_new, e->txid, e->dbg, e->lg.src, e->lg.cnt, e->lg.px0, e->lg.rew, e->lg.rtx};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
   return DIRAL_OK;
@@ -818,7 +883,14 @@ int diral_env_set_option(DiralEnv* e, int option, int64_t value) {
       e->env_offset = value;
       return DIRAL_OK;
     case DIRAL_OPT_KERNEL_PATH:
-      if (value != DIRAL_PATH_AUTO && value != DIRAL_PATH_GENERAL) return DIRAL_ERR_BAD_ARG;
+      if (value != DIRAL_PATH_AUTO && value != DIRAL_PATH_GENERAL && value != DIRAL_PATH_LARGE) return DIRAL_ERR_BAD_ARG;
+      if (e->large) return value == DIRAL_PATH_GENERAL ? DIRAL_ERR_UNSUPPORTED : DIRAL_OK;   // (there is one path for such a handle)
+      if (value == DIRAL_PATH_LARGE) {
+        if (large_lds_bytes(e->N, e->A, e->K) > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
+        DeviceGuard guard(e->device);
+        if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+        HIP_TRY(e, alloc_large_scratch(e));
+      }
       e->kernel_path = (int)value;
       return DIRAL_OK;
     default:
@@ -970,7 +1042,7 @@ int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_i
   p.actions = actions; p.state_out = state_out;
   p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr;
   p.chobs_in = chobs_in; p.rew_in = rew_in;
-  if (e->kernel_path == DIRAL_PATH_GENERAL) HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));   // (tests: the general kernel's observe mode)
+  if (e->kernel_path == DIRAL_PATH_GENERAL || runs_large(e)) HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));   // (tests: the general kernel's observe mode; step_large.hpp's)
   else HIP_TRY(e, launch_observe_any(e, p, (hipStream_t)stream));
   HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));
   if (e->prev_obs && e->off_chobs_pb >= 0) {                    // `obs` = piggy_obs, A * A values per agent

@@ -37,6 +37,10 @@ hipError_t launch_observe(const ObserveParams& p, const RichParams& r, bool flat
 hipError_t set_attr_observe(int N, int K);
 hipError_t launch_general(int vpl, bool fast, const StepParams& p, uint32_t lds, hipStream_t s);
 hipError_t set_attr_general(int vpl, uint32_t lds);
+// num_users > 256 / num_channels > 256 / num_bins > 64 (step_large.hpp): search + merge + histogram launches
+hipError_t launch_large(const StepParams& p, const LargeScratch& g, hipStream_t s);
+hipError_t set_attr_large(int N, int A, int K);
+uint32_t large_lds_bytes(int N, int A, int K);   // the largest workgroup's LDS (must stay within 160 KB)
 
 // run-time bools -> template arguments: f(std::integer_sequence<bool, ...>) is called with the
 // values as a type

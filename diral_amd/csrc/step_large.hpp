@@ -1,0 +1,525 @@
+// step_large.hpp - the env step for sizes the one-workgroup kernels do not hold: num_users > 256,
+// num_channels > 256 or num_bins > 64 (TestEnv takes any N, A - test_env.py:12-13 - and any State.num_bins, :40).
+//
+// Same statement of the reference as step_kernel.hpp (TestEnv.my_step / my_step_ch / my_step_design +
+// obtain_state, test_env.py:124-266 / 351-443 / 269-349 / 527-583), split where the data stops fitting a CU:
+//   large_search_kernel   one workgroup per env: tx lists per resource (a stable counting sort of the
+//                         actions), the closest in-range transmitter of every (viewer, resource) pair
+//                         (Network.find_closest_tx, network.py:378-398), rewards, PRR, arrival stamps, the
+//                         move (network.py:189-206), and every column of the state vector that needs no
+//                         table; leaves the gather sources of the gossip merge in HBM (`src`, u16 [A][N])
+//   large_merge_kernel    one WAVE per table column (subject k): Vehicle.periodic_update + every
+//                         Vehicle.received_update of the slot (vehicle.py:35-70) as key[u] = max(key[u],
+//                         key[src_i(u)]) for the resources in ascending order, key = (sequence number, source
+//                         viewer) in 64 bits, the column in the wave's LDS (the wave's own LDS queue is in
+//                         order: no barrier); xpos follows the winning number from the source viewer's entry
+//   large_hist_kernel     one wave per 64 viewers (fewer for many bins): Network.dist_piggy +
+//                         get_positional_dist_2_piggy (network.py:538-558, 473-513), lane = viewer, its
+//                         histogram row private in LDS
+// The tables are the (seq << 8 | age) and xpos planes of common.hpp.  Columns are independent (tx rows
+// are read-only within a resource, a receiver writes its own row), so the merge spreads over B x N waves where the
+// one-workgroup kernels have B workgroups: at N = 1024 that is what fills the chip.
+// Not tuned like step_fast64 / step_wide: no BASELINE.json configuration runs here.
+#pragma once
+#include "common.hpp"
+#include "step_kernel.hpp"
+
+namespace diral {
+
+constexpr int kLargeThreads = 1024;          // large_search_kernel: 16 waves
+constexpr int kLargeWaves = kLargeThreads / 64;
+constexpr uint32_t kLargeMergeLdsBudget = 64u * 1024u;
+
+struct LargeLds {
+  uint32_t px, py, inr, rec, act, list, cnt, off, red, total;
+};
+__host__ __device__ inline LargeLds large_lds_layout(int N, int A) {
+  const uint32_t np = (uint32_t)((N + 63) & ~63);
+  LargeLds l;
+  uint32_t o = 0;
+  l.px = o;   o += 8u * np;
+  l.py = o;   o += 8u * np;
+  l.red = o;  o += 8u * 4u * (np / 64u);
+  l.inr = o;  o += 4u * np;
+  l.rec = o;  o += 4u * np;
+  l.cnt = o;  o += 4u * (uint32_t)A;
+  l.off = o;  o += 4u * ((uint32_t)A + 1u);
+  l.act = o;  o += 2u * np;
+  l.list = o; o += 2u * np;
+  l.total = align_up(o, 16);
+  return l;
+}
+// waves (= columns) per workgroup of the merge, and its LDS: 8 bytes per viewer and column + one flag word per 64 viewers
+__host__ __device__ inline int large_merge_waves(int N) {
+  const uint32_t np = (uint32_t)((N + 63) & ~63);
+  const uint32_t per = 8u * np + 8u * (np / 64u);
+  const uint32_t w = kLargeMergeLdsBudget / per;
+  return w >= 4u ? 4 : (w >= 2u ? 2 : 1);
+}
+__host__ __device__ inline uint32_t large_merge_lds(int N) {
+  const uint32_t np = (uint32_t)((N + 63) & ~63);
+  return (uint32_t)large_merge_waves(N) * (8u * np + 8u * (np / 64u));
+}
+// viewers per workgroup of the histogram kernel: 64, fewer when the rows of K counters would not fit
+__host__ __device__ inline int large_hist_viewers(int K) {
+  int vw = 64;
+  while (vw > 1 && (uint32_t)vw * 4u * (uint32_t)(K | 1) > 64u * 1024u) vw >>= 1;
+  return vw;
+}
+__host__ __device__ inline uint32_t large_hist_lds(int K) {
+  return 8u * (uint32_t)(K + 2) + 4u * 64u + (uint32_t)large_hist_viewers(K) * 4u * (uint32_t)(K | 1);
+}
+
+// Network.calculate_reward_weights (network.py:273-300) over the ascending transmitter list of one resource;
+// wave-uniform (every lane walks the same pairs in the same order: calculate_avg_distance sums serially)
+__device__ inline int large_reward_weight(const StepParams& p, const unsigned short* lst, int c, const double* s_px,
+                                          const double* s_py) {
+  double s = 0.0;
+  int cnt = 0;
+  for (int qa = 0; qa < c; ++qa) {
+    const int a = lst[qa];
+    for (int qb = qa + 1; qb < c; ++qb) {
+      const int b = lst[qb];
+      s = s + dist2d(s_px[a], s_py[a], s_px[b], s_py[b]);
+      ++cnt;
+    }
+  }
+  const double m = s / (double)cnt;
+  if (p.flags & DIRAL_F_TOY_WEIGHTS) {
+    double x_min = p.L + 1, x_max = -p.L - 1;      // calculate_norm (network.py:225-246)
+    int umin = 0, umax = 0;
+    for (int u = 0; u < p.N; ++u) {
+      const double x = s_px[u];
+      if (x < x_min) { x_min = x; umin = u; }
+      if (x > x_max) { x_max = x; umax = u; }
+    }
+    return m == dist2d(s_px[umin], s_py[umin], s_px[umax], s_py[umax]);
+  }
+  return m > p.Rc;
+}
+
+__global__ __launch_bounds__(kLargeThreads) void large_search_kernel(const StepParams p, const LargeScratch g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const LargeLds lay = large_lds_layout(p.N, p.A);
+  double* s_px = reinterpret_cast<double*>(smem + lay.px);
+  double* s_py = reinterpret_cast<double*>(smem + lay.py);
+  double* s_red = reinterpret_cast<double*>(smem + lay.red);
+  int* s_inr = reinterpret_cast<int*>(smem + lay.inr);
+  int* s_rec = reinterpret_cast<int*>(smem + lay.rec);
+  int* s_cnt = reinterpret_cast<int*>(smem + lay.cnt);
+  int* s_off = reinterpret_cast<int*>(smem + lay.off);
+  short* s_act = reinterpret_cast<short*>(smem + lay.act);
+  unsigned short* s_list = reinterpret_cast<unsigned short*>(smem + lay.list);
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N, A = p.A, K = p.K;
+  const int NP = (N + 63) & ~63;
+  const int mode = p.mode;
+  const bool do_step = mode != kModeObserve;
+  const bool piggy = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) != 0;
+  const bool track_la = (p.flags & DIRAL_F_TRACK_ARRIVAL) && p.la != nullptr;
+  const bool want_prr = do_step && (mode == DIRAL_STEP_MY_STEP_CH || (mode == DIRAL_STEP_MY_STEP && (p.flags & DIRAL_F_TRACK_PRR)));
+  const bool mobile = (p.flags & DIRAL_F_MOBILITY) != 0;
+  const bool use_pf = (p.flags & DIRAL_F_PROPORTIONAL_FAIR) != 0;
+  const int out_f64 = p.out_f64;
+  const size_t bN = (size_t)b * N, bA = (size_t)b * A;
+  const long long t_now = p.t + (p.t_dev ? *p.t_dev : 0ll);
+
+  // ---- stage the vehicles; the move (update_positions, network.py:189-206) -----------------------------
+  for (int u = tid; u < NP; u += kLargeThreads) {
+    int a = -1;
+    double x = 0.0, y = 0.0;
+    if (u < N) {
+      a = p.actions[bN + u];
+      if (a < 0 || a >= A) { atomicOr(p.err, kErrAction); a = -1; }
+      x = p.pos_x[bN + u];
+      y = p.pos_y[bN + u];
+      if (do_step) {
+        g.px0[bN + u] = x;
+        g.rew[bN + u] = 0.0;
+        if (mobile) {
+          double nx;
+          if (p.trace) {                                             // replay branch, network.py:194-199
+            long long tt = t_now % p.trace_len;
+            if (tt < 0) tt += p.trace_len;
+            const size_t base = p.trace_per_env ? (size_t)b * p.trace_len : 0;
+            nx = p.trace[(base + (size_t)tt) * N + u];
+          } else {
+            nx = py_mod_pos(x + p.vel[bN + u] + p.L, p.L);           // network.py:203
+          }
+          p.pos_x[bN + u] = nx;
+        }
+      }
+    }
+    s_act[u] = (short)a; s_px[u] = x; s_py[u] = y; s_inr[u] = 0; s_rec[u] = 0;
+  }
+  for (int i = tid; i < A; i += kLargeThreads) s_cnt[i] = 0;
+  __syncthreads();
+
+  if (do_step) {
+    // ---- transmitter lists per resource, ascending id (test_env.py:141-157): a stable counting sort -------
+    for (int u = tid; u < N; u += kLargeThreads) {
+      const int a = s_act[u];
+      if (a >= 0) atomicAdd(&s_cnt[a], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int running = 0;
+      for (int base = 0; base < A; base += 64) {
+        const int i = base + lane;
+        const int c = i < A ? s_cnt[i] : 0;
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        if (i < A) { s_off[i] = running + inc - c; s_cnt[i] = running + inc - c; }   // s_cnt: the fill cursor
+        running += __shfl(inc, 63);
+      }
+      if (lane == 0) s_off[A] = running;
+      wave_lds_order();
+      for (int base = 0; base < NP; base += 64) {
+        const int a = s_act[base + lane];
+        unsigned long long todo = __ballot(a >= 0);
+        while (todo) {
+          const int l = __builtin_ctzll(todo);
+          const int a0 = __builtin_amdgcn_readlane(a, l);
+          const unsigned long long m = __ballot(a == a0);
+          const int cur = s_cnt[a0];
+          wave_lds_order();
+          if (a == a0) s_list[cur + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(base + lane);
+          if (lane == l) s_cnt[a0] = cur + __popcll(m);
+          wave_lds_order();
+          todo &= ~m;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- per resource: closest in-range transmitter per viewer, channel observation, rewards ----------------
+    const bool want_obs = p.chobs_out != nullptr || (p.state_out != nullptr && p.off_chobs >= 0);
+    for (int i = wave; i < A; i += kLargeWaves) {
+      const int o0 = s_off[i], c = s_off[i + 1] - o0;
+      const unsigned short* lst = s_list + o0;
+      if (lane == 0) g.cnt[bA + i] = (uint32_t)c;
+      if (c == 0 && !want_obs) continue;
+      for (int vb = 0; vb < NP; vb += 64) {
+        const int u = vb + lane;
+        const bool valid = u < N;
+        const double mx = s_px[u], my = s_py[u];
+        const int myact = s_act[u];
+        const bool rx = valid && myact != i;
+        double best = 100000.0;                                      // network.py:385-386
+        int bid = -1;
+        for (int q = 0; q < c; ++q) {                                // ascending tx id, strict '<' (network.py:387-392)
+          const int w = lst[q];
+          const double d = dist2d(s_px[w], s_py[w], mx, my);
+          const bool inr = d < p.Rc;
+          if (inr && d < best) { best = d; bid = w; }
+          if (track_la && rx && !inr) p.la[(bN + w) * N + u] = -1;   // network.py:394
+          if (want_prr && c > 1) {                                   // test_env.py:395-397
+            const int n = __popcll(__ballot(rx && inr));
+            if (lane == 0) s_inr[w] += n;
+          }
+        }
+        const bool is_tx = myact == i;
+        const bool got = !is_tx && bid >= 0 && valid && c > 0;
+        if (valid && c > 0) g.src[(bA + i) * N + u] = (unsigned short)(got ? bid : u);
+        if (valid) {
+          double ob = 0.0;                                           // `obs[user][i]`
+          if (!is_tx && c > 0) {
+            if (mode == DIRAL_STEP_MY_STEP && p.state_type == 2) ob = best;   // test_env.py:240
+            else ob = 1.0;                                           // :228, :306, :432
+          }
+          if (p.chobs_out) store_out(p.chobs_out, (bN + u) * A + i, ob, out_f64);
+          if (p.state_out && p.off_chobs >= 0) store_out(p.state_out, (bN + u) * p.S + p.off_chobs + i, ob, out_f64);
+          if (track_la && mode == DIRAL_STEP_MY_STEP_CH && got) p.la[(bN + bid) * N + u] = (int32_t)t_now;   // test_env.py:436
+        }
+        if (want_prr && c > 1 && rx && bid >= 0) atomicAdd(&s_rec[bid], 1);   // test_env.py:398-400
+      }
+      if (c == 0) continue;
+      wave_lds_order();
+      // one value per colliding resource (test_env.py:163-199)
+      double rw = 0.0;
+      if (mode == DIRAL_STEP_MY_STEP && c > 1) {
+        const int rd = p.reward_design;
+        if (rd == 1) {
+          const double R = (double)large_reward_weight(p, lst, c, s_px, s_py) / (double)c;
+          rw = -1.0 * (1.0 - R);
+        } else if (rd == 2) {
+          if (c == 2) rw = 2.0 * (double)large_reward_weight(p, lst, c, s_px, s_py) - (double)c;
+          else rw = 0.0 - (double)c;
+        } else if (rd == 3) {
+          const double R = 1.0 / (double)c;
+          rw = -1.0 * exp(1.0 - R);
+        } else if (rd == 4) {
+          rw = 1.0 / (double)c;
+        } else {
+          if (c == 2) rw = (large_reward_weight(p, lst, c, s_px, s_py) == 1) ? 0.0 : -1.0;
+          else rw = -1.0;
+        }
+      }
+      // the reward of each of its transmitters
+      for (int q = lane; q < c; q += 64) {
+        const int u = lst[q];
+        double r = 0.0;
+        if (mode == DIRAL_STEP_MY_STEP) {                              // test_env.py:211-222
+          if (c > 1) {
+            r = rw;
+            if (use_pf) {
+              const int pc = p.pf[bN + u];
+              if (pc > p.pf_threshold) r = p.pf_penalty;
+              p.pf[bN + u] = pc + 1;
+            }
+          } else {
+            r = 1.0;
+            if (use_pf) p.pf[bN + u] = 0;
+          }
+          if (want_prr && c > 1) {
+            const int n_in = s_inr[u];
+            g.rtx[bN + u] = n_in > 0 ? (double)s_rec[u] / (double)n_in : 1.0;     // test_env.py:402-405
+          }
+        } else if (mode == DIRAL_STEP_MY_STEP_CH) {                     // test_env.py:411-429
+          const int rd = p.reward_design;
+          if (c > 1) {
+            const int n_in = s_inr[u];
+            const double R = n_in > 0 ? (double)s_rec[u] / (double)n_in : 1.0;
+            g.rtx[bN + u] = R;
+            if (rd == 3) r = 1.0 - exp(1.0 - R);
+            else if (rd == 4) r = -1.0 * exp(1.0 - R);
+            else if (rd == 2) r = -1.0 * (1.0 - R);
+          } else {
+            if (rd == 3) r = 1.0;
+            else if (rd == 4) r = exp(1.0);
+            else if (rd == 2) r = 1.0;
+          }
+        } else {                                                       // test_env.py:297-301, 319-349
+          if (c == 1) r = 1.0;
+          else {
+            int n = 1;
+            double dlast = 0.0;
+            for (int qo = 0; qo < c; ++qo) {
+              const int o = lst[qo];
+              if (o == u) continue;
+              const double d = dist2d(s_px[u], s_py[u], s_px[o], s_py[o]);
+              if (d < 2.0 * p.Rc) { if (n == 1) dlast = d; ++n; }      // network.py:122-133
+            }
+            if (n == 1) r = 1.0;
+            else if (n == 2) r = ((dlast / 1.0) > p.Rc * 2.0) ? 0.0 : -2.0;     // network.py:135-157
+            else r = -(double)n;
+          }
+        }
+        g.rew[bN + u] = r;
+        if (p.rew_out) store_out(p.rew_out, bN + u, r, out_f64);
+      }
+    }
+    __syncthreads();
+
+    // ---- metric accumulators: per 64 vehicles a shuffle tree, the partial sums added in order ---------------
+    for (int u = tid; u < NP; u += kLargeThreads) {
+      double vr = 0.0, vp = 0.0;
+      int vs = 0, vc = 0;
+      const int a = s_act[u];
+      if (u < N) {
+        if (a >= 0) {
+          const int c = s_off[a + 1] - s_off[a];
+          vr = g.rew[bN + u];
+          vs = c == 1; vc = c > 1;
+          if (want_prr) vp = c > 1 ? g.rtx[bN + u] : 1.0;
+        } else if (p.rew_out) {
+          store_out(p.rew_out, bN + u, 0.0, out_f64);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        vr += __shfl_down(vr, off);
+        vp += __shfl_down(vp, off);
+        vs += __shfl_down(vs, off);
+        vc += __shfl_down(vc, off);
+      }
+      if (lane == 0) {
+        const int slot = u >> 6;
+        s_red[slot * 4 + 0] = vr; s_red[slot * 4 + 1] = vp; s_red[slot * 4 + 2] = (double)vs; s_red[slot * 4 + 3] = (double)vc;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (p.done_out) p.done_out[b] = (uint8_t)((t_now % p.episode_interval) == p.episode_interval - 1);
+      double sr = 0.0, sp = 0.0, ss = 0.0, sc = 0.0;
+      for (int w = 0; w < NP / 64; ++w) { sr += s_red[w * 4 + 0]; sp += s_red[w * 4 + 1]; ss += s_red[w * 4 + 2]; sc += s_red[w * 4 + 3]; }
+      double* mt = p.metrics + (size_t)b * DIRAL_M_COLUMNS;
+      mt[DIRAL_M_SLOTS] += 1.0;
+      mt[DIRAL_M_SUM_REWARD] += sr;
+      mt[DIRAL_M_TX_SOLE] += ss;
+      mt[DIRAL_M_TX_COLLIDED] += sc;
+      if (want_prr) { mt[DIRAL_M_PRR_SUM] += sp; mt[DIRAL_M_PRR_CNT] += ss + sc; }
+    }
+  }
+
+  // ---- the state vector (test_env.py:527-583) except its table columns ----------------------------------------
+  if (p.state_out) {
+    const int S = p.S;
+    const size_t total = (size_t)N * S;
+    const int act_w = (p.flags & DIRAL_F_ACTION_REAL) ? 1 : A;
+    for (size_t e = tid; e < total; e += kLargeThreads) {
+      const int u = (int)(e / S), s = (int)(e - (size_t)u * S);
+      double val = 0.0;
+      bool write = true;
+      if (p.off_act >= 0 && s >= p.off_act && s < p.off_act + act_w) {
+        val = (p.flags & DIRAL_F_ACTION_REAL) ? (double)s_act[u] : ((s_act[u] == s - p.off_act) ? 1.0 : 0.0);   // test_env.py:585-595
+      } else if (p.off_chobs >= 0 && s >= p.off_chobs && s < p.off_chobs + A) {
+        if (do_step) write = false;                                   // written above
+        else val = p.chobs_in ? p.chobs_in[(bN + u) * A + (s - p.off_chobs)] : 0.0;
+      } else if (p.off_hist >= 0 && s >= p.off_hist && s < p.off_hist + K) {
+        write = !(piggy && (p.posdist_type == 2 || p.posdist_type == 1));   // large_hist_kernel / posdist_kernel
+      } else if (p.off_posdist >= 0 && s >= p.off_posdist && s < p.off_posdist + N - 1) {
+        write = false;                                                // posdist_kernel
+      } else if (s == p.off_rew) {
+        val = do_step ? g.rew[bN + u] : (p.rew_in ? p.rew_in[bN + u] : 0.0);
+      } else if (s == p.off_idx) {
+        val = (double)(u + 1);
+      } else if (p.off_pos >= 0 && s == p.off_pos) {
+        val = p.pos_x[bN + u] / p.L;                                  // network.py:403-407 (behind the move)
+      } else if (p.off_pos >= 0 && s == p.off_pos + 1) {
+        val = s_py[u] / p.H;
+      } else if (s == p.off_vel) {
+        val = p.vel[bN + u];
+      } else if (p.off_fp >= 0 && s == p.off_fp) {
+        val = p.episode;
+      } else if (p.off_fp >= 0 && s == p.off_fp + 1) {
+        val = p.eps;
+      }
+      if (write) store_out(p.state_out, bN * S + e, val, out_f64);
+    }
+  }
+}
+
+// One wave per table column.  grid = B * ceil(N / W), W = large_merge_waves(N) waves per workgroup.
+__global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, const LargeScratch g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = p.N, A = p.A, NV = p.NV;
+  const int NP = (N + 63) & ~63;
+  const int W = large_merge_waves(N);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+ const int nblk = (N + W - 1) / W;
+  const int b = blockIdx.x / nblk, k = (blockIdx.x - b * nblk) * W + wave;
+  if (k >= N) return;                                                 // (no workgroup barrier below)
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + NP / 64);
+  unsigned long long* s_msk = key + NP;
+  double* xs = reinterpret_cast<double*>(key);
+  const size_t bN = (size_t)b * N, bA = (size_t)b * A;
+  const size_t row = ((size_t)b * p.NR + k) * NV;
+  bool seq_ovf = false;
+
+  // Vehicle.periodic_update (vehicle.py:56-70) of this column's entries
+  auto stamp = [&](unsigned int w, int u) -> unsigned int {
+    const bool own = u == k;
+    const unsigned int seq = (w >> 8) + (own ? 1u : 0u);
+    const unsigned int a0 = w & 255u;
+    const unsigned int age = own ? 0u : (a0 + (a0 < 255u ? 1u : 0u));
+    seq_ovf = seq_ovf || (own && seq >= (1u << 24) - 1u);
+    return (seq << 8) | age;
+  };
+  for (int vb = 0; vb < NP; vb += 64) {
+    const int u = vb + lane;
+    const unsigned int w = u < N ? stamp(p.tkey[row + u], u) : 0u;
+    key[u] = ((unsigned long long)(w >> 8) << 32) | (unsigned int)u;
+  }
+  wave_lds_order();
+  // Vehicle.received_update (vehicle.py:35-47) for every (resource, receiver) in reference order: the transmitters of
+  // resource i do not merge on i (test_env.py:204-209), so the entries read in step i are not written in step i
+  for (int i = 0; i < A; ++i) {
+    if (g.cnt[bA + i] == 0u) continue;
+    const unsigned short* src = g.src + (bA + i) * N;
+    for (int vb = 0; vb < NP; vb += 64) {
+      const int u = vb + lane;
+      if (u < N) {
+        const int m = src[u];
+        const unsigned long long v = key[m], mine = key[u];
+        if (v > mine) key[u] = v;
+      }
+    }
+    wave_lds_order();
+  }
+  // xpos follows the winning sequence number (from the source viewer's entry as the slot found it, or the subject's own
+  // stamp), last_updated resets where the entry changed
+  const double pxk = g.px0[bN + k];
+  for (int vb = 0; vb < NP; vb += 64) {
+    const int u = vb + lane;
+    const bool valid = u < N;
+    bool wr = false;
+    double xg = 0.0;
+    if (valid) {
+      const unsigned int ws = stamp(p.tkey[row + u], u);
+      const unsigned long long kf = key[u];
+      const unsigned int seqf = (unsigned int)(kf >> 32), sv = (unsigned int)kf;
+      const bool upd = seqf != (ws >> 8);
+      p.tkey[row + u] = upd ? (seqf << 8) : ws;
+      if (u == k) { xg = pxk; wr = true; }                            // vehicle.py:63
+      else if (upd) { xg = (int)sv == k ? pxk : p.tx[row + sv]; wr = true; }
+    }
+    wave_lds_order();
+    xs[u] = xg;                                                       // (the key of this viewer is consumed)
+    const unsigned long long mk = __ballot(wr);
+    if (lane == 0) s_msk[vb >> 6] = mk;
+  }
+  wave_lds_order();
+  for (int vb = 0; vb < NP; vb += 64) {
+    const int u = vb + lane;
+    const unsigned long long mk = s_msk[vb >> 6];
+    if ((mk >> lane) & 1ull) p.tx[row + u] = xs[u];
+  }
+  if (seq_ovf) atomicOr(p.err, kErrSeq);
+}
+
+// The type-2 piggybacked histogram of 64 (or fewer) viewers per wave.  grid = B * ceil(N / VW), 64 threads.
+__global__ __launch_bounds__(64) void large_hist_kernel(const StepParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = p.N, K = p.K, NV = p.NV, KP = K | 1;
+  const int VW = large_hist_viewers(K);
+  double* s_edges = reinterpret_cast<double*>(smem);
+  unsigned int* s_n = reinterpret_cast<unsigned int*>(smem + 8u * (K + 2));
+  unsigned int* s_hist = s_n + 64;
+  const int lane = threadIdx.x;
+  const int nblk = (N + VW - 1) / VW;
+  const int b = blockIdx.x / nblk, vb0 = (blockIdx.x - b * nblk) * VW;
+  const int u = vb0 + lane;
+  const bool mine = lane < VW && u < N;
+  const size_t bN = (size_t)b * N, bR = (size_t)b * p.NR;
+  for (int j = lane; j <= K; j += 64) s_edges[j] = p.edges[j];
+  for (int j = lane; j < VW * KP; j += 64) s_hist[j] = 0u;
+  wave_lds_order();
+  const double x2 = mine ? p.pos_x[bN + u] : 0.0, y2 = mine ? p.pos_y[bN + u] : 0.0;
+  unsigned int* hrow = s_hist + lane * KP;
+  unsigned int cnt = 0u;
+  const size_t col = mine ? (size_t)u : 0;
+#pragma unroll 4
+  for (int k = 0; k < N; ++k) {
+    const size_t idx = (bR + k) * NV + col;
+    const unsigned int w = p.tkey[idx];
+    const double x1 = p.tx[idx];
+    const double pyk = p.pos_y[bN + k];
+    // Network.dist_piggy + get_positional_dist_2_piggy (network.py:538-558, 473-513)
+    if (mine && u != k && (int)(w & 255u) < p.age_limit) {
+      const double y1 = (w >> 8) ? pyk : 0.0;
+      const double d = dist2d(x1, y1, x2, y2);
+      if (d < p.Rb) {
+        const double v = (x1 - x2 > 0.0) ? d : -d;
+        hrow[hist_bin(v, -p.Rb, p.hist_inv_width, K, s_edges)] += 1u;
+        cnt += 1u;
+      }
+    }
+  }
+  s_n[lane] = cnt;
+  wave_lds_order();
+  const int rows = min(VW, N - vb0);
+  for (int e = lane; e < rows * K; e += 64) {
+    const int r = e / K, j = e - r * K;
+    const unsigned int n = s_n[r], h = s_hist[r * KP + j];
+    const double val = n ? (double)h / (double)n : 0.0;                // network.py:501
+    store_out(p.state_out, (bN + vb0 + r) * p.S + p.off_hist + j, val, p.out_f64);
+  }
+}
+
+}  // namespace diral

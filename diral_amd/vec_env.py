@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from .config import (DT_F32, DT_F64, ERR_HIP, M_COLUMNS, OK, OPT_ENV_OFFSET, OPT_KERNEL_PATH, PATH_AUTO,
-                     PATH_GENERAL, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, ConfigError, EnvConfig)
+                     PATH_GENERAL, PATH_LARGE, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, ConfigError, EnvConfig)
 
 # MA_NeighborTableEntry (envs/ma_messages_pb2.py:195-230) as a host view of DiralNeighborEntry
 ENTRY_DTYPE = np.dtype([("pos_x", "<f4"), ("pos_y", "<f4"), ("seq_num", "<i4"), ("last_update", "<i4")])
@@ -203,6 +203,12 @@ class VecV2VEnv:
     def force_general_kernel(self, on: bool = True) -> None:
         """Tests / A-B timing: run every step on the general kernel (csrc/step_kernel.hpp)."""
         self._ok(self.lib.diral_env_set_option(self._h, OPT_KERNEL_PATH, PATH_GENERAL if on else PATH_AUTO),
+                 "diral_env_set_option")
+
+    def force_large_path(self, on: bool = True) -> None:
+        """Tests: run every step / observe on the three launches of csrc/step_large.hpp, the form that serves
+        num_users > 256, num_channels > 256 or num_bins > 64 (there it is the only path and this is a no-op)."""
+        self._ok(self.lib.diral_env_set_option(self._h, OPT_KERNEL_PATH, PATH_LARGE if on else PATH_AUTO),
                  "diral_env_set_option")
 
     def set_clock(self, clock: Optional[torch.Tensor]) -> None:

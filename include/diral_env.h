@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIRAL_ABI_VERSION 7
+#define DIRAL_ABI_VERSION 8
 
 /* ---- status codes --------------------------------------------------------- */
 typedef enum DiralStatus {
@@ -128,13 +128,21 @@ typedef enum DiralStepMode {
  * The arithmetic is always float64, like the reference; F32 is a final cast. */
 typedef enum DiralDType { DIRAL_F32 = 0, DIRAL_F64 = 1 } DiralDType;
 
-/* limits of this build.  Beyond num_users = 256 diral_env_create returns DIRAL_ERR_UNSUPPORTED.  The specialised
- * kernels (csrc/step_fast64.hpp, step_wide.hpp: every number bench.py reports) serve num_channels <= 64; a config
- * with 64 < num_channels <= 256 is stepped by the general kernel (csrc/step_kernel.hpp: same results, bit for bit,
- * 2.5-4 x the time - diral_env_last_kernel() says which one ran). */
-#define DIRAL_MAX_USERS    256
-#define DIRAL_MAX_CHANNELS 256
-#define DIRAL_MAX_BINS     64
+/* limits of this build (the reference has none: TestEnv takes any N, A and State.num_bins, test_env.py:12-13, 40).
+ * The specialised kernels (csrc/step_fast64.hpp, step_wide.hpp: every number bench.py reports) serve num_users <= 256
+ * with num_channels <= 64; 64 < num_channels <= 256 at num_users <= 256 is stepped by the general kernel
+ * (csrc/step_kernel.hpp: same results, bit for bit, 2.5-4 x the time).  Beyond num_users 256, num_channels 256 or
+ * num_bins 64 the step runs as three launches with the tables' columns spread over the chip (csrc/step_large.hpp,
+ * DIRAL_KERNEL_LARGE: same results, bit for bit) up to the sizes below - as long as the per-env working set fits a
+ * workgroup's 160 KB of LDS (28 bytes per vehicle + 8 per resource: 4096 vehicles with 4096 resources do), else
+ * DIRAL_ERR_UNSUPPORTED.  diral_env_last_kernel() says which kernel ran.  Not served beyond 256 vehicles: State.piggybacking,
+ * and the type-1 histogram beyond ~1400 (DIRAL_ERR_UNSUPPORTED at create). */
+#define DIRAL_MAX_USERS    4096
+#define DIRAL_MAX_CHANNELS 4096
+#define DIRAL_MAX_BINS     1024
+#define DIRAL_SMALL_MAX_USERS    256   /* the one-workgroup kernels */
+#define DIRAL_SMALL_MAX_CHANNELS 256
+#define DIRAL_SMALL_MAX_BINS     64
 #define DIRAL_MAX_SLOTS    16777214   /* steps between resets (24-bit sequence numbers) */
 
 /* per-env episode metric columns written by diral_env_metrics() */
@@ -190,10 +198,12 @@ typedef enum DiralOption {
    * the whole batch draws with the same seed. */
   DIRAL_OPT_ENV_OFFSET = 1,
   /* DIRAL_PATH_AUTO (default): configurations the specialised kernels serve run on
-   * them; DIRAL_PATH_GENERAL: always the general kernel (tests compare the two). */
+   * them; DIRAL_PATH_GENERAL: always the general kernel (tests compare the two);
+   * DIRAL_PATH_LARGE: always the three-launch form of csrc/step_large.hpp (tests run the
+   * reference's fixtures through it; not with State.piggybacking's A * A section). */
   DIRAL_OPT_KERNEL_PATH = 2
 } DiralOption;
-enum { DIRAL_PATH_AUTO = 0, DIRAL_PATH_GENERAL = 1 };
+enum { DIRAL_PATH_AUTO = 0, DIRAL_PATH_GENERAL = 1, DIRAL_PATH_LARGE = 2 };
 int diral_env_set_option(DiralEnv* env, int option, int64_t value);
 
 /* which kernel the last diral_env_step / diral_env_observe call launched:
@@ -204,6 +214,7 @@ enum {
   DIRAL_KERNEL_FAST64  = 1,   /* csrc/step_fast64.hpp, N <= 64       */
   DIRAL_KERNEL_WIDE    = 2,   /* csrc/step_wide.hpp,  64 < N <= 256  */
   DIRAL_KERNEL_OBSERVE = 3,   /* csrc/observe_kernel.hpp: diral_env_observe (stand-alone obtain_state) */
+  DIRAL_KERNEL_LARGE   = 4,   /* csrc/step_large.hpp: N > 256, A > 256 or K > 64 (step and observe) */
   DIRAL_KERNEL_RICH    = 16,  /* channel-obs output / cheap State flags (csrc/rich_out.hpp) */
   DIRAL_KERNEL_EXTRA   = 32,  /* my_step_design / arrival stamps / trace replay */
   DIRAL_KERNEL_CH      = 64,  /* my_step_ch */

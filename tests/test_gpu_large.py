@@ -1,0 +1,113 @@
+"""GPU parity of the three-launch form (csrc/step_large.hpp): the path that serves what the reference takes and the
+one-workgroup kernels do not - num_users > 256, num_channels > 256, State.num_bins > 64 (TestEnv has no limits,
+test_env.py:12-13, 40).  Two angles:
+  * every reference fixture replayed through it (DIRAL_PATH_LARGE on small handles): the same bar as the specialised
+    kernels - bit-exact against the oracle, 1 ulp (pow) against the reference's own numbers;
+  * sizes only it runs (300 ... 2048 vehicles, up to 700 resources, up to 300 bins) against the oracle, every step
+    kind, the State flags, PRR / arrival tracking, velocity updates, lanes off the y = 0 line, the secondary
+    observation modes.
+"""
+import numpy as np
+import pytest
+import torch
+
+import tests.test_gpu_parity as tp
+from diral_amd.config import (KERNEL_LARGE, STEP_DESIGN, STEP_MY_STEP, STEP_MY_STEP_CH, bench_config, c2_config)
+from tests.golden_util import golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def large_path(monkeypatch):
+    """make_env of the parity tests hands out handles pinned to the large path."""
+    plain = tp.make_env
+
+    def make(cfg, B, mode=STEP_MY_STEP, dtype=torch.float64):
+        env = plain(cfg, B, mode, dtype)
+        env.force_large_path()
+        return env
+    monkeypatch.setattr(tp, "make_env", make)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_replay_on_the_large_path(name, large_path):
+    tp.test_golden_replay_on_gpu(name)
+
+
+@pytest.mark.parametrize("mode,rd", [(STEP_MY_STEP, 1), (STEP_MY_STEP, 2), (STEP_MY_STEP, 3), (STEP_MY_STEP, 5),
+                                     (STEP_MY_STEP_CH, 2), (STEP_MY_STEP_CH, 4), (STEP_DESIGN, 2)])
+def test_c2_shapes_on_the_large_path(mode, rd):
+    """64 vehicles / 32 resources, rich State flags, sticky actions, PRR tracking: against the oracle."""
+    cfg = c2_config(reward_design=rd, State=dict(add_channel_obs=True, add_reward=True, add_index=True, add_velocity=True,
+                                                  add_position=True))
+    tp.random_rollout(cfg, B=12, T=30, seed=900 + rd + 10 * mode, mode=mode, sticky=0.7, track_prr=(mode == STEP_MY_STEP),
+                      path="large", expect_kernel=KERNEL_LARGE)
+
+
+def test_c5_shapes_with_velocity_updates_on_the_large_path():
+    tp.random_rollout(bench_config(128, 64, 4000.0, mobility_vary=True, proportional_fair=True), B=6, T=55, seed=907,
+                      vel_every=25, sticky=0.9, path="large", expect_kernel=KERNEL_LARGE)
+
+
+def _lanes(rng, B, N):
+    return rng.integers(0, 2, size=(B, N)).astype(np.float64) * 1.5
+
+
+@pytest.mark.parametrize("N,A,K,L,rc,mode,kw", [
+    (257, 8, 20, 4000.0, 250.0, STEP_MY_STEP, {}),                               # one vehicle past the limit
+    (300, 40, 20, 5000.0, 250.0, STEP_MY_STEP_CH, dict(reward_design=3)),
+    (300, 40, 20, 5000.0, 120.0, STEP_DESIGN, {}),
+    (512, 64, 20, 8000.0, 250.0, STEP_MY_STEP, dict(reward_design=1)),
+    (700, 300, 20, 9000.0, 250.0, STEP_MY_STEP, dict(reward_design=5)),          # more resources than any other kernel takes
+    (1024, 64, 40, 16000.0, 250.0, STEP_MY_STEP, {}),
+    (200, 200, 64, 3000.0, 250.0, STEP_MY_STEP, {}),                             # below the sizes, beyond the general kernel's LDS
+    (100, 16, 300, 2000.0, 250.0, STEP_MY_STEP, {}),                             # bins only
+    (64, 700, 20, 2000.0, 250.0, STEP_MY_STEP_CH, dict(reward_design=2)),        # resources only
+])
+def test_sizes_only_the_large_path_runs(N, A, K, L, rc, mode, kw):
+    cfg = bench_config(N, A, L, communication_range=rc,
+                       State=dict(num_bins=K, add_channel_obs=True, add_reward=True, add_index=True, add_position=True), **kw)
+    T = 8 if N >= 700 else 14
+    tp.random_rollout(cfg, B=2 if N >= 700 else 3, T=T, seed=1000 + N + A, mode=mode, sticky=0.5,
+                      track_prr=(mode == STEP_MY_STEP), expect_kernel=KERNEL_LARGE)
+
+
+def test_lanes_off_the_line_and_velocity_updates_at_400_vehicles():
+    cfg = bench_config(400, 50, 6000.0, mobility_vary=True, State=dict(add_velocity=True, add_position=True))
+    tp.random_rollout(cfg, B=2, T=30, seed=1400, vel_every=25, y0=_lanes, expect_kernel=KERNEL_LARGE)
+
+
+def test_secondary_observation_modes_at_300_vehicles():
+    """add_positional_dist (sorted true distances) and the type-1 histogram beyond 256 vehicles: posdist_kernel.hpp's
+    flat ranking and its literal statement."""
+    cfg = bench_config(300, 16, 5000.0, State=dict(add_positional_dist=True, add_positional_dist_type=1, num_bins=12))
+    tp.random_rollout(cfg, B=2, T=8, seed=1500, expect_kernel=KERNEL_LARGE)
+    cfg = bench_config(300, 16, 5000.0, State=dict(add_positional_dist=True))
+    tp.random_rollout(cfg, B=2, T=8, seed=1501, y0=_lanes, expect_kernel=KERNEL_LARGE)
+
+
+def test_2048_vehicles_two_slots():
+    """The table column of 2048 viewers in one wave's LDS (two columns per workgroup)."""
+    cfg = bench_config(2048, 128, 30000.0)
+    tp.random_rollout(cfg, B=1, T=3, seed=1600, expect_kernel=KERNEL_LARGE)
+
+
+def test_limits_of_the_large_path():
+    from diral_amd.config import ERR_UNSUPPORTED
+    from diral_amd.vec_env import DiralError, VecV2VEnv
+    for cfg in (bench_config(4097, 8, 50000.0), bench_config(64, 4097, 2000.0),
+                bench_config(300, 8, 5000.0, State=dict(piggybacking=True, add_channel_obs=True)),
+                bench_config(2000, 8, 30000.0, State=dict(add_positional_dist_type=1))):
+        with pytest.raises(Exception) as ei:
+            VecV2VEnv(cfg, batch=1, device="cuda:0")
+        assert getattr(ei.value, "status", ERR_UNSUPPORTED) == ERR_UNSUPPORTED, ei.value
+    env = VecV2VEnv(bench_config(4096, 16, 60000.0), batch=1, device="cuda:0")     # the largest env: 16.7 M table entries
+    rng = np.random.default_rng(5)
+    x0 = rng.integers(0, 60000, size=(1, 4096)).astype(np.float64)
+    env.reset_topology(x0, 0.0, rng.uniform(1.1, 2.7, size=(1, 4096)))
+    obs, rew, done = env.step(rng.integers(0, 16, size=(1, 4096)).astype(np.int32), 0)
+    torch.cuda.synchronize()
+    env.check()
+    assert env.last_kernel() == KERNEL_LARGE
+    assert obs.shape == (1, 4096, 36) and float(obs[0, :, :16].sum()) == 4096.0

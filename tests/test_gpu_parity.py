@@ -131,21 +131,25 @@ def test_golden_replay_on_gpu(name):
 
 
 def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=None, threads=8, track_prr=False,
-                   expect_kernel=None, force_general=False):
+                   expect_kernel=None, force_general=False, path=None, y0=None):
     """GPU vs oracle (IEEE squares) on B different random envs, T slots; returns
     the number of compared slots.  Everything must match bit for bit (exp()
     rewards within EXP_ATOL).  The specialised kernels serve every configuration they can
     (`expect_kernel`: assert which family ran); `force_general` pins the run to the general
-    kernel (DIRAL_OPT_KERNEL_PATH); track_prr: PRR metrics also in my_step (a build extension)."""
+    kernel (DIRAL_OPT_KERNEL_PATH), `path="large"` to the three launches of csrc/step_large.hpp (the only path beyond
+    256 vehicles / 256 resources / 64 bins); track_prr: PRR metrics also in my_step (a build extension); `y0`: a
+    function (rng, B, N) -> lanes (default: the one-lane highway the reference draws)."""
     from oracle.oracle import Oracle, SQ_IEEE
     rng = np.random.default_rng(seed)
     N, A, L = cfg.num_users, cfg.num_channels, cfg.highway_length
     cfg = cfg.replace(track_arrival=True, track_prr=track_prr)
     x0 = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
-    y0 = np.zeros((B, N))
+    y0 = np.zeros((B, N)) if y0 is None else y0(rng, B, N)
     v0 = np.full((B, N), 1.7) if cfg.mobility_vary else rng.uniform(1.1, 2.7, size=(B, N))
     env = make_env(cfg, B)
     env.force_general_kernel(force_general)
+    if path == "large":
+        env.force_large_path()
     env.reset_topology(x0, y0, v0)
     orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=threads)
     orc.reset(x0, y0, v0)
@@ -170,12 +174,12 @@ def random_rollout(cfg, B, T, seed, mode=STEP_MY_STEP, sticky=0.0, vel_every=Non
         if t % 6 == 4 and env.S > 0:
             # a stand-alone obtain_state with FOREIGN arguments (test_env.py:527-583 on the current tables):
             # diral_env_observe -> observe_kernel.hpp (the general kernel's observe mode when forced)
-            from diral_amd.config import KERNEL_GENERAL, KERNEL_OBSERVE
+            from diral_amd.config import KERNEL_GENERAL, KERNEL_LARGE, KERNEL_OBSERVE
             fa = rng.integers(0, A, size=(B, N)).astype(np.int32)
             fc = rng.uniform(0.0, 300.0, size=(B, N, cfg.chobs_width))
             fr = rng.uniform(-3.0, 1.0, size=(B, N))
             s1 = env.obtain_state(fc, fa, fr, 3.0, 0.25).cpu().numpy()
-            assert (env.last_kernel() & 15) == (KERNEL_GENERAL if force_general else KERNEL_OBSERVE)
+            assert (env.last_kernel() & 15) == (KERNEL_LARGE if (path == "large" or expect_kernel == KERNEL_LARGE) else (KERNEL_GENERAL if force_general else KERNEL_OBSERVE))
             s2 = orc.obtain_state(fa, fc, fr, 3.0, 0.25)
             assert np.array_equal(s1, s2), (t, np.argwhere(s1 != s2)[:5])
         if vel_every and t % vel_every == vel_every - 1:

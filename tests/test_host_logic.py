@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     from diral_amd.config import ABI_VERSION
     src = open(os.path.join(ROOT, "include", "diral_env.h")).read()
-    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 7
+    assert lib.diral_env_abi_version() == ABI_VERSION == int(re.search(r"#define DIRAL_ABI_VERSION (\d+)", src).group(1)) == 8
 
 
 def test_cfg_struct_layout_matches_header():
@@ -81,8 +81,16 @@ def test_host_validation_and_state_space():
     assert lib.diral_env_validate(ctypes.byref(ok)) == 0
     bad = c2_config().to_c(); bad.reward_design = 9
     assert lib.diral_env_validate(ctypes.byref(bad)) == -2
-    big = c2_config().to_c(); big.num_users = 257
-    assert lib.diral_env_validate(ctypes.byref(big)) == -3
+    # sizes: the reference has no limits (test_env.py:12-13, 40); beyond 256 vehicles / 256 resources / 64 bins the
+    # three-launch form (csrc/step_large.hpp) runs, up to 4096 / 4096 / 1024 while one env fits a workgroup's LDS
+    for n, a, k, want in ((257, 32, 20, 0), (4096, 4096, 20, 0), (4097, 32, 20, -3), (64, 4097, 20, -3), (64, 32, 1024, 0),
+                          (64, 32, 1025, -3), (200, 200, 64, 0)):
+        big = c2_config().to_c(); big.num_users = n; big.num_channels = a; big.num_bins = k
+        assert lib.diral_env_validate(ctypes.byref(big)) == want, (n, a, k)
+    pb = c2_config(State=dict(piggybacking=True, add_channel_obs=True)).to_c()
+    assert lib.diral_env_validate(ctypes.byref(pb)) == 0
+    pb.num_users = 300                                        # State.piggybacking stays on the one-workgroup sizes
+    assert lib.diral_env_validate(ctypes.byref(pb)) == -3
     short = c2_config().to_c(); short.struct_bytes = 4
     assert lib.diral_env_validate(ctypes.byref(short)) == -1
     assert b"action" in lib.diral_env_strerror(-6)
