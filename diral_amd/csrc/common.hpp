@@ -79,6 +79,8 @@ struct StepParams {
 struct LargeScratch {
   unsigned short* src;   // [B][A][N] gather source of (resource, viewer): the closest in-range transmitter, or the viewer itself
   uint32_t* cnt;         // [B][A] transmitters per resource
+  unsigned short* alist; // [B][A] the resources with at least one transmitter, ascending
+  uint32_t* nact;        // [B] how many
   double* px0;           // [B][N] positions the slot started with (the own stamp of periodic_update, vehicle.py:63)
   double* rew;           // [B][N] reward per vehicle
   double* rtx;           // [B][N] reception ratio per colliding transmitter (test_env.py:402-405)

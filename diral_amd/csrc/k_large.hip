@@ -11,9 +11,17 @@ hipError_t launch_large(const StepParams& p, const LargeScratch& g, hipStream_t 
   if (do_step || p.state_out)
     hipLaunchKernelGGL(large_search_kernel, dim3(p.B), dim3(kLargeThreads), large_lds_layout(p.N, p.A).total, s, p, g);
   if (do_step && piggy) {
-    const int w = large_merge_waves(p.N);
-    const unsigned nblk = (unsigned)((p.N + w - 1) / w);
-    hipLaunchKernelGGL(large_merge_kernel, dim3((unsigned)p.B * nblk), dim3(64 * w), large_merge_lds(p.N), s, p, g);
+    if (p.N <= 1024) {                                                // two columns per wave, keys in registers
+      const unsigned nblk = (unsigned)((((p.N + 1) >> 1) + 3) >> 2);
+      const dim3 grid((unsigned)p.B * nblk), block(256);
+      if (p.N <= 256) hipLaunchKernelGGL(large_merge2_kernel<4>, grid, block, large_merge2_lds(4), s, p, g);
+      else if (p.N <= 512) hipLaunchKernelGGL(large_merge2_kernel<8>, grid, block, large_merge2_lds(8), s, p, g);
+      else hipLaunchKernelGGL(large_merge2_kernel<16>, grid, block, large_merge2_lds(16), s, p, g);
+    } else {
+      const int w = large_merge_waves(p.N);
+      const unsigned nblk = (unsigned)((p.N + w - 1) / w);
+      hipLaunchKernelGGL(large_merge_kernel, dim3((unsigned)p.B * nblk), dim3(64 * w), large_merge_lds(p.N), s, p, g);
+    }
   }
   if (want_hist) {
     const int vw = large_hist_viewers(p.K);
@@ -29,6 +37,10 @@ hipError_t set_attr_large(int N, int A, int K) {
   if (r != hipSuccess) return r;
   r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)large_merge_lds(N));
+  if (r != hipSuccess) return r;
+  if (N <= 1024 && N > 512)
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_merge2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)large_merge2_lds(16));
   if (r != hipSuccess) return r;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(large_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)large_hist_lds(K));

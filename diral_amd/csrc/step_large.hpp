@@ -8,11 +8,12 @@
 //                         (Network.find_closest_tx, network.py:378-398), rewards, PRR, arrival stamps, the
 //                         move (network.py:189-206), and every column of the state vector that needs no
 //                         table; leaves the gather sources of the gossip merge in HBM (`src`, u16 [A][N])
-//   large_merge_kernel    one WAVE per table column (subject k): Vehicle.periodic_update + every
+//   large_merge2_kernel / large_merge_kernel
+//                         one WAVE per table column (subject k; two columns at N <= 1024): Vehicle.periodic_update + every
 //                         Vehicle.received_update of the slot (vehicle.py:35-70) as key[u] = max(key[u],
 //                         key[src_i(u)]) for the resources in ascending order, key = (sequence number, source
-//                         viewer) in 64 bits, the column in the wave's LDS (the wave's own LDS queue is in
-//                         order: no barrier); xpos follows the winning number from the source viewer's entry
+//                         viewer), the column in the wave's LDS (the wave's own LDS queue is in order: no
+//                         barrier); xpos follows the winning number from the source viewer's entry
 //   large_hist_kernel     one wave per 64 viewers (fewer for many bins): Network.dist_piggy +
 //                         get_positional_dist_2_piggy (network.py:538-558, 473-513), lane = viewer, its
 //                         histogram row private in LDS
@@ -60,6 +61,8 @@ __host__ __device__ inline uint32_t large_merge_lds(int N) {
   const uint32_t np = (uint32_t)((N + 63) & ~63);
   return (uint32_t)large_merge_waves(N) * (8u * np + 8u * (np / 64u));
 }
+// large_merge2_kernel<CH>: four waves, each 64 CH pair words + CH flag words (the slice large_merge_column needs)
+__host__ __device__ inline uint32_t large_merge2_lds(int ch) { return 4u * 8u * (uint32_t)(64 * ch + ch); }
 // viewers per workgroup of the histogram kernel: 64, fewer when the rows of K counters would not fit
 __host__ __device__ inline int large_hist_viewers(int K) {
   int vw = 64;
@@ -196,6 +199,17 @@ __global__ __launch_bounds__(kLargeThreads) void large_search_kernel(const StepP
       }
     }
     __syncthreads();
+    if (wave == 1) {                                                  // the used resources, ascending: what the merge walks
+      int n = 0;
+      for (int base = 0; base < A; base += 64) {
+        const int i = base + lane;
+        const bool used = i < A && s_off[i + 1] > s_off[i];
+        const unsigned long long m = __ballot(used);
+        if (used) g.alist[bA + n + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        n += __popcll(m);
+      }
+      if (lane == 0) g.nact[b] = (uint32_t)n;
+    }
 
     // ---- per resource: closest in-range transmitter per viewer, channel observation, rewards ----------------
     const bool want_obs = p.chobs_out != nullptr || (p.state_out != nullptr && p.off_chobs >= 0);
@@ -395,17 +409,12 @@ __global__ __launch_bounds__(kLargeThreads) void large_search_kernel(const StepP
   }
 }
 
-// One wave per table column.  grid = B * ceil(N / W), W = large_merge_waves(N) waves per workgroup.
-__global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, const LargeScratch g) {
-  extern __shared__ __align__(16) unsigned char smem[];
+// One table column (subject k of env b) by one wave, any N: 64-bit keys (sequence number, source viewer) in the wave's LDS
+// slice `key` [NP + NP / 64].
+__device__ inline void large_merge_column(const StepParams& p, const LargeScratch& g, int b, int k, int lane,
+                                          unsigned long long* key) {
   const int N = p.N, A = p.A, NV = p.NV;
   const int NP = (N + 63) & ~63;
-  const int W = large_merge_waves(N);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
- const int nblk = (N + W - 1) / W;
-  const int b = blockIdx.x / nblk, k = (blockIdx.x - b * nblk) * W + wave;
-  if (k >= N) return;                                                 // (no workgroup barrier below)
-  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + NP / 64);
   unsigned long long* s_msk = key + NP;
   double* xs = reinterpret_cast<double*>(key);
   const size_t bN = (size_t)b * N, bA = (size_t)b * A;
@@ -429,15 +438,32 @@ __global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, co
   wave_lds_order();
   // Vehicle.received_update (vehicle.py:35-47) for every (resource, receiver) in reference order: the transmitters of
   // resource i do not merge on i (test_env.py:204-209), so the entries read in step i are not written in step i
-  for (int i = 0; i < A; ++i) {
-    if (g.cnt[bA + i] == 0u) continue;
+  const int na = (int)g.nact[b];
+  for (int qa = 0; qa < na; ++qa) {
+    const int i = g.alist[bA + qa];
     const unsigned short* src = g.src + (bA + i) * N;
-    for (int vb = 0; vb < NP; vb += 64) {
-      const int u = vb + lane;
-      if (u < N) {
-        const int m = src[u];
-        const unsigned long long v = key[m], mine = key[u];
-        if (v > mine) key[u] = v;
+    // eight chunks of 64 viewers at a time: their sources, then their gathers, then their writes - one chunk after the
+    // other is a chain of round trips (HBM, LDS, LDS) per chunk
+    constexpr int G = 8;
+    for (int vb = 0; vb < NP; vb += 64 * G) {
+      int m[G];
+      unsigned long long v[G], mine[G];
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int u = vb + c * 64 + lane;
+        m[c] = u < N ? (int)src[u] : (u < NP ? u : NP - 1);
+      }
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int u = vb + c * 64 + lane;
+        v[c] = key[m[c]];
+        mine[c] = key[u < NP ? u : NP - 1];
+      }
+      wave_lds_order();
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int u = vb + c * 64 + lane;
+        if (u < N && v[c] > mine[c]) key[u] = v[c];
       }
     }
     wave_lds_order();
@@ -470,7 +496,130 @@ __global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, co
     const unsigned long long mk = s_msk[vb >> 6];
     if ((mk >> lane) & 1ull) p.tx[row + u] = xs[u];
   }
+  wave_lds_order();
   if (seq_ovf) atomicOr(p.err, kErrSeq);
+}
+
+// Any N: one wave per table column.  grid = B * ceil(N / W), W = large_merge_waves(N) waves per workgroup.
+__global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, const LargeScratch g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = p.N;
+  const int NP = (N + 63) & ~63;
+  const int W = large_merge_waves(N);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = (N + W - 1) / W;
+  const int b = blockIdx.x / nblk, k = (blockIdx.x - b * nblk) * W + wave;
+  if (k >= N) return;                                                 // (no workgroup barrier)
+  large_merge_column(p, g, b, k, lane, reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + NP / 64));
+}
+
+// N <= 64 CH (CH = 4, 8, 16): TWO columns per wave, the wave's own keys in registers, LDS only as the gather target.
+// A key is 32 bits: (rank << 12) | source viewer, rank = 2^20 - 1 - (the subject's own number - the entry's number), 0 for
+// a never-heard entry - the same order as the numbers while every heard entry lags its subject by less than 2^20 - 1
+// stamps; a column pair holding an older entry (imported tables) takes large_merge_column.  Per (resource, 64 viewers):
+// one 16-bit load (shared by the two columns), one ds_read_b64, two v_max_u32, one ds_write_b64; the next resource's
+// sources are in flight meanwhile.  grid = B * ceil(ceil(N / 2) / 4), 256 threads.
+constexpr unsigned int kLargeRankMax = (1u << 20) - 1u;
+template <int CH>
+__global__ __launch_bounds__(256) void large_merge2_kernel(const StepParams p, const LargeScratch g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NP = 64 * CH;
+  const int N = p.N, A = p.A, NV = p.NV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npair = (N + 1) >> 1, nblk = (npair + 3) >> 2;
+  const int b = blockIdx.x / nblk, k0 = 2 * ((blockIdx.x - b * nblk) * 4 + wave);
+  if (k0 >= N) return;                                                // (no workgroup barrier)
+  unsigned long long* const kl = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + CH);
+  const bool two = k0 + 1 < N;                                        // (the row k0 + 1 exists either way: NR is N rounded up to 16)
+  const size_t bN = (size_t)b * N, bA = (size_t)b * A;
+  const size_t row0 = ((size_t)b * p.NR + k0) * NV, row1 = row0 + NV;
+  const unsigned int tko0 = (p.tkey[row0 + k0] >> 8) + 1u;            // the subjects' own numbers behind this slot's stamp
+  const unsigned int tko1 = two ? (p.tkey[row1 + k0 + 1] >> 8) + 1u : 0u;
+  unsigned int key0[CH], key1[CH];
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int u = c * 64 + lane;
+    const bool in = u < N;
+    const unsigned int w0 = in ? p.tkey[row0 + u] : 0u, w1 = (in && two) ? p.tkey[row1 + u] : 0u;
+    const unsigned int s0 = (w0 >> 8) + (u == k0 ? 1u : 0u), s1 = (w1 >> 8) + ((two && u == k0 + 1) ? 1u : 0u);
+    const unsigned int l0 = tko0 - s0, l1 = tko1 - s1;
+    bad = bad || (s0 != 0u && l0 >= kLargeRankMax) || (s1 != 0u && l1 >= kLargeRankMax) || s0 >= (1u << 24) - 1u || s1 >= (1u << 24) - 1u;
+    key0[c] = ((s0 != 0u ? kLargeRankMax - l0 : 0u) << 12) | (unsigned int)u;
+    key1[c] = ((s1 != 0u ? kLargeRankMax - l1 : 0u) << 12) | (unsigned int)u;
+  }
+  if (__ballot(bad) != 0ull) {                                        // (uniform) old entries, or a number about to overflow: the 64-bit form
+    large_merge_column(p, g, b, k0, lane, kl);
+    if (two) large_merge_column(p, g, b, k0 + 1, lane, kl);
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) kl[c * 64 + lane] = ((unsigned long long)key1[c] << 32) | key0[c];
+  wave_lds_order();
+  const int na = (int)g.nact[b];
+  const unsigned short* const alist = g.alist + bA;
+  int m[CH], mn[CH];
+  auto load_src = [&](int qa, int (&dst)[CH]) {
+    const unsigned short* src = g.src + (bA + alist[qa]) * N;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int u = c * 64 + lane;
+      dst[c] = u < N ? (int)src[u] : u;
+    }
+  };
+  if (na > 0) load_src(0, m);
+  for (int qa = 0; qa < na; ++qa) {
+    if (qa + 1 < na) load_src(qa + 1, mn);
+    unsigned long long v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = kl[m[c]];
+    // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      key0[c] = max(key0[c], (unsigned int)v[c]);
+      key1[c] = max(key1[c], (unsigned int)(v[c] >> 32));
+      kl[c * 64 + lane] = ((unsigned long long)key1[c] << 32) | key0[c];
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) m[c] = mn[c];
+  }
+  // back to numbers; xpos from the source viewer's entry as the slot found it (every gather before the first store)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j == 1 && !two) break;
+    const int k = k0 + j;
+    const size_t row = j ? row1 : row0;
+    const unsigned int tko = j ? tko1 : tko0;
+    const double pxk = g.px0[bN + k];
+    double xg[CH];
+    unsigned long long wrm = 0ull;                                    // bit c: this lane writes the xpos of chunk c
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int u = c * 64 + lane;
+      xg[c] = 0.0;
+      if (u < N) {
+        const unsigned int w = p.tkey[row + u];
+        const bool own = u == k;
+        const unsigned int a0 = w & 255u;
+        const unsigned int so = (w >> 8) + (own ? 1u : 0u);
+        const unsigned int ws = (so << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));   // vehicle.py:56-70
+        const unsigned int kf = j ? key1[c] : key0[c];
+        const unsigned int rank = kf >> 12, sv = kf & 4095u;
+        const unsigned int seqf = rank ? tko - (kLargeRankMax - rank) : 0u;
+        const bool upd = seqf != so;
+        p.tkey[row + u] = upd ? (seqf << 8) : ws;
+        if (own) { xg[c] = pxk; wrm |= 1ull << c; }                  // vehicle.py:63
+        else if (upd) { xg[c] = (int)sv == k ? pxk : p.tx[row + sv]; wrm |= 1ull << c; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every old xpos is here before the first new one leaves
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if ((wrm >> c) & 1ull) p.tx[row + c * 64 + lane] = xg[c];
+    asm volatile("" ::: "memory");
+  }
 }
 
 // The type-2 piggybacked histogram of 64 (or fewer) viewers per wave.  grid = B * ceil(N / VW), 64 threads.

@@ -111,3 +111,48 @@ def test_limits_of_the_large_path():
     env.check()
     assert env.last_kernel() == KERNEL_LARGE
     assert obs.shape == (1, 4096, 36) and float(obs[0, :, :16].sum()) == 4096.0
+
+
+@pytest.mark.parametrize("N,A,L", [(40, 6, 1500.0), (300, 20, 6000.0), (1100, 30, 20000.0)])
+def test_entries_a_million_stamps_old_take_the_64_bit_merge(N, A, L):
+    """large_merge2_kernel orders entries by a 20-bit rank (how far the entry lags its subject); imported tables with
+    entries 2^20 stamps behind make the column pair fall back on the (number, source) keys of large_merge_column - and
+    beyond 1024 vehicles that form is the only one.  Tables, state and rewards against the oracle over 6 slots."""
+    from oracle.oracle import Oracle, SQ_IEEE
+    cfg = bench_config(N, A, L)
+    B = 2
+    rng = np.random.default_rng(4242 + N)
+    pos_x = rng.integers(0, int(L), size=(B, N)).astype(np.float64)
+    vel = rng.uniform(1.1, 2.7, size=(B, N))
+    T0 = 1_300_000
+    kind = rng.integers(0, 4, size=(B, N, N))                       # 0 never heard, 1 fresh, 2 a few stamps old, 3 ancient
+    lag = np.where(kind == 1, rng.integers(1, 4, size=(B, N, N)), np.where(kind == 2, rng.integers(4, 40, size=(B, N, N)),
+                                                                            rng.integers(1 << 20, 1_200_000, size=(B, N, N))))
+    seq = np.where(kind == 0, 0, T0 - lag).astype(np.int32)
+    # equal (subject, number) => equal xpos (what a run produces and import_state asks for): xpos a function of both
+    kk = np.broadcast_to(np.arange(N)[None, None, :], (B, N, N))
+    x = np.where(seq > 0, (kk * 7919 + seq.astype(np.int64) * 31) % int(L), 0).astype(np.float64)
+    age = np.where(kind == 0, 0, np.minimum(lag, 255)).astype(np.int32)
+    for u in range(N):
+        seq[:, u, u] = T0
+        age[:, u, u] = 0
+        x[:, u, u] = pos_x[:, u]
+    env = tp.make_env(cfg, B)
+    env.force_large_path()
+    env.reset_topology(pos_x, 0.0, vel)
+    env.import_state(pos_x, np.zeros((B, N)), vel, seq=seq, age=age, x=x)
+    orc = Oracle(cfg, batch=B, sq_mode=SQ_IEEE, threads=4)
+    orc.reset(pos_x, np.zeros((B, N)), vel)
+    orc.import_state(seq=seq, age=age, x=x, y=np.zeros((B, N, N)))
+    for t in range(6):
+        acts = rng.integers(0, A, size=(B, N)).astype(np.int32)
+        obs, rew, chobs, _ = tp.gpu_step(env, STEP_MY_STEP, acts, t)
+        assert env.last_kernel() == KERNEL_LARGE
+        o_rew, o_chobs = orc.step(STEP_MY_STEP, acts, t)
+        assert np.array_equal(rew, o_rew) and np.array_equal(chobs, o_chobs)
+        assert np.array_equal(obs, orc.obtain_state(acts, o_chobs, o_rew)), t
+        st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        oe = orc.export()
+        assert np.array_equal(st["seq"], oe["seq"]) and np.array_equal(st["x"], oe["x"]), t
+        assert np.array_equal(st["age"], np.minimum(oe["age"], 255)), t
+    env.check()
