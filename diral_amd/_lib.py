@@ -26,7 +26,7 @@ SYMBOLS = [
     "diral_env_export_entries", "diral_env_import_entries",
     "diral_env_set_clock", "diral_clock_add", "diral_sps_step_chobs_clocked", "diral_env_step_policy",
     "diral_env_set_capture_rotation", "diral_env_align_phase",
-    "diral_env_export_prev_obs", "diral_env_import_prev_obs",
+    "diral_env_export_prev_obs", "diral_env_import_prev_obs", "diral_env_prefill",
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def load() -> ctypes.CDLL:
         "diral_env_align_phase": (I, [P, I, P]),
         "diral_env_export_prev_obs": (I, [P, P, P]),
         "diral_env_import_prev_obs": (I, [P, P, P]),
+        "diral_env_prefill": (I, [P, P, I, U64, P, I, P, P, P, D, D, P]),
     }
     for name in SYMBOLS:
         try:

@@ -372,6 +372,8 @@ struct StepDispatch {
   const double* trace;
   bool extra;
   bool pol_ok;          // the POL instantiation of step_fast64 (policy epilogue inside the launch) takes this call
+  bool prefill_ok;      // ... and the K-slot form of it runs this configuration's random prefill (diral_env_prefill: my_step_design's
+                        // reward is computed in P2 there, so the design switch does not count against it)
 };
 StepDispatch step_dispatch(const DiralEnv* e, const StepParams& p) {
   StepDispatch d;
@@ -390,6 +392,7 @@ StepDispatch step_dispatch(const DiralEnv* e, const StepParams& p) {
   d.trace = d.nomove ? nullptr : p.trace;
   d.extra = d.design || d.la != nullptr || d.trace != nullptr || d.prr || d.notab || d.nomove;
   d.pol_ok = d.use_fast64 && e->flat_y && !d.ch && !d.extra && p.N >= 8;
+  d.prefill_ok = d.use_fast64 && e->flat_y && d.design && d.la == nullptr && d.trace == nullptr && !d.prr && !d.notab && !d.nomove && p.N >= 8;
   return d;
 }
 
@@ -461,7 +464,7 @@ hipError_t launch_step_any(DiralEnv* e, const StepParams& p, hipStream_t s, cons
     bool slow_first = false;
     // K slots per launch (diral_env_step_policy, DiralSlotPolicy::slots > 1): blocks = envs in order - over K slots a
     // straggler averages out; the slow-env sets stay as the last one-slot launch left them (complete or empty), unread
-    const bool kslots = pol && d.pol_ok && pol->K > 1;
+    const bool kslots = pol && ((d.pol_ok && pol->K > 1) || (pol->prefill && d.prefill_ok));
     // (step_wide: the packed form at N <= 128 only - its slow envs are 4 x the others; the plane form's are 1.6 x and measured
     // 4 % SLOWER dispatched first, N > 128 packed runs on dense topologies without any: - 0.7 % for the bookkeeping)
     // Round 6: with the far-entry guard (step_wide.hpp `wide_far_guard`) the flagged passes of a highway that broke apart run
@@ -1010,6 +1013,7 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   const int slots = pol->slots > 1 ? pol->slots : 1;
   q.K = slots; q.vel_vary = has(&e->cfg, DIRAL_F_MOBILITY_VARY) ? 1 : 0; q.vel_seed = pol->vel_seed;
   q.idx0 = (uint64_t)e->env_offset * (uint64_t)e->N; q.vel_w = e->vel;
+  q.prefill = 0; q.actions_all = nullptr; q.rew_in = nullptr;
   if (slots > 1 && (pol->draw_counter || pol->draw_keep || pol->draw_choice)) return DIRAL_ERR_BAD_ARG;
   // (decided before anything is launched: a caller without a channel-observation buffer can retry with one)
   const bool will_fuse = step_dispatch(e, p).pol_ok;
@@ -1029,6 +1033,32 @@ int diral_env_step_policy(DiralEnv* e, int mode, const int32_t* actions, int64_t
   return sps_step_chobs_impl(e->B * e->N, e->A, chobs_out, out_dtype, actions, pol->sps_prev_action, pol->sps_counter,
                              pol->rssi_threshold, pol->inc_db, pol->keep_prob, pol->draw_counter, pol->draw_keep,
                              pol->draw_choice, pol->seed, (const long long*)pol->seed_clock, pol->actions_out, stream);
+}
+
+int diral_env_prefill(DiralEnv* e, const int32_t* actions, int32_t slots, uint64_t seed, void* states_out, int out_dtype,
+                      int32_t* actions_all_out, int32_t* actions_next_out, const double* rew_in, double episode, double epsilon,
+                      void* stream) {
+  if (!e || !actions || !actions_next_out || slots < 1) return DIRAL_ERR_BAD_ARG;
+  if (out_dtype != DIRAL_F32 && out_dtype != DIRAL_F64) return DIRAL_ERR_BAD_ARG;
+  if (e->prev_obs) return DIRAL_ERR_BAD_CONFIG;                  // State.piggybacking: my_step only (diral_env_step)
+  // the secondary observation modes are launches of their own behind ONE state vector (posdist_kernel.hpp)
+  if (states_out && (has(&e->cfg, DIRAL_F_ADD_POSDIST) || (has(&e->cfg, DIRAL_F_ADD_POSDIST_PIGGY) && e->cfg.posdist_type == 1)))
+    return DIRAL_ERR_UNSUPPORTED;
+  DeviceGuard guard(e->device);
+  if (!guard.ok) return DIRAL_ERR_NO_DEVICE;
+  StepParams p = e->base;
+  p.mode = DIRAL_STEP_DESIGN; p.t = 0; p.episode = episode; p.eps = epsilon; p.out_f64 = (out_dtype == DIRAL_F64);
+  p.actions = actions;
+  p.state_out = e->S > 0 ? states_out : nullptr;
+  p.rew_out = nullptr; p.done_out = nullptr; p.chobs_out = nullptr; p.chobs_in = nullptr; p.rew_in = nullptr;
+  if (!step_dispatch(e, p).prefill_ok) return DIRAL_ERR_UNSUPPORTED;   // (nothing launched: the caller loops sample + step + observe)
+  PolParams q;
+  std::memset(&q, 0, sizeof(q));
+  q.K = slots; q.prefill = 1; q.seed = seed; q.idx0 = (uint64_t)e->env_offset * (uint64_t)e->N;
+  q.actions_out = actions_next_out; q.actions_all = actions_all_out; q.rew_in = rew_in; q.vel_w = e->vel;
+  bool fused = false;
+  HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream, &q, &fused));
+  return fused ? DIRAL_OK : DIRAL_ERR_HIP;
 }
 
 int diral_env_observe(DiralEnv* e, const int32_t* actions, const double* chobs_in, const double* rew_in,

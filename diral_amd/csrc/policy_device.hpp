@@ -35,6 +35,13 @@ struct PolParams {
   uint64_t vel_seed;             // ... device draws seeded vel_seed + episode index, as diral_env_update_velocity(env, NULL, seed)
   uint64_t idx0;                 // global index of agent 0 of env 0 (DIRAL_OPT_ENV_OFFSET * N): the draws are indexed globally
   double* vel_w;                 // [B][N] velocities (written back behind the last slot when vel_vary)
+  // The driver's random prefill (main_test.py:99-114: sample -> my_step_design -> obtain_state, every state kept) as the K
+  // slots of one launch (diral_env_prefill): the agents of slot ks + 1 act at random - diral_env_sample(seed + ks + 1) -,
+  // the reward is my_step_design's (network.py:122-157; P2), every slot's state vector leaves ([K][B][N][S]), its reward
+  // column taken from `rew_in` (the bootstrap step's rewards: main_test.py:110 hands obtain_state the stale `rews`)
+  int prefill;
+  int32_t* actions_all;          // [K][B][N] the actions slot ks ran with, or null
+  const double* rew_in;          // [B][N] or null (null: the slot's own reward)
 };
 
 // counter-based generator (splitmix64 finaliser over seed/stream/index); the

@@ -119,6 +119,29 @@ class DriverLoop:
             obs, _ = self.env.my_step_design(action, 0)
         return self._t(self.env.obtain_state(obs, action, self._rews0)).clone()
 
+    # main_test.py:99-114 as a whole: K random slots, every state kept (what the loop hands to memory.add)
+    def prefill(self, slots: int, seed: int):
+        """``for k in range(slots): a = env.sample(seed + k); states[k] = prefill_step(a)``: returns
+        ``(states [K, B, N, S], actions [K, B, N])``.  On the HIP env with `enable_channel` off this is ONE launch
+        (`VecV2VEnv.prefill` -> `diral_env_prefill`: the env stays on the chip for the K slots); configurations that
+        launch does not take - and any other env - run the loop."""
+        env = self.env
+        if not self.enable_channel and hasattr(env, "prefill"):
+            from .config import ERR_UNSUPPORTED
+            from .vec_env import DiralError
+            try:
+                states, acts, _ = env.prefill(env.sample(seed), slots, seed, rew_in=self._rews0)
+                return states, acts
+            except DiralError as exc:
+                if exc.status != ERR_UNSUPPORTED:
+                    raise
+        states, acts = [], []
+        for k in range(int(slots)):
+            a = env.sample(seed + k)
+            acts.append(self._t(a).clone())
+            states.append(self.prefill_step(a))
+        return torch.stack(states), torch.stack(acts)
+
     # main_test.py:119-236, everything between the agent's action and memory.add
     def slot(self, action, time_step: int, want_ia: Optional[bool] = None) -> Dict[str, Any]:
         env = self.env

@@ -304,6 +304,30 @@ class VecV2VEnv:
                  "diral_env_sample")
         return out
 
+    def prefill(self, actions: torch.Tensor, slots: int, seed: int, rew_in=None, want_states: bool = True,
+                episode: float = 0.0, eps: float = 1.0):
+        """The driver's random prefill (main_test.py:99-114) as ONE launch of `slots` slots (`diral_env_prefill`):
+        slot 0 runs `actions` ([B, N] int32, e.g. ``env.sample(seed)``), slot k the draw ``env.sample(seed + k)``
+        would make; every slot is ``my_step_design(a_k, 0)`` followed by ``obtain_state(obs, a_k, rew_in)``.
+        Returns ``(states [K, B, N, S] or None, actions_all [K, B, N], next_actions [B, N])``; `next_actions` is
+        the draw of ``seed + slots`` (pass it, with that seed, to continue).  Bit-equal to the loop of
+        sample + my_step_design + obtain_state calls.  Raises DiralError(ERR_UNSUPPORTED) with nothing launched for
+        configurations the fused kernel does not take (diral_amd.driver.DriverLoop.prefill loops then)."""
+        K = int(slots)
+        a = self._actions(actions)
+        states = torch.empty((K, self.B, self.N, self.S), dtype=self.out_dtype, device=self.device) if (want_states and self.S > 0) else None
+        a_all = torch.empty((K, self.B, self.N), dtype=torch.int32, device=self.device)
+        a_next = torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
+        rin = None if rew_in is None else self._f64(rew_in, (self.B, self.N))
+        self._spec = None
+        st = self.lib.diral_env_prefill(self._h, _ptr(a), K, int(seed) & (2**64 - 1), _ptr(states) if states is not None else None,
+                                        self._dt, _ptr(a_all), _ptr(a_next), _ptr(rin) if rin is not None else None,
+                                        float(episode), float(eps), self._stream())
+        self._ok(st, "diral_env_prefill")
+        if rin is not None:
+            torch.cuda.current_stream(self.device).synchronize()   # `rin` may be a temporary
+        return states, a_all, a_next
+
     def _step(self, mode: int, actions: torch.Tensor, t: int, episode: float = 0.0, eps: float = 1.0,
               want_chobs: bool = False, want_obs: bool = True, stream: Optional[ctypes.c_void_p] = None):
         if self.io_ring > 1:

@@ -457,6 +457,24 @@ int diral_env_step_policy(DiralEnv* env, int mode, const int32_t* actions, int64
                           uint8_t* done_out, void* chobs_out, int out_dtype, const DiralSlotPolicy* policy,
                           void* stream);
 
+/* The driver's random prefill (main_test.py:99-114) as ONE launch of K slots (ABI 8; step_fast64_slots_kernel):
+ *   for k = 0 .. K - 1:   a_k = (k == 0) ? actions : TestEnv.sample()          [diral_env_sample(env, ., seed + k, .)]
+ *                         obs, _ = my_step_design(a_k, 0)                        [test_env.py:269-349]
+ *                         states_out[k] = obtain_state(obs, a_k, rews)           [rews = rew_in: the bootstrap step's, :110]
+ * with the env kept on the chip from slot to slot.  Equal, bit for bit, to that loop of diral_env_sample +
+ * diral_env_step(DIRAL_STEP_DESIGN) + diral_env_observe calls: states, tables, positions, metrics.
+ *   actions [B][N]            slot 0's actions (e.g. diral_env_sample(env, actions, seed, stream))
+ *   states_out [K][B][N][S]   out dtype, or NULL (no state is built)
+ *   actions_all_out [K][B][N] a_k, or NULL          actions_next_out [B][N]  the draw of seed + K (mandatory: what the
+ *                                                    next call passes as `actions`, with seed + K)
+ *   rew_in [B][N] float64     the reward column of the state vectors (State.add_reward), or NULL: each slot's own reward
+ * Configurations the fused kernel takes - N <= 64 (>= 8), A <= 64, the one-lane highway, piggybacked tables, no arrival /
+ * PRR tracking, no trace replay, no secondary observation mode; otherwise DIRAL_ERR_UNSUPPORTED with nothing launched
+ * (loop over the three calls instead: diral_amd.driver.DriverLoop.prefill does). */
+int diral_env_prefill(DiralEnv* env, const int32_t* actions, int32_t slots, uint64_t seed, void* states_out, int out_dtype,
+                      int32_t* actions_all_out, int32_t* actions_next_out, const double* rew_in, double episode,
+                      double epsilon, void* stream);
+
 /* ---- slot clock: rollouts captured into a hipGraph ---------------------------------------------
  * A captured sequence of K slots (env step, reward shaping, policy) bakes every by-value argument into its
  * kernel nodes; what has to move on from replay to replay - the slot number behind `done`, arrival stamps and
