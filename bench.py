@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_PACKED, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
+from diral_amd.config import (KERNEL_CH, KERNEL_EXTRA, KERNEL_FAST64, KERNEL_LARGE, KERNEL_PACKED, KERNEL_RICH, KERNEL_WIDE,  # noqa: E402
                               bench_config)
 from diral_amd.metrics import gather_metrics  # noqa: E402
 from diral_amd.roofline import (HBM_ACHIEVABLE_GBPS, HBM_PEAK_GBPS, algorithmic_bytes_per_env_slot, memory_level,  # noqa: E402
@@ -54,6 +54,8 @@ WORKLOADS = {
     "c3": (256, 64, 4000.0, 8192, False),   # configs[2] congested
     "c5": (128, 64, 4000.0, 16384, True),   # configs[4] dynamic density
     "c4shard": (64, 32, 2000.0, 32768, False),   # configs[3]: the per-GPU share of 262144 envs over 8 GPUs
+    # beyond every BASELINE.json configuration: a size only the three-launch form runs (csrc/step_large.hpp; same density as c3)
+    "n1024": (1024, 64, 16000.0, 256, False),
 }
 PREROLL = 60      # untimed slots after every reset, before the requested warm-up (>= 50)
 PREROLL_SECONDS = 0.3   # ... and at least this long: a GPU coming out of idle needs tens of ms to reach its clocks
@@ -206,6 +208,9 @@ def kernel_name(code: int, N: int, out_dtype: str) -> str:
     def b(x):
         return "true" if x else "false"
     fam = code & 15
+    if fam == KERNEL_LARGE:
+        return "diral::large_search_kernel + diral::large_mergen_kernel<%s> + diral::large_hist_kernel" % (
+            "4,4" if N <= 256 else "8,2" if N <= 512 else "16,2") if N <= 1024 else "diral::large_search_kernel + diral::large_merge_kernel + diral::large_hist_kernel"
     o64, ch, extra, rich = out_dtype == "f64", bool(code & KERNEL_CH), bool(code & KERNEL_EXTRA), bool(code & KERNEL_RICH)
     if fam == KERNEL_FAST64:
         return "diral::step_fast64_kernel<true,%s,%s,%s,%s>" % (b(o64), b(ch), b(extra), b(rich))
@@ -834,7 +839,8 @@ def main() -> int:
         specs = [("c2_emit_chobs_%d" % (0 if emit else 1), "c2", dict(emit_chobs=not emit, steps=300)),
                  ("c4shard", "c4shard", dict(emit_chobs=emit, steps=100)),
                  ("c3", "c3", dict(emit_chobs=emit, steps=40)),
-                 ("c5", "c5", dict(emit_chobs=emit, steps=60))]
+                 ("c5", "c5", dict(emit_chobs=emit, steps=60)),
+                 ("n1024_three_launch_form", "n1024", dict(emit_chobs=emit, steps=10))]
         for key, wl, kw in specs:
             if args.workload != "c2" or args.batch:
                 break

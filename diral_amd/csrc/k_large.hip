@@ -9,14 +9,15 @@ hipError_t launch_large(const StepParams& p, const LargeScratch& g, hipStream_t 
   const bool piggy = (p.flags & DIRAL_F_ADD_POSDIST_PIGGY) != 0;
   const bool want_hist = piggy && p.posdist_type == 2 && p.state_out != nullptr && p.off_hist >= 0;
   if (do_step || p.state_out)
-    hipLaunchKernelGGL(large_search_kernel, dim3(p.B), dim3(kLargeThreads), large_lds_layout(p.N, p.A).total, s, p, g);
+    hipLaunchKernelGGL(large_search_kernel, dim3(p.B), dim3(large_search_threads(p.N)), large_lds_layout(p.N, p.A).total, s, p, g);
   if (do_step && piggy) {
-    if (p.N <= 1024) {                                                // two columns per wave, keys in registers
-      const unsigned nblk = (unsigned)((((p.N + 1) >> 1) + 3) >> 2);
+    if (p.N <= 1024) {                                                // two / four columns per wave, keys in registers
+      const int nc = p.N <= 256 ? 4 : 2;   // (four columns at N <= 512 measured slower: 144 VGPRs, three waves per SIMD - 6.1 -> 6.7 ms at 512 / 64)
+      const unsigned nblk = (unsigned)((((p.N + nc - 1) / nc) + 3) >> 2);
       const dim3 grid((unsigned)p.B * nblk), block(256);
-      if (p.N <= 256) hipLaunchKernelGGL(large_merge2_kernel<4>, grid, block, large_merge2_lds(4), s, p, g);
-      else if (p.N <= 512) hipLaunchKernelGGL(large_merge2_kernel<8>, grid, block, large_merge2_lds(8), s, p, g);
-      else hipLaunchKernelGGL(large_merge2_kernel<16>, grid, block, large_merge2_lds(16), s, p, g);
+      if (p.N <= 256) hipLaunchKernelGGL((large_mergen_kernel<4, 4>), grid, block, large_mergen_lds(4, 4), s, p, g);
+      else if (p.N <= 512) hipLaunchKernelGGL((large_mergen_kernel<8, 2>), grid, block, large_mergen_lds(8, 2), s, p, g);
+      else hipLaunchKernelGGL((large_mergen_kernel<16, 2>), grid, block, large_mergen_lds(16, 2), s, p, g);
     } else {
       const int w = large_merge_waves(p.N);
       const unsigned nblk = (unsigned)((p.N + w - 1) / w);
@@ -39,8 +40,11 @@ hipError_t set_attr_large(int N, int A, int K) {
                           (int)large_merge_lds(N));
   if (r != hipSuccess) return r;
   if (N <= 1024 && N > 512)
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_merge2_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)large_merge2_lds(16));
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)large_mergen_lds(16, 2));
+  else if (N <= 512 && N > 256)
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)large_mergen_lds(8, 2));
   if (r != hipSuccess) return r;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(large_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)large_hist_lds(K));

@@ -8,8 +8,8 @@
 //                         (Network.find_closest_tx, network.py:378-398), rewards, PRR, arrival stamps, the
 //                         move (network.py:189-206), and every column of the state vector that needs no
 //                         table; leaves the gather sources of the gossip merge in HBM (`src`, u16 [A][N])
-//   large_merge2_kernel / large_merge_kernel
-//                         one WAVE per table column (subject k; two columns at N <= 1024): Vehicle.periodic_update + every
+//   large_mergen_kernel / large_merge_kernel
+//                         one WAVE per table column (subject k; four columns at N <= 256, two at N <= 1024): Vehicle.periodic_update + every
 //                         Vehicle.received_update of the slot (vehicle.py:35-70) as key[u] = max(key[u],
 //                         key[src_i(u)]) for the resources in ascending order, key = (sequence number, source
 //                         viewer), the column in the wave's LDS (the wave's own LDS queue is in order: no
@@ -27,8 +27,8 @@
 
 namespace diral {
 
-constexpr int kLargeThreads = 1024;          // large_search_kernel: 16 waves
-constexpr int kLargeWaves = kLargeThreads / 64;
+constexpr int kLargeMaxThreads = 1024;       // large_search_kernel: 4 ... 16 waves by the env's size
+__host__ __device__ inline int large_search_threads(int N) { return N <= 256 ? 256 : (N <= 512 ? 512 : 1024); }
 constexpr uint32_t kLargeMergeLdsBudget = 64u * 1024u;
 
 struct LargeLds {
@@ -61,8 +61,13 @@ __host__ __device__ inline uint32_t large_merge_lds(int N) {
   const uint32_t np = (uint32_t)((N + 63) & ~63);
   return (uint32_t)large_merge_waves(N) * (8u * np + 8u * (np / 64u));
 }
-// large_merge2_kernel<CH>: four waves, each 64 CH pair words + CH flag words (the slice large_merge_column needs)
-__host__ __device__ inline uint32_t large_merge2_lds(int ch) { return 4u * 8u * (uint32_t)(64 * ch + ch); }
+// large_mergen_kernel<CH, NC>: four waves, each 64 CH key vectors of NC words - and never less than the 64 CH + CH 64-bit
+// words large_merge_column needs when it takes the slice over
+__host__ __device__ inline uint32_t large_mergen_slice(int ch, int nc) {
+  const uint32_t a = 4u * (uint32_t)nc * 64u * (uint32_t)ch, b = 8u * (uint32_t)(64 * ch + ch);
+  return align_up(a > b ? a : b, 16);
+}
+__host__ __device__ inline uint32_t large_mergen_lds(int ch, int nc) { return 4u * large_mergen_slice(ch, nc); }
 // viewers per workgroup of the histogram kernel: 64, fewer when the rows of K counters would not fit
 __host__ __device__ inline int large_hist_viewers(int K) {
   int vw = 64;
@@ -101,8 +106,9 @@ __device__ inline int large_reward_weight(const StepParams& p, const unsigned sh
   return m > p.Rc;
 }
 
-__global__ __launch_bounds__(kLargeThreads) void large_search_kernel(const StepParams p, const LargeScratch g) {
+__global__ __launch_bounds__(kLargeMaxThreads) void large_search_kernel(const StepParams p, const LargeScratch g) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const int kLargeThreads = (int)blockDim.x, kLargeWaves = kLargeThreads >> 6;
   const LargeLds lay = large_lds_layout(p.N, p.A);
   double* s_px = reinterpret_cast<double*>(smem + lay.px);
   double* s_py = reinterpret_cast<double*>(smem + lay.py);
@@ -513,48 +519,60 @@ __global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, co
   large_merge_column(p, g, b, k, lane, reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + NP / 64));
 }
 
-// N <= 64 CH (CH = 4, 8, 16): TWO columns per wave, the wave's own keys in registers, LDS only as the gather target.
+// N <= 64 CH (CH = 4, 8, 16): NC = 2 or 4 columns per wave, the wave's own keys in registers, LDS only as the gather target.
 // A key is 32 bits: (rank << 12) | source viewer, rank = 2^20 - 1 - (the subject's own number - the entry's number), 0 for
 // a never-heard entry - the same order as the numbers while every heard entry lags its subject by less than 2^20 - 1
-// stamps; a column pair holding an older entry (imported tables) takes large_merge_column.  Per (resource, 64 viewers):
-// one 16-bit load (shared by the two columns), one ds_read_b64, two v_max_u32, one ds_write_b64; the next resource's
-// sources are in flight meanwhile.  grid = B * ceil(ceil(N / 2) / 4), 256 threads.
+// stamps; a column group holding an older entry (imported tables) takes large_merge_column.  Per (resource, 64 viewers):
+// one 16-bit load (shared by the NC columns), one ds_read_b64 / b128, NC v_max_u32, one ds_write_b64 / b128; the next
+// resource's sources are in flight meanwhile.  grid = B * ceil(ceil(N / NC) / 4), 256 threads.
 constexpr unsigned int kLargeRankMax = (1u << 20) - 1u;
-template <int CH>
-__global__ __launch_bounds__(256) void large_merge2_kernel(const StepParams p, const LargeScratch g) {
+template <int NC> struct LargeKeyVec;
+template <> struct LargeKeyVec<2> { typedef uint2 type; };
+template <> struct LargeKeyVec<4> { typedef uint4 type; };
+__device__ inline unsigned int large_kv(const uint2& v, int j) { return j ? v.y : v.x; }
+__device__ inline unsigned int large_kv(const uint4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+__device__ inline uint2 large_mk(const unsigned int (&k)[2]) { return make_uint2(k[0], k[1]); }
+__device__ inline uint4 large_mk(const unsigned int (&k)[4]) { return make_uint4(k[0], k[1], k[2], k[3]); }
+template <int CH, int NC>
+__global__ __launch_bounds__(256) void large_mergen_kernel(const StepParams p, const LargeScratch g) {
+  typedef typename LargeKeyVec<NC>::type kv_t;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NP = 64 * CH;
   const int N = p.N, A = p.A, NV = p.NV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int npair = (N + 1) >> 1, nblk = (npair + 3) >> 2;
-  const int b = blockIdx.x / nblk, k0 = 2 * ((blockIdx.x - b * nblk) * 4 + wave);
+  const int ngrp = (N + NC - 1) / NC, nblk = (ngrp + 3) >> 2;
+  const int b = blockIdx.x / nblk, k0 = NC * ((blockIdx.x - b * nblk) * 4 + wave);
   if (k0 >= N) return;                                                // (no workgroup barrier)
-  unsigned long long* const kl = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (NP + CH);
-  const bool two = k0 + 1 < N;                                        // (the row k0 + 1 exists either way: NR is N rounded up to 16)
+  // the wave's slice: NP key vectors (as large_merge_column's 64-bit form: at least 8 NP + 8 CH bytes)
+  unsigned char* const slice = smem + (size_t)wave * large_mergen_slice(CH, NC);
+  kv_t* const kl = reinterpret_cast<kv_t*>(slice);
+  const int ncol = N - k0 < NC ? N - k0 : NC;                         // (the rows k0 .. k0 + NC - 1 exist either way: NR is N rounded up to 16)
   const size_t bN = (size_t)b * N, bA = (size_t)b * A;
-  const size_t row0 = ((size_t)b * p.NR + k0) * NV, row1 = row0 + NV;
-  const unsigned int tko0 = (p.tkey[row0 + k0] >> 8) + 1u;            // the subjects' own numbers behind this slot's stamp
-  const unsigned int tko1 = two ? (p.tkey[row1 + k0 + 1] >> 8) + 1u : 0u;
-  unsigned int key0[CH], key1[CH];
+  const size_t row0 = ((size_t)b * p.NR + k0) * NV;
+  unsigned int tko[NC];                                               // the subjects' own numbers behind this slot's stamp
+#pragma unroll
+  for (int j = 0; j < NC; ++j) tko[j] = j < ncol ? (p.tkey[row0 + (size_t)j * NV + k0 + j] >> 8) + 1u : 0u;
+  unsigned int key[CH][NC];
   bool bad = false;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int u = c * 64 + lane;
     const bool in = u < N;
-    const unsigned int w0 = in ? p.tkey[row0 + u] : 0u, w1 = (in && two) ? p.tkey[row1 + u] : 0u;
-    const unsigned int s0 = (w0 >> 8) + (u == k0 ? 1u : 0u), s1 = (w1 >> 8) + ((two && u == k0 + 1) ? 1u : 0u);
-    const unsigned int l0 = tko0 - s0, l1 = tko1 - s1;
-    bad = bad || (s0 != 0u && l0 >= kLargeRankMax) || (s1 != 0u && l1 >= kLargeRankMax) || s0 >= (1u << 24) - 1u || s1 >= (1u << 24) - 1u;
-    key0[c] = ((s0 != 0u ? kLargeRankMax - l0 : 0u) << 12) | (unsigned int)u;
-    key1[c] = ((s1 != 0u ? kLargeRankMax - l1 : 0u) << 12) | (unsigned int)u;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const unsigned int w = (in && j < ncol) ? p.tkey[row0 + (size_t)j * NV + u] : 0u;
+      const unsigned int sq = (w >> 8) + ((j < ncol && u == k0 + j) ? 1u : 0u);
+      const unsigned int lg = tko[j] - sq;
+      bad = bad || (sq != 0u && lg >= kLargeRankMax) || sq >= (1u << 24) - 1u;
+      key[c][j] = ((sq != 0u ? kLargeRankMax - lg : 0u) << 12) | (unsigned int)u;
+    }
   }
   if (__ballot(bad) != 0ull) {                                        // (uniform) old entries, or a number about to overflow: the 64-bit form
-    large_merge_column(p, g, b, k0, lane, kl);
-    if (two) large_merge_column(p, g, b, k0 + 1, lane, kl);
+    for (int j = 0; j < ncol; ++j) large_merge_column(p, g, b, k0 + j, lane, reinterpret_cast<unsigned long long*>(slice));
     return;
   }
 #pragma unroll
-  for (int c = 0; c < CH; ++c) kl[c * 64 + lane] = ((unsigned long long)key1[c] << 32) | key0[c];
+  for (int c = 0; c < CH; ++c) kl[c * 64 + lane] = large_mk(key[c]);
   wave_lds_order();
   const int na = (int)g.nact[b];
   const unsigned short* const alist = g.alist + bA;
@@ -570,16 +588,16 @@ __global__ __launch_bounds__(256) void large_merge2_kernel(const StepParams p, c
   if (na > 0) load_src(0, m);
   for (int qa = 0; qa < na; ++qa) {
     if (qa + 1 < na) load_src(qa + 1, mn);
-    unsigned long long v[CH];
+    kv_t v[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) v[c] = kl[m[c]];
     // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
     wave_lds_order();
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      key0[c] = max(key0[c], (unsigned int)v[c]);
-      key1[c] = max(key1[c], (unsigned int)(v[c] >> 32));
-      kl[c * 64 + lane] = ((unsigned long long)key1[c] << 32) | key0[c];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) key[c][j] = max(key[c][j], large_kv(v[c], j));
+      kl[c * 64 + lane] = large_mk(key[c]);
     }
     wave_lds_order();
 #pragma unroll
@@ -587,14 +605,13 @@ __global__ __launch_bounds__(256) void large_merge2_kernel(const StepParams p, c
   }
   // back to numbers; xpos from the source viewer's entry as the slot found it (every gather before the first store)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (j == 1 && !two) break;
+  for (int j = 0; j < NC; ++j) {
+    if (j >= ncol) break;
     const int k = k0 + j;
-    const size_t row = j ? row1 : row0;
-    const unsigned int tko = j ? tko1 : tko0;
+    const size_t row = row0 + (size_t)j * NV;
     const double pxk = g.px0[bN + k];
     double xg[CH];
-    unsigned long long wrm = 0ull;                                    // bit c: this lane writes the xpos of chunk c
+    unsigned int wrm = 0u;                                            // bit c: this lane writes the xpos of chunk c
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int u = c * 64 + lane;
@@ -605,19 +622,19 @@ __global__ __launch_bounds__(256) void large_merge2_kernel(const StepParams p, c
         const unsigned int a0 = w & 255u;
         const unsigned int so = (w >> 8) + (own ? 1u : 0u);
         const unsigned int ws = (so << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));   // vehicle.py:56-70
-        const unsigned int kf = j ? key1[c] : key0[c];
+        const unsigned int kf = key[c][j];
         const unsigned int rank = kf >> 12, sv = kf & 4095u;
-        const unsigned int seqf = rank ? tko - (kLargeRankMax - rank) : 0u;
+        const unsigned int seqf = rank ? tko[j] - (kLargeRankMax - rank) : 0u;
         const bool upd = seqf != so;
         p.tkey[row + u] = upd ? (seqf << 8) : ws;
-        if (own) { xg[c] = pxk; wrm |= 1ull << c; }                  // vehicle.py:63
-        else if (upd) { xg[c] = (int)sv == k ? pxk : p.tx[row + sv]; wrm |= 1ull << c; }
+        if (own) { xg[c] = pxk; wrm |= 1u << c; }                    // vehicle.py:63
+        else if (upd) { xg[c] = (int)sv == k ? pxk : p.tx[row + sv]; wrm |= 1u << c; }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every old xpos is here before the first new one leaves
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if ((wrm >> c) & 1ull) p.tx[row + c * 64 + lane] = xg[c];
+      if ((wrm >> c) & 1u) p.tx[row + c * 64 + lane] = xg[c];
     asm volatile("" ::: "memory");
   }
 }

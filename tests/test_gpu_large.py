@@ -156,3 +156,43 @@ def test_entries_a_million_stamps_old_take_the_64_bit_merge(N, A, L):
         assert np.array_equal(st["seq"], oe["seq"]) and np.array_equal(st["x"], oe["x"]), t
         assert np.array_equal(st["age"], np.minimum(oe["age"], 255)), t
     env.check()
+
+
+def test_float32_outputs_and_a_closed_loop_on_a_320_vehicle_handle():
+    """float32 outputs = the float32 cast of the float64 ones (the arithmetic is float64 either way); the SPS closed
+    loop (`step_policy`, here the three-launch form: env step with the channel observation, reward shaping, the agents'
+    decisions) and a rollout captured into a hipGraph run on such a handle like on any other."""
+    from diral_amd.rollout import GraphRollout
+    from diral_amd.sps import SpsPolicy
+    from diral_amd.vec_env import VecV2VEnv
+    N, A, B = 320, 24, 3
+    cfg = bench_config(N, A, 6000.0, State=dict(add_channel_obs=True, add_reward=True, add_position=True))
+    e64 = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float64)
+    e32 = VecV2VEnv(cfg, batch=B, device="cuda:0", out_dtype=torch.float32)
+    for e in (e64, e32):
+        e.reset_topology(seed=3)
+    for t in range(12):
+        a = e64.sample(50 + t)
+        o64, r64, _ = e64.step(a, t)
+        o32, r32, _ = e32.step(a, t)
+        assert e32.last_kernel() == KERNEL_LARGE
+        assert torch.equal(o32, o64.to(torch.float32)) and torch.equal(r32, r64.to(torch.float32)), t
+    runs = []
+    for capture in (False, True):
+        env = VecV2VEnv(bench_config(N, A, 6000.0), batch=B, device="cuda:0", io_ring=2)
+        env.reset_topology(seed=8)
+        pol = SpsPolicy(B, N, A, device="cuda:0", seed=6)
+        runs.append((env, pol, GraphRollout(env, pol, K=4, capture=capture, fused=True)))
+    (e1, p1, r1), (e2, p2, r2) = runs
+    r1.run(5)
+    r2.run(4)                                                        # (the capture itself ran the K slots once)
+    torch.cuda.synchronize()
+    assert r1.slots == r2.slots == 20
+    assert e1.last_kernel() == KERNEL_LARGE
+    a, b = e1.export_state(), e2.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(p1.prev_action, p2.prev_action) and torch.allclose(e1.metrics(), e2.metrics(), rtol=1e-12, atol=1e-9)
+    for e, _, r in runs:
+        e.check()
+        r.close()
