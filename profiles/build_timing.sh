@@ -8,5 +8,5 @@ mkdir -p variants_tmp/obj_timing
 for tu in diral_env k_fast64 k_wide2 k_wide4; do $CC -c diral_amd/csrc/$tu.hip -o variants_tmp/obj_timing/$tu.o & done
 wait
 $CC -shared variants_tmp/obj_timing/diral_env.o variants_tmp/obj_timing/k_fast64.o variants_tmp/obj_timing/k_wide2.o variants_tmp/obj_timing/k_wide4.o \
-  diral_amd/build/k_general.o diral_amd/build/k_observe.o -o variants_tmp/lib_timing.so
+  diral_amd/build/k_general.o diral_amd/build/k_observe.o diral_amd/build/k_large.o -o variants_tmp/lib_timing.so
 ls -la variants_tmp/lib_timing.so

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; FLAGS=$2; shift 2
 mkdir -p variants_tmp/obj_$NAME
 OBJS=""
-for tu in diral_env k_fast64 k_wide2 k_wide4 k_general k_observe; do
+for tu in diral_env k_fast64 k_wide2 k_wide4 k_general k_observe k_large; do
   if [[ " $* " == *" $tu "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC $FLAGS \
       -c diral_amd/csrc/$tu.hip -o variants_tmp/obj_$NAME/$tu.o &

@@ -4,7 +4,7 @@
 #   bash profiles/resource_usage.sh [out.txt] [extra -D flags...]
 OUT=${1:-/dev/stdout}; shift
 cd "$(dirname "$0")/.."
-for tu in k_fast64 k_wide2 k_wide4 k_general k_observe diral_env; do
+for tu in k_fast64 k_wide2 k_wide4 k_general k_observe k_large diral_env; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC "$@" \
     -Rpass-analysis=kernel-resource-usage -c diral_amd/csrc/$tu.hip -o /dev/null 2>&1 |
   python3 -c '

@@ -34,6 +34,8 @@ if [ -f variants_tmp/lib_timing.so ]; then
   for B in 64 4096; do echo "=== B=$B"; B=$B DIRAL_LIB=$PWD/variants_tmp/lib_timing.so python profiles/phase_timing.py 2>&1 | grep -v amdgpu | head -10; done > gpurun_out/phase_timing_r06.txt
 fi
 python profiles/kslots_bench.py 2>&1 | grep -v amdgpu > gpurun_out/kslots_r06.txt
+python profiles/prefill_bench.py 2>&1 | grep -v amdgpu > gpurun_out/prefill_r06.txt
+python profiles/large_path_bench.py 2>&1 | grep -v amdgpu > gpurun_out/large_path_r06.txt
 # C5: the two table forms of 64 < N <= 128, the packed one with and without its slow envs dispatched first; how many passes leave the codes
 (for F in plane packed; do for S in 0 1; do [ $F = plane ] && [ $S = 0 ] && continue; for i in 1 2; do
   DIRAL_NO_SLOW_FIRST=$S DIRAL_TABLE_FORM=$F python bench.py --workload c5 --lean --steps 100 --warmup 20 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 form=$F NO_SLOW_FIRST=$S: %.4f ms/step' % d['ms_per_step'], d['roofline'].get('kernel'))"
@@ -49,7 +51,9 @@ fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_secondary -o t -- env WORKLOADS=c2,c5,c3 python $GRAFT_REPO_ROOT/profiles/secondary_modes.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_rollout -o t -- python $GRAFT_REPO_ROOT/profiles/rollout_lines.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_large -o t -- python $GRAFT_REPO_ROOT/profiles/large_path_prof.py 1024 64 16000 256 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_large -name "*_kernel_trace.csv" | xargs rm -f
 find gpurun_out/prof_secondary gpurun_out/prof_rollout -name "*_kernel_trace.csv" | xargs rm -f
 for t in c2_chobs1 c2_chobs0 c3_chobs1 c3_chobs0 c5_chobs1 c5_chobs0 c4shard; do echo "== $t"; grep "steady state" gpurun_out/prof_$t/summary.txt; done
 cat gpurun_out/rollout_r06.txt gpurun_out/scale_r06.txt
