@@ -27,7 +27,7 @@ hipError_t launch_large(const StepParams& p, const LargeScratch& g, hipStream_t 
   if (want_hist) {
     const int vw = large_hist_viewers(p.K);
     const unsigned nblk = (unsigned)((p.N + vw - 1) / vw);
-    hipLaunchKernelGGL(large_hist_kernel, dim3((unsigned)p.B * nblk), dim3(64), large_hist_lds(p.K), s, p);
+    hipLaunchKernelGGL(large_hist_kernel, dim3((unsigned)p.B * nblk), dim3(64 * kLargeHistWaves), large_hist_lds(p.K), s, p);
   }
   return hipGetLastError();
 }

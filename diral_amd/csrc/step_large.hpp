@@ -14,9 +14,9 @@
 //                         key[src_i(u)]) for the resources in ascending order, key = (sequence number, source
 //                         viewer), the column in the wave's LDS (the wave's own LDS queue is in order: no
 //                         barrier); xpos follows the winning number from the source viewer's entry
-//   large_hist_kernel     one wave per 64 viewers (fewer for many bins): Network.dist_piggy +
-//                         get_positional_dist_2_piggy (network.py:538-558, 473-513), lane = viewer, its
-//                         histogram row private in LDS
+//   large_hist_kernel     one workgroup per 64 viewers (fewer for many bins): Network.dist_piggy +
+//                         get_positional_dist_2_piggy (network.py:538-558, 473-513), lane = viewer, four waves
+//                         sharing the subjects, each lane's histogram row private in LDS
 // The tables are the (seq << 8 | age) and xpos planes of common.hpp.  Columns are independent (tx rows
 // are read-only within a resource, a receiver writes its own row), so the merge spreads over B x N waves where the
 // one-workgroup kernels have B workgroups: at N = 1024 that is what fills the chip.
@@ -71,11 +71,11 @@ __host__ __device__ inline uint32_t large_mergen_lds(int ch, int nc) { return 4u
 // viewers per workgroup of the histogram kernel: 64, fewer when the rows of K counters would not fit
 __host__ __device__ inline int large_hist_viewers(int K) {
   int vw = 64;
-  while (vw > 1 && (uint32_t)vw * 4u * (uint32_t)(K | 1) > 64u * 1024u) vw >>= 1;
+  while (vw > 1 && 4u * (uint32_t)vw * 4u * (uint32_t)(K | 1) > 96u * 1024u) vw >>= 1;   // four waves' rows
   return vw;
 }
 __host__ __device__ inline uint32_t large_hist_lds(int K) {
-  return 8u * (uint32_t)(K + 2) + 4u * 64u + (uint32_t)large_hist_viewers(K) * 4u * (uint32_t)(K | 1);
+  return 8u * (uint32_t)(K + 2) + 4u * 4u * 64u + 4u * (uint32_t)large_hist_viewers(K) * 4u * (uint32_t)(K | 1);
 }
 
 // Network.calculate_reward_weights (network.py:273-300) over the ascending transmitter list of one resource;
@@ -533,8 +533,10 @@ __device__ inline unsigned int large_kv(const uint2& v, int j) { return j ? v.y 
 __device__ inline unsigned int large_kv(const uint4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 __device__ inline uint2 large_mk(const unsigned int (&k)[2]) { return make_uint2(k[0], k[1]); }
 __device__ inline uint4 large_mk(const unsigned int (&k)[4]) { return make_uint4(k[0], k[1], k[2], k[3]); }
+// (waves per SIMD the register allocation is held to: left alone the compiler takes 108 VGPRs for <8, 2> - four waves -
+// where 80 do: 512 / 64 / B = 1024 7.0 -> 6.1 ms)
 template <int CH, int NC>
-__global__ __launch_bounds__(256) void large_mergen_kernel(const StepParams p, const LargeScratch g) {
+__global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_kernel(const StepParams p, const LargeScratch g) {
   typedef typename LargeKeyVec<NC>::type kv_t;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NP = 64 * CH;
@@ -639,29 +641,32 @@ __global__ __launch_bounds__(256) void large_mergen_kernel(const StepParams p, c
   }
 }
 
-// The type-2 piggybacked histogram of 64 (or fewer) viewers per wave.  grid = B * ceil(N / VW), 64 threads.
-__global__ __launch_bounds__(64) void large_hist_kernel(const StepParams p) {
+// The type-2 piggybacked histogram of 64 (or fewer) viewers per workgroup: four waves share the subjects (wave w takes k = w,
+// w + 4, ...: B * N / 64 waves alone are four per SIMD at 1024 vehicles - too few to cover the table loads), each with its
+// own rows of counters, added up behind one barrier.  grid = B * ceil(N / VW), 256 threads.
+constexpr int kLargeHistWaves = 4;
+__global__ __launch_bounds__(64 * kLargeHistWaves) void large_hist_kernel(const StepParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = p.N, K = p.K, NV = p.NV, KP = K | 1;
   const int VW = large_hist_viewers(K);
   double* s_edges = reinterpret_cast<double*>(smem);
-  unsigned int* s_n = reinterpret_cast<unsigned int*>(smem + 8u * (K + 2));
-  unsigned int* s_hist = s_n + 64;
-  const int lane = threadIdx.x;
+  unsigned int* s_n = reinterpret_cast<unsigned int*>(smem + 8u * (K + 2));       // [waves][64]
+  unsigned int* s_hist = s_n + 64 * kLargeHistWaves;                              // [waves][VW][KP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = (N + VW - 1) / VW;
   const int b = blockIdx.x / nblk, vb0 = (blockIdx.x - b * nblk) * VW;
   const int u = vb0 + lane;
   const bool mine = lane < VW && u < N;
   const size_t bN = (size_t)b * N, bR = (size_t)b * p.NR;
-  for (int j = lane; j <= K; j += 64) s_edges[j] = p.edges[j];
-  for (int j = lane; j < VW * KP; j += 64) s_hist[j] = 0u;
-  wave_lds_order();
+  for (int j = tid; j <= K; j += 64 * kLargeHistWaves) s_edges[j] = p.edges[j];
+  for (int j = tid; j < kLargeHistWaves * VW * KP; j += 64 * kLargeHistWaves) s_hist[j] = 0u;
+  __syncthreads();
   const double x2 = mine ? p.pos_x[bN + u] : 0.0, y2 = mine ? p.pos_y[bN + u] : 0.0;
-  unsigned int* hrow = s_hist + lane * KP;
+  unsigned int* hrow = s_hist + ((size_t)wave * VW + lane) * KP;
   unsigned int cnt = 0u;
   const size_t col = mine ? (size_t)u : 0;
 #pragma unroll 4
-  for (int k = 0; k < N; ++k) {
+  for (int k = wave; k < N; k += kLargeHistWaves) {
     const size_t idx = (bR + k) * NV + col;
     const unsigned int w = p.tkey[idx];
     const double x1 = p.tx[idx];
@@ -677,12 +682,14 @@ __global__ __launch_bounds__(64) void large_hist_kernel(const StepParams p) {
       }
     }
   }
-  s_n[lane] = cnt;
-  wave_lds_order();
+  s_n[wave * 64 + lane] = cnt;
+  __syncthreads();
   const int rows = min(VW, N - vb0);
-  for (int e = lane; e < rows * K; e += 64) {
+  for (int e = tid; e < rows * K; e += 64 * kLargeHistWaves) {
     const int r = e / K, j = e - r * K;
-    const unsigned int n = s_n[r], h = s_hist[r * KP + j];
+    unsigned int n = 0u, h = 0u;
+#pragma unroll
+    for (int w = 0; w < kLargeHistWaves; ++w) { n += s_n[w * 64 + r]; h += s_hist[((size_t)w * VW + r) * KP + j]; }
     const double val = n ? (double)h / (double)n : 0.0;                // network.py:501
     store_out(p.state_out, (bN + vb0 + r) * p.S + p.off_hist + j, val, p.out_f64);
   }

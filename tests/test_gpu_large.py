@@ -196,3 +196,48 @@ def test_float32_outputs_and_a_closed_loop_on_a_320_vehicle_handle():
     for e, _, r in runs:
         e.check()
         r.close()
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_configuration_on_the_large_path(i):
+    """tests/test_gpu_fuzz.py's generator - every State flag, reward design, step kind, static and design topologies,
+    State blocks without piggybacked tables, both secondary observation modes, proportional fairness - with the handle
+    pinned to the three-launch form: against the oracle, PRR metrics tracked on odd draws."""
+    from diral_amd.config import ConfigError
+    from tests.test_gpu_fuzz import draw_case
+    cfg, mode, sticky, vel_every = draw_case(i)
+    if not (cfg.mobility or cfg.enable_design_topology):
+        cfg = cfg.replace(enable_design_topology=True)
+    cfg.validate()
+    tp.random_rollout(cfg, B=3 if cfg.num_users > 64 else 8, T=20, seed=300 + i, mode=mode, sticky=sticky,
+                      vel_every=vel_every or None, threads=8, track_prr=bool(i & 1), path="large", expect_kernel=KERNEL_LARGE)
+
+
+def draw_large_case(i):
+    rng = np.random.default_rng(12000 + i)
+    N = int(rng.choice([257, 300, 333, 400, 512, 513, 640]))
+    A = int(rng.choice([1, 5, 32, 64, 100, 257, 300]))
+    K = int(rng.choice([1, 20, 64, 65, 130]))
+    mode = int(rng.choice([STEP_MY_STEP, STEP_MY_STEP, STEP_MY_STEP_CH, STEP_DESIGN]))
+    rd = int(rng.choice([2, 3, 4])) if mode == STEP_MY_STEP_CH else int(rng.integers(1, 6))
+    L = float(rng.choice([8.0, 20.0, 40.0]) * N + rng.integers(20, 200))
+    state = dict(type=2, add_reward=bool(rng.random() < 0.4), add_action=bool(rng.random() < 0.8),
+                 add_index=bool(rng.random() < 0.3), add_velocity=bool(rng.random() < 0.3),
+                 action_index=str(rng.choice(["binary", "real"])), add_position=bool(rng.random() < 0.3),
+                 add_positional_dist=bool(rng.random() < 0.2), add_positional_dist_piggy=bool(rng.random() < 0.85),
+                 add_positional_dist_type=int(rng.choice([1, 2, 2, 2])), num_bins=K,
+                 add_channel_obs=bool(rng.random() < 0.4))
+    cfg = bench_config(N, A, L, reward_design=rd, State=state, mobility_vary=bool(rng.random() < 0.4),
+                       enable_fingerprint=bool(rng.random() < 0.3),
+                       proportional_fair=bool(rng.random() < 0.2 and mode == STEP_MY_STEP),
+                       communication_range=float(rng.choice([30.0, 120.0, 250.0])),
+                       bin_range=float(rng.choice([100.0, 500.0])))
+    return cfg, mode, float(rng.choice([0.0, 0.5, 0.9])), int(rng.choice([0, 5]))
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_configuration_beyond_256_vehicles(i):
+    cfg, mode, sticky, vel_every = draw_large_case(i)
+    cfg.validate()
+    tp.random_rollout(cfg, B=2, T=11, seed=700 + i, mode=mode, sticky=sticky, vel_every=vel_every or None, threads=8,
+                      track_prr=bool(i & 1), expect_kernel=KERNEL_LARGE)
