@@ -59,9 +59,9 @@ __device__ inline void piggy_store(void* base, size_t idx, double v, int f64) {
 __global__ void piggy_search_kernel(PiggyParams p) {
   const int b = blockIdx.x, N = p.N, A = p.A;
   const size_t bN = (size_t)b * N;
-  // the env's actions and positions once into LDS (N <= DIRAL_MAX_USERS): every (receiver, resource) pair walks all of them
-  __shared__ int32_t act[DIRAL_MAX_USERS];
-  __shared__ double px[DIRAL_MAX_USERS], py[DIRAL_MAX_USERS];
+  // the env's actions and positions once into LDS (N <= DIRAL_SMALL_MAX_USERS: State.piggybacking stays on the one-workgroup sizes): every (receiver, resource) pair walks all of them
+  __shared__ int32_t act[DIRAL_SMALL_MAX_USERS];
+  __shared__ double px[DIRAL_SMALL_MAX_USERS], py[DIRAL_SMALL_MAX_USERS];
   for (int u = threadIdx.x; u < N; u += blockDim.x) {
     act[u] = p.actions[bN + u];
     px[u] = p.pos_x[bN + u];
