@@ -569,6 +569,47 @@ def rollout_sps_kslots(device, envs=4096, K=25, launches=16, warm=4, want_obs=Fa
             "collision_fraction": float(m[3] / (m[2] + m[3]))}
 
 
+def prefill_kslots(device, K=25, reps=8):
+    """The driver's random prefill (main_test.py:99-114: sample -> my_step_design -> obtain_state, every state kept) as ONE
+    launch of K slots (`diral_env_prefill`) beside the loop of [diral_env_sample + one fused design step] it replaces, at
+    C2's shape; bit-equal to that loop (tests/test_gpu_prefill.py)."""
+    from diral_amd import c2_config
+    from diral_amd.config import KERNEL_POLICY, STEP_DESIGN
+    out = {"what": "random prefill, %d slots per launch (diral_env_prefill) vs the loop of sample + fused my_step_design step; "
+                   "us per slot, every slot's state vector written" % K}
+    for envs in (1024, 4096):
+        env = VecV2VEnv(c2_config(), batch=envs, device=device, out_dtype=torch.float32)
+        env.reset_topology(seed=GLOBAL_SEED)
+        for t in range(PREROLL):
+            env.step(env.sample(t), t)
+        nxt = [env.sample(0)]
+
+        def launch(seed):
+            _, _, nxt[0] = env.prefill(nxt[0], K, seed)
+
+        def loop(seed):
+            for k in range(K):
+                env._step(STEP_DESIGN, env.sample(seed + k), 0)
+
+        res = {}
+        for name, fn in (("one_launch", launch), ("loop", loop)):
+            fn(0)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for r in range(reps):
+                fn(1000 * (r + 1))
+            torch.cuda.synchronize(device)
+            res[name + "_us_per_slot"] = (time.perf_counter() - t0) / (reps * K) * 1e6
+            if name == "one_launch":
+                assert env.last_kernel() & KERNEL_POLICY
+        env.check()
+        res["agent_steps_per_s"] = envs * env.N / (res["one_launch_us_per_slot"] * 1e-6)
+        out["envs_%d" % envs] = res
+        del env
+        torch.cuda.empty_cache()
+    return out
+
+
 def c2_graph(device, envs=4096, K=24, replays=42):
     """The headline step (c2: state + reward + channel observation, iid-uniform actions from a ring of K action tensors)
     with K slots captured into ONE hipGraph (slot number on the device: diral_env_set_clock) and replayed: what is left of
@@ -877,6 +918,7 @@ def main() -> int:
                 also["rollout_sps_fused_chobs"] = rollout_sps_fused(device, write_chobs=True)
                 also["rollout_sps_kslots"] = rollout_sps_kslots(device)
                 also["rollout_sps_kslots_state"] = rollout_sps_kslots(device, K=5, launches=80, warm=16, want_obs=True)
+                also["prefill_kslots"] = prefill_kslots(device)
                 also["c2_graph"] = c2_graph(device)
                 torch.cuda.empty_cache()
                 also["secondary_observation_modes"] = secondary_modes(device)
