@@ -81,6 +81,9 @@ struct LargeScratch {
   uint32_t* cnt;         // [B][A] transmitters per resource
   unsigned short* alist; // [B][A] the resources with at least one transmitter, ascending
   uint32_t* nact;        // [B] how many
+  unsigned char* qflag;  // [B][ceil(N / 2)] per column PAIR: != 0 = it holds (held, as a hint for the next slot) an entry the
+                         // thermometer codes do not reach - the rank-keyed merge takes it (large_mergec_kernel /
+                         // large_mergen_kernel<CH, 2> write and read)
   double* px0;           // [B][N] positions the slot started with (the own stamp of periodic_update, vehicle.py:63)
   double* rew;           // [B][N] reward per vehicle
   double* rtx;           // [B][N] reception ratio per colliding transmitter (test_env.py:402-405)

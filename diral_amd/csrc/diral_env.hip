@@ -76,7 +76,7 @@ struct DiralEnv {
   int32_t* txid = nullptr;
   // num_users > 256 / num_channels > 256 / num_bins > 64 (step_large.hpp): no one-workgroup kernel holds such an env
   bool large = false;
-  LargeScratch lg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  LargeScratch lg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long* dbg = nullptr;   // DIRAL_TIMING builds: [B][waves][8] timestamps
   bool capture_violation = false;   // a ring <-> plane switch was asked for inside a stream capture
   std::string last_hip_error;
@@ -343,7 +343,7 @@ hipError_t alloc_large_scratch(DiralEnv* e) {
   const size_t bn = (size_t)e->B * e->N, ba = (size_t)e->B * e->A;
   struct { void** p; size_t bytes; } bufs[] = {
     {(void**)&e->lg.src, ba * e->N * 2}, {(void**)&e->lg.cnt, ba * 4}, {(void**)&e->lg.alist, ba * 2},
-    {(void**)&e->lg.nact, (size_t)e->B * 4}, {(void**)&e->lg.px0, bn * 8},
+    {(void**)&e->lg.nact, (size_t)e->B * 4}, {(void**)&e->lg.qflag, (size_t)e->B * ((e->N + 1) / 2) + 16}, {(void**)&e->lg.px0, bn * 8},
     {(void**)&e->lg.rew, bn * 8}, {(void**)&e->lg.rtx, bn * 8}};
   for (auto& q : bufs) {
     hipError_t r = hipMalloc(q.p, q.bytes);
@@ -871,7 +871,7 @@ int diral_env_destroy(DiralEnv* e) {
   if (!e) return DIRAL_OK;
   DeviceGuard guard(e->device);
   void* ptrs[] = {e->pos_x, e->pos_y, e->vel, e->tkey, e->tx, e->ring, e->tcode, e->tage, e->tseq, e->told, e->slow, e->la, e->pf, e->metrics, e->err, e->edges, e->edges1, e->inv_tab, e->trace, e->yflag,
-                  e->prev_obs, e->obs_new, e->txid, e->dbg, e->lg.src, e->lg.cnt, e->lg.alist, e->lg.nact, e->lg.px0, e->lg.rew, e->lg.rtx};
+                  e->prev_obs, e->obs_new, e->txid, e->dbg, e->lg.src, e->lg.cnt, e->lg.alist, e->lg.nact, e->lg.qflag, e->lg.px0, e->lg.rew, e->lg.rtx};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   delete e;
   return DIRAL_OK;

@@ -11,13 +11,24 @@ hipError_t launch_large(const StepParams& p, const LargeScratch& g, hipStream_t 
   if (do_step || p.state_out)
     hipLaunchKernelGGL(large_search_kernel, dim3(p.B), dim3(large_search_threads(p.N)), large_lds_layout(p.N, p.A).total, s, p, g);
   if (do_step && piggy) {
-    if (p.N <= 1024) {                                                // two / four columns per wave, keys in registers
-      const int nc = p.N <= 256 ? 4 : 2;   // (four columns at N <= 512 measured slower: 144 VGPRs, three waves per SIMD - 6.1 -> 6.7 ms at 512 / 64)
-      const unsigned nblk = (unsigned)((((p.N + nc - 1) / nc) + 3) >> 2);
-      const dim3 grid((unsigned)p.B * nblk), block(256);
-      if (p.N <= 256) hipLaunchKernelGGL((large_mergen_kernel<4, 4>), grid, block, large_mergen_lds(4, 4), s, p, g);
-      else if (p.N <= 512) hipLaunchKernelGGL((large_mergen_kernel<8, 2>), grid, block, large_mergen_lds(8, 2), s, p, g);
-      else hipLaunchKernelGGL((large_mergen_kernel<16, 2>), grid, block, large_mergen_lds(16, 2), s, p, g);
+    if (p.N <= 1024) {
+      // four columns per wave on thermometer codes (tables that stay fresh); the quads it flags - an entry 8 or more stamps
+      // behind - on (rank, source) keys, two columns per wave, behind it
+      const unsigned nquad = (unsigned)((p.N + 3) >> 2), cblk = (nquad + 3) >> 2;
+      const unsigned npair = (unsigned)((p.N + 1) >> 1), rblk = (npair + 3) >> 2;
+      const dim3 cgrid((unsigned)p.B * cblk), rgrid((unsigned)p.B * rblk), block(256);
+      if (p.N <= 256) {
+        hipLaunchKernelGGL((large_mergec_kernel<4>), cgrid, block, large_mergec_lds(4), s, p, g);
+        hipLaunchKernelGGL((large_mergen_kernel<4, 2, true>), rgrid, block, large_mergen_lds(4, 2), s, p, g);
+      } else if (p.N <= 512) {
+        hipLaunchKernelGGL((large_mergec_kernel<8>), cgrid, block, large_mergec_lds(8), s, p, g);
+        hipLaunchKernelGGL((large_mergen_kernel<8, 2, true>), rgrid, block, large_mergen_lds(8, 2), s, p, g);
+      } else {
+        // (512 < N <= 1024: the rank keys alone.  The codes form at 16 chunks per lane runs at 128 VGPRs with 23 spilled and
+        // measured no gain where it applies - 1024 / 512: 23.7 -> 27.2 ms, 1024 / 64: 6.5 -> 6.8 - and a highway that long
+        // keeps entries about far vehicles for more than 7 stamps anyway)
+        hipLaunchKernelGGL((large_mergen_kernel<16, 2, false>), rgrid, block, large_mergen_lds(16, 2), s, p, g);
+      }
     } else {
       const int w = large_merge_waves(p.N);
       const unsigned nblk = (unsigned)((p.N + w - 1) / w);
@@ -40,10 +51,10 @@ hipError_t set_attr_large(int N, int A, int K) {
                           (int)large_merge_lds(N));
   if (r != hipSuccess) return r;
   if (N <= 1024 && N > 512)
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<16, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)large_mergen_lds(16, 2));
   else if (N <= 512 && N > 256)
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(large_mergen_kernel<8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)large_mergen_lds(8, 2));
   if (r != hipSuccess) return r;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(large_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -9,7 +9,7 @@
 //                         move (network.py:189-206), and every column of the state vector that needs no
 //                         table; leaves the gather sources of the gossip merge in HBM (`src`, u16 [A][N])
 //   large_mergen_kernel / large_merge_kernel
-//                         one WAVE per table column (subject k; four columns at N <= 256, two at N <= 1024): Vehicle.periodic_update + every
+//                         one WAVE per table column (subject k; four columns on thermometer codes at N <= 512 where the table is fresh, two on rank keys up to 1024): Vehicle.periodic_update + every
 //                         Vehicle.received_update of the slot (vehicle.py:35-70) as key[u] = max(key[u],
 //                         key[src_i(u)]) for the resources in ascending order, key = (sequence number, source
 //                         viewer), the column in the wave's LDS (the wave's own LDS queue is in order: no
@@ -68,6 +68,8 @@ __host__ __device__ inline uint32_t large_mergen_slice(int ch, int nc) {
   return align_up(a > b ? a : b, 16);
 }
 __host__ __device__ inline uint32_t large_mergen_lds(int ch, int nc) { return 4u * large_mergen_slice(ch, nc); }
+// large_mergec_kernel<CH>: four waves, each 64 CH code words + the [4][8] xpos table
+__host__ __device__ inline uint32_t large_mergec_lds(int ch) { return 4u * 4u * (uint32_t)(64 * ch + 64); }
 // viewers per workgroup of the histogram kernel: 64, fewer when the rows of K counters would not fit
 __host__ __device__ inline int large_hist_viewers(int K) {
   int vw = 64;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kLargeMaxThreads) void large_search_kernel(const St
   short* s_act = reinterpret_cast<short*>(smem + lay.act);
   unsigned short* s_list = reinterpret_cast<unsigned short*>(smem + lay.list);
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, A = p.A, K = p.K;
   const int NP = (N + 63) & ~63;
   const int mode = p.mode;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, co
   const int N = p.N;
   const int NP = (N + 63) & ~63;
   const int W = large_merge_waves(N);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform for the compiler too: scalar row bases)
   const int nblk = (N + W - 1) / W;
   const int b = blockIdx.x / nblk, k = (blockIdx.x - b * nblk) * W + wave;
   if (k >= N) return;                                                 // (no workgroup barrier)
@@ -535,16 +537,21 @@ __device__ inline uint2 large_mk(const unsigned int (&k)[2]) { return make_uint2
 __device__ inline uint4 large_mk(const unsigned int (&k)[4]) { return make_uint4(k[0], k[1], k[2], k[3]); }
 // (waves per SIMD the register allocation is held to: left alone the compiler takes 108 VGPRs for <8, 2> - four waves -
 // where 80 do: 512 / 64 / B = 1024 7.0 -> 6.1 ms)
-template <int CH, int NC>
+// GATED: the launch behind large_mergec_kernel - only the flagged column pairs, and the hint for the next slot at the end
+template <int CH, int NC, bool GATED>
 __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_kernel(const StepParams p, const LargeScratch g) {
+  static_assert(!GATED || NC == 2, "the flags are per column pair");
   typedef typename LargeKeyVec<NC>::type kv_t;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NP = 64 * CH;
   const int N = p.N, A = p.A, NV = p.NV;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform for the compiler too: scalar row bases)
   const int ngrp = (N + NC - 1) / NC, nblk = (ngrp + 3) >> 2;
   const int b = blockIdx.x / nblk, k0 = NC * ((blockIdx.x - b * nblk) * 4 + wave);
   if (k0 >= N) return;                                                // (no workgroup barrier)
+  // behind large_mergec_kernel (NC == 2): only the column pairs of the quads it left alone (an entry beyond the codes)
+  unsigned char* const my_flag = g.qflag + (size_t)b * ((N + 1) >> 1) + (k0 >> 1);
+  if constexpr (GATED) { if (*my_flag == 0) return; }
   // the wave's slice: NP key vectors (as large_merge_column's 64-bit form: at least 8 NP + 8 CH bytes)
   unsigned char* const slice = smem + (size_t)wave * large_mergen_slice(CH, NC);
   kv_t* const kl = reinterpret_cast<kv_t*>(slice);
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_ker
   }
   if (__ballot(bad) != 0ull) {                                        // (uniform) old entries, or a number about to overflow: the 64-bit form
     for (int j = 0; j < ncol; ++j) large_merge_column(p, g, b, k0 + j, lane, reinterpret_cast<unsigned long long*>(slice));
-    return;
+    return;                                                           // (the pair stays flagged for the next slot)
   }
 #pragma unroll
   for (int c = 0; c < CH; ++c) kl[c * 64 + lane] = large_mk(key[c]);
@@ -606,6 +613,7 @@ __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_ker
     for (int c = 0; c < CH; ++c) m[c] = mn[c];
   }
   // back to numbers; xpos from the source viewer's entry as the slot found it (every gather before the first store)
+  bool stale = false;
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     if (j >= ncol) break;
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_ker
         const unsigned int kf = key[c][j];
         const unsigned int rank = kf >> 12, sv = kf & 4095u;
         const unsigned int seqf = rank ? tko[j] - (kLargeRankMax - rank) : 0u;
+        if constexpr (GATED) stale = stale || (rank != 0u && kLargeRankMax - rank >= 7u);   // the next slot's stamp takes it beyond the codes
         const bool upd = seqf != so;
         p.tkey[row + u] = upd ? (seqf << 8) : ws;
         if (own) { xg[c] = pxk; wrm |= 1u << c; }                    // vehicle.py:63
@@ -638,6 +647,138 @@ __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_ker
     for (int c = 0; c < CH; ++c)
       if ((wrm >> c) & 1u) p.tx[row + c * 64 + lane] = xg[c];
     asm volatile("" ::: "memory");
+  }
+  // the hint large_mergec_kernel reads next slot: does this pair still hold an entry its codes would not reach
+  if constexpr (GATED) {
+    const bool st = __ballot(stale) != 0ull;
+    if (lane == 0) *my_flag = st ? 1 : 0;
+  }
+}
+
+// N <= 512, the common case of a table that stays fresh: FOUR columns per wave as ONE 32-bit word per viewer - byte j the
+// thermometer code of the entry's lag behind subject k0 + j, (0xff << lag) & 0xff for lag 0 ... 7, 0 = never heard
+// (step_fast64.hpp's codes, derived here from the (seq << 8 | age) plane every slot).  The codes of one subject form a chain
+// under bit inclusion, so Vehicle.received_update (vehicle.py:35-47) is a bitwise OR of words: per (resource, 64 viewers) one
+// 16-bit load shared by the four columns, one ds_read_b32 gather, one v_or_b32, one ds_write_b32 - a quarter of the LDS
+// bytes of the rank keys, whose gathers pace large_mergen_kernel.  xpos is a function of (subject, number): the pre-slot
+// entries of a column fill an 8-entry table [lag] in LDS (every viewer writes its own entry's xpos to the slot of its lag:
+// equal lags carry equal xpos), a changed entry reads it there.  A quad with a heard entry 8 or more stamps behind is left
+// untouched and flagged (`qflag`, per column pair): large_mergen_kernel<CH, 2, true> runs behind this launch for exactly those,
+// and leaves a hint for the next slot - a pair that still holds such an entry is not looked at here again until it is fresh.
+// grid = B * ceil(ceil(N / 4) / 4), 256 threads.
+template <int CH>
+__global__ __launch_bounds__(256, (CH <= 8 ? 6 : 4)) void large_mergec_kernel(const StepParams p, const LargeScratch g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NP = 64 * CH;
+  const int N = p.N, A = p.A, NV = p.NV;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform for the compiler too: scalar row bases)
+  const int nquad = (N + 3) >> 2, nblk = (nquad + 3) >> 2;
+  const int b = blockIdx.x / nblk, q = (blockIdx.x - b * nblk) * 4 + wave, k0 = 4 * q;
+  if (k0 >= N) return;                                                // (no workgroup barrier)
+  // one flag per column PAIR (what a wave of large_mergen_kernel<CH, 2> owns).  As this launch finds them they are last
+  // slot's hints: a pair that still held an entry 7 or more stamps behind after its merge (large_mergen_kernel's last
+  // statement) cannot be clean now - the quad goes to the rank keys without a look at its words.  (Hints only: any value
+  // is correct, a wrong one costs the detour.)
+  unsigned char* const qf = g.qflag + (size_t)b * ((N + 1) >> 1) + 2 * q;
+  const bool two_pairs = k0 + 2 < N;
+  if ((qf[0] | (two_pairs ? qf[1] : 0)) != 0) {
+    if (lane == 0) { qf[0] = 1; if (two_pairs) qf[1] = 1; }
+    return;
+  }
+  unsigned int* const kl = reinterpret_cast<unsigned int*>(smem) + (size_t)wave * (NP + 64);
+  double* const xtab = reinterpret_cast<double*>(kl + NP);            // [4][8] xpos by (column, lag)
+  const int ncol = N - k0 < 4 ? N - k0 : 4;                           // (the rows k0 .. k0 + 3 exist either way: NR is N rounded up to 16)
+  const size_t bN = (size_t)b * N, bA = (size_t)b * A;
+  const size_t row0 = ((size_t)b * p.NR + k0) * NV;
+  unsigned int tko[4];                                                // the subjects' own numbers behind this slot's stamp
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tko[j] = j < ncol ? (p.tkey[row0 + (size_t)j * NV + k0 + j] >> 8) + 1u : 0u;
+  unsigned int code[CH];
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int u = c * 64 + lane;
+    const bool in = u < N;
+    unsigned int cw = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = in && j < ncol;
+      const unsigned int w = live ? p.tkey[row0 + (size_t)j * NV + u] : 0u;
+      const unsigned int sq = (w >> 8) + ((live && u == k0 + j) ? 1u : 0u);   // Vehicle.periodic_update, vehicle.py:56-70
+      const unsigned int lg = tko[j] - sq;
+      const bool heard = sq != 0u;
+      bad = bad || (heard && lg > 7u) || sq >= (1u << 24) - 1u;
+      cw |= (heard ? ((0xffu << (lg & 7u)) & 0xffu) : 0u) << (8 * j);
+      // the xpos this number carries, for whoever receives it in this slot (lag 0 is the subject's own stamp)
+      if (live && heard && lg >= 1u && lg <= 7u) xtab[j * 8 + lg] = p.tx[row0 + (size_t)j * NV + u];
+    }
+    code[c] = cw;
+    // (four chunks' loads in flight at a time: all 16 x 8 of a 1024-vehicle quad cost 59 spilled VGPRs and 345 SGPRs)
+    if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+  const bool flagged = __ballot(bad) != 0ull;
+  if (lane == 0) { qf[0] = flagged ? 1 : 0; if (two_pairs) qf[1] = flagged ? 1 : 0; }
+  if (flagged) return;                                                // (uniform; nothing of the quad has been written)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) kl[c * 64 + lane] = code[c];
+  wave_lds_order();
+  const int na = (int)g.nact[b];
+  const unsigned short* const alist = g.alist + bA;
+  int m[CH], mn[CH];
+  auto load_src = [&](int qa, int (&dst)[CH]) {
+    const unsigned short* src = g.src + (bA + alist[qa]) * N;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int u = c * 64 + lane;
+      dst[c] = u < N ? (int)src[u] : u;
+    }
+  };
+  if (na > 0) load_src(0, m);
+  for (int qa = 0; qa < na; ++qa) {
+    if (qa + 1 < na) load_src(qa + 1, mn);
+    unsigned int v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = kl[m[c]];
+    // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      code[c] |= v[c];
+      kl[c * 64 + lane] = code[c];
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) m[c] = mn[c];
+  }
+  // back to numbers and ages; a changed entry takes the xpos of its new number.  (One column at a time, the loop rolled:
+  // unrolled four times the 1024-vehicle form spilled 47 VGPRs and 354 SGPRs.)
+#pragma unroll 1
+  for (int j = 0; j < ncol; ++j) {
+    const int k = k0 + j;
+    const size_t row = row0 + (size_t)j * NV;
+    const double pxk = g.px0[bN + k];
+    const unsigned int tko_j = (p.tkey[row + k] >> 8) + 1u;           // (read before this column's own entry is rewritten below)
+    const int sh = 8 * j;
+    const double* const xt = xtab + j * 8;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int u = c * 64 + lane;
+      if (u < N) {
+        const unsigned int w = p.tkey[row + u];
+        const bool own = u == k;
+        const unsigned int a0 = w & 255u;
+        const unsigned int so = (w >> 8) + (own ? 1u : 0u);
+        const unsigned int ws = (so << 8) | (own ? 0u : (a0 + (a0 < 255u ? 1u : 0u)));
+        const unsigned int byte = (code[c] >> sh) & 0xffu;
+        const unsigned int lagn = 8u - (unsigned int)__popc(byte);           // (byte != 0 wherever it is used)
+        const unsigned int seqf = byte ? tko_j - lagn : 0u;
+        const bool upd = seqf != so;
+        if (upd) p.tkey[row + u] = seqf << 8;
+        else if (ws != w) p.tkey[row + u] = ws;
+        if (own) p.tx[row + u] = pxk;                                       // vehicle.py:63
+        else if (upd) p.tx[row + u] = lagn == 0u ? pxk : xt[lagn];
+      }
+    }
   }
 }
 
@@ -652,7 +793,7 @@ __global__ __launch_bounds__(64 * kLargeHistWaves) void large_hist_kernel(const 
   double* s_edges = reinterpret_cast<double*>(smem);
   unsigned int* s_n = reinterpret_cast<unsigned int*>(smem + 8u * (K + 2));       // [waves][64]
   unsigned int* s_hist = s_n + 64 * kLargeHistWaves;                              // [waves][VW][KP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + VW - 1) / VW;
   const int b = blockIdx.x / nblk, vb0 = (blockIdx.x - b * nblk) * VW;
   const int u = vb0 + lane;
