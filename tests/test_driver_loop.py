@@ -200,3 +200,24 @@ def test_io_ring_keeps_the_previous_slot_intact_without_copies(fused):
         prev = (o1, o2)
     with pytest.raises(ValueError):
         VecV2VEnv(cfg, batch=1, io_ring=0)
+
+
+def test_driver_loop_prefill_as_a_whole_equals_its_steps_cpu():
+    """DriverLoop.prefill (main_test.py:99-114 as one call: K random slots, every state and action kept) on an env
+    without the one-launch form - the oracle-backed stand-in - is the loop of `prefill_step` calls on the draws
+    `sample(seed + k)` makes; on the HIP env it is one launch, compared with this loop in tests/test_gpu_prefill.py."""
+    from diral_amd.config import c2_config
+    cfg = c2_config(State=dict(add_reward=True, add_channel_obs=True))
+    for ch in (False, True):
+        envs = [OracleBackend(cfg, batch=2), OracleBackend(cfg, batch=2)]
+        loops = [DriverLoop(e, enable_channel=ch) for e in envs]
+        for e, lp in zip(envs, loops):
+            e.reset_topology(seed=3)
+            lp.bootstrap(e.sample(11))
+        states, acts = loops[0].prefill(6, 500)
+        assert tuple(states.shape) == (6, 2, cfg.num_users, cfg.state_space) and tuple(acts.shape) == (6, 2, cfg.num_users)
+        for k in range(6):
+            a = envs[1].sample(500 + k)
+            assert np.array_equal(acts[k].numpy(), a)
+            assert np.array_equal(states[k].numpy(), loops[1].prefill_step(a).numpy()), (ch, k)
+        assert np.array_equal(envs[0].export_state()["seq"], envs[1].export_state()["seq"])
