@@ -724,31 +724,46 @@ __global__ __launch_bounds__(256, (CH <= 8 ? 6 : 4)) void large_mergec_kernel(co
   wave_lds_order();
   const int na = (int)g.nact[b];
   const unsigned short* const alist = g.alist + bA;
-  int m[CH], mn[CH];
-  auto load_src = [&](int qa, int (&dst)[CH]) {
-    const unsigned short* src = g.src + (bA + alist[qa]) * N;
+  // The gather sources of D resources at a time, the next D already in flight: one resource ahead (what large_mergen_kernel
+  // does) left the wave waiting for the row - in a timing probe with every resource reading ONE cached row the kernel ran in
+  // 1.08 ms instead of 1.87 (C3's shape): the rows come from L2 / the Infinity Cache, 1-2 us away.
+  constexpr int D = 4;                                               // (C3 shape: 1.87 / 1.61 / 1.75 ms for 1 / 4 / 8 resources ahead; 512 vehicles: 3.27 / 3.00 / 2.85 for 1 / 2 / 4)
+  int cur[D][CH], nxt[D][CH];
+  auto load_group = [&](int q0, int (&dst)[D][CH]) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int u = c * 64 + lane;
-      dst[c] = u < N ? (int)src[u] : u;
+    for (int d = 0; d < D; ++d) {
+      const int qa = q0 + d < na ? q0 + d : na - 1;                   // (behind the last resource: its row again, not used)
+      const unsigned short* src = g.src + (bA + alist[qa]) * N;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int u = c * 64 + lane;
+        dst[d][c] = u < N ? (int)src[u] : u;
+      }
     }
   };
-  if (na > 0) load_src(0, m);
-  for (int qa = 0; qa < na; ++qa) {
-    if (qa + 1 < na) load_src(qa + 1, mn);
-    unsigned int v[CH];
+  if (na > 0) load_group(0, cur);
+  for (int q0 = 0; q0 < na; q0 += D) {
+    if (q0 + D < na) load_group(q0 + D, nxt);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = kl[m[c]];
-    // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
-    wave_lds_order();
+    for (int d = 0; d < D; ++d) {
+      if (q0 + d < na) {                                              // (uniform)
+        unsigned int v[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      code[c] |= v[c];
-      kl[c * 64 + lane] = code[c];
+        for (int c = 0; c < CH; ++c) v[c] = kl[cur[d][c]];
+        // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          code[c] |= v[c];
+          kl[c * 64 + lane] = code[c];
+        }
+        wave_lds_order();
+      }
     }
-    wave_lds_order();
 #pragma unroll
-    for (int c = 0; c < CH; ++c) m[c] = mn[c];
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) cur[d][c] = nxt[d][c];
   }
   // back to numbers and ages; a changed entry takes the xpos of its new number.  (One column at a time, the loop rolled:
   // unrolled four times the 1024-vehicle form spilled 47 VGPRs and 354 SGPRs.)
