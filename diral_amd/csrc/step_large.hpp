@@ -528,6 +528,10 @@ __global__ __launch_bounds__(256) void large_merge_kernel(const StepParams p, co
 // one 16-bit load (shared by the NC columns), one ds_read_b64 / b128, NC v_max_u32, one ds_write_b64 / b128; the next
 // resource's sources are in flight meanwhile.  grid = B * ceil(ceil(N / NC) / 4), 256 threads.
 constexpr unsigned int kLargeRankMax = (1u << 20) - 1u;
+#ifndef DIRAL_LARGE_RANK_AHEAD
+#define DIRAL_LARGE_RANK_AHEAD 2          // large_mergen_kernel<16, 2>: resources whose gather sources are fetched ahead - 1024 / 64 / B = 256:
+                                          // 4.96 / 4.40 / 7.23 ms for 1 / 2 / 4 (interleaved variant libraries; 4 spills)
+#endif
 template <int NC> struct LargeKeyVec;
 template <> struct LargeKeyVec<2> { typedef uint2 type; };
 template <> struct LargeKeyVec<4> { typedef uint4 type; };
@@ -585,32 +589,45 @@ __global__ __launch_bounds__(256, (CH * NC <= 16 ? 6 : 3)) void large_mergen_ker
   wave_lds_order();
   const int na = (int)g.nact[b];
   const unsigned short* const alist = g.alist + bA;
-  int m[CH], mn[CH];
-  auto load_src = [&](int qa, int (&dst)[CH]) {
-    const unsigned short* src = g.src + (bA + alist[qa]) * N;
+  // the gather sources of D resources at a time, the next D in flight (large_mergec_kernel: the rows are 1-2 us away)
+  constexpr int D = CH >= 16 ? DIRAL_LARGE_RANK_AHEAD : 1;          // (the gated forms sit at their 80-VGPR cap)
+  int cur[D][CH], nxt[D][CH];
+  auto load_group = [&](int q0, int (&dst)[D][CH]) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int u = c * 64 + lane;
-      dst[c] = u < N ? (int)src[u] : u;
+    for (int d = 0; d < D; ++d) {
+      const int qa = q0 + d < na ? q0 + d : na - 1;
+      const unsigned short* src = g.src + (bA + alist[qa]) * N;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int u = c * 64 + lane;
+        dst[d][c] = u < N ? (int)src[u] : u;
+      }
     }
   };
-  if (na > 0) load_src(0, m);
-  for (int qa = 0; qa < na; ++qa) {
-    if (qa + 1 < na) load_src(qa + 1, mn);
-    kv_t v[CH];
+  if (na > 0) load_group(0, cur);
+  for (int q0 = 0; q0 < na; q0 += D) {
+    if (q0 + D < na) load_group(q0 + D, nxt);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = kl[m[c]];
-    // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
-    wave_lds_order();
+    for (int d = 0; d < D; ++d) {
+      if (q0 + d < na) {                                              // (uniform)
+        kv_t v[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
+        for (int c = 0; c < CH; ++c) v[c] = kl[cur[d][c]];
+        // (the transmitters of a resource do not merge on it, test_env.py:204-209: every gather of the step may precede its writes)
+        wave_lds_order();
 #pragma unroll
-      for (int j = 0; j < NC; ++j) key[c][j] = max(key[c][j], large_kv(v[c], j));
-      kl[c * 64 + lane] = large_mk(key[c]);
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) key[c][j] = max(key[c][j], large_kv(v[c], j));
+          kl[c * 64 + lane] = large_mk(key[c]);
+        }
+        wave_lds_order();
+      }
     }
-    wave_lds_order();
 #pragma unroll
-    for (int c = 0; c < CH; ++c) m[c] = mn[c];
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) cur[d][c] = nxt[d][c];
   }
   // back to numbers; xpos from the source viewer's entry as the slot found it (every gather before the first store)
   bool stale = false;
