@@ -678,8 +678,8 @@ int diral_env_validate(const DiralCfg* c) {
   if (is_large_cfg(c)) {
     // step_large.hpp: the env's vehicles and resource lists in one workgroup's LDS, a table column in a wave's
     if (large_lds_bytes(c->num_users, c->num_channels, kbins) > 160u * 1024u) return DIRAL_ERR_UNSUPPORTED;
-    // piggyback_kernel.hpp stages one env in static LDS
-    if (c->num_users > DIRAL_SMALL_MAX_USERS && has(c, DIRAL_F_PIGGYBACKING)) return DIRAL_ERR_UNSUPPORTED;
+    // State.piggybacking: A * A values per agent, indexed with 32 bits in piggyback_kernel.hpp
+    if (has(c, DIRAL_F_PIGGYBACKING) && c->num_channels > DIRAL_SMALL_MAX_CHANNELS) return DIRAL_ERR_UNSUPPORTED;
     // the type-1 histogram at these sizes is posdist_kernel's literal statement: one env's values in LDS (N <~ 1400)
     if (has(c, DIRAL_F_ADD_POSDIST_PIGGY) && c->posdist_type == 1 && posdist_lds_bytes(c->num_users, kbins) > 160u * 1024u)
       return DIRAL_ERR_UNSUPPORTED;
@@ -777,6 +777,9 @@ int diral_env_create(const DiralCfg* cfg, int batch, int device, DiralEnv** out)
   if (has(cfg, DIRAL_F_TRACK_ARRIVAL)) CREATE_TRY(alloc((void**)&e->la, bn * e->N * 4));
   if (has(cfg, DIRAL_F_PROPORTIONAL_FAIR)) CREATE_TRY(alloc((void**)&e->pf, bn * 4));
   if (has(cfg, DIRAL_F_PIGGYBACKING)) {
+    if (piggy_search_lds_bytes(e->N) > 48u * 1024u)
+      CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(piggy_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)piggy_search_lds_bytes(e->N)));
     CREATE_TRY(alloc((void**)&e->prev_obs, bn * e->A * 8));
     CREATE_TRY(alloc((void**)&e->obs_new, bn * e->A * 8));
     CREATE_TRY(alloc((void**)&e->txid, bn * e->A * 4));
@@ -963,7 +966,7 @@ int diral_env_step(DiralEnv* e, int mode, const int32_t* actions, int64_t t, voi
     if (mode != DIRAL_STEP_MY_STEP) return DIRAL_ERR_BAD_CONFIG;
     PiggyParams q = piggy_params(e, p);
     p.chobs_out = nullptr;                                       // (the A * A observation is piggy_emit_kernel's)
-    hipLaunchKernelGGL(piggy_search_kernel, dim3(e->B), dim3(256), 0, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(piggy_search_kernel, dim3(e->B), dim3(256), piggy_search_lds_bytes(e->N), (hipStream_t)stream, q);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, launch_step_any(e, p, (hipStream_t)stream));
     HIP_TRY(e, launch_posdist_if_needed(e, p, (hipStream_t)stream));

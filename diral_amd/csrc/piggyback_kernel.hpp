@@ -55,13 +55,17 @@ __device__ inline void piggy_store(void* base, size_t idx, double v, int f64) {
   else static_cast<float*>(base)[idx] = (float)v;
 }
 
+__host__ __device__ inline uint32_t piggy_search_lds_bytes(int N) { return 20u * (uint32_t)N + 16u; }
 // one workgroup per env, one thread per (receiver, resource) pair
 __global__ void piggy_search_kernel(PiggyParams p) {
   const int b = blockIdx.x, N = p.N, A = p.A;
   const size_t bN = (size_t)b * N;
-  // the env's actions and positions once into LDS (N <= DIRAL_SMALL_MAX_USERS: State.piggybacking stays on the one-workgroup sizes): every (receiver, resource) pair walks all of them
-  __shared__ int32_t act[DIRAL_SMALL_MAX_USERS];
-  __shared__ double px[DIRAL_SMALL_MAX_USERS], py[DIRAL_SMALL_MAX_USERS];
+  // the env's actions and positions once into LDS (piggy_search_lds_bytes(N): 20 bytes per vehicle): every (receiver,
+  // resource) pair walks all of them
+  extern __shared__ __align__(16) unsigned char pg_smem[];
+  double* const px = reinterpret_cast<double*>(pg_smem);
+  double* const py = px + N;
+  int32_t* const act = reinterpret_cast<int32_t*>(py + N);
   for (int u = threadIdx.x; u < N; u += blockDim.x) {
     act[u] = p.actions[bN + u];
     px[u] = p.pos_x[bN + u];

@@ -135,8 +135,8 @@ typedef enum DiralDType { DIRAL_F32 = 0, DIRAL_F64 = 1 } DiralDType;
  * num_bins 64 the step runs as three launches with the tables' columns spread over the chip (csrc/step_large.hpp,
  * DIRAL_KERNEL_LARGE: same results, bit for bit) up to the sizes below - as long as the per-env working set fits a
  * workgroup's 160 KB of LDS (28 bytes per vehicle + 8 per resource: 4096 vehicles with 4096 resources do), else
- * DIRAL_ERR_UNSUPPORTED.  diral_env_last_kernel() says which kernel ran.  Not served beyond 256 vehicles: State.piggybacking,
- * and the type-1 histogram beyond ~1400 (DIRAL_ERR_UNSUPPORTED at create). */
+ * DIRAL_ERR_UNSUPPORTED.  diral_env_last_kernel() says which kernel ran.  Not served: State.piggybacking beyond 256
+ * resources (A * A values per agent), the type-1 histogram beyond ~1400 vehicles (DIRAL_ERR_UNSUPPORTED at create). */
 #define DIRAL_MAX_USERS    4096
 #define DIRAL_MAX_CHANNELS 4096
 #define DIRAL_MAX_BINS     1024

@@ -89,7 +89,9 @@ def test_host_validation_and_state_space():
         assert lib.diral_env_validate(ctypes.byref(big)) == want, (n, a, k)
     pb = c2_config(State=dict(piggybacking=True, add_channel_obs=True)).to_c()
     assert lib.diral_env_validate(ctypes.byref(pb)) == 0
-    pb.num_users = 300                                        # State.piggybacking stays on the one-workgroup sizes
+    pb.num_users = 300                                        # State.piggybacking: any number of vehicles, up to 256 resources
+    assert lib.diral_env_validate(ctypes.byref(pb)) == 0
+    pb.num_channels = 257
     assert lib.diral_env_validate(ctypes.byref(pb)) == -3
     short = c2_config().to_c(); short.struct_bytes = 4
     assert lib.diral_env_validate(ctypes.byref(short)) == -1
