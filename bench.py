@@ -640,7 +640,8 @@ def c2_graph(device, envs=4096, K=24, replays=42):
     side.wait_stream(torch.cuda.current_stream(device))
     assert K % 3 == 0                           # the captured launches rotate the slow-env sets: VecV2VEnv.set_capture_rotation
     env.set_capture_rotation(True)
-    with torch.cuda.stream(side):
+    from diral_amd.rollout import no_finalizers_during_capture
+    with no_finalizers_during_capture(), torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             k_slots()
     env.set_capture_rotation(False)

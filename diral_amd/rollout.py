@@ -21,7 +21,9 @@ mobility_vary, the epsilon schedule behind the fingerprint columns) are not part
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import gc
 from typing import Optional
 
 import torch
@@ -29,6 +31,21 @@ import torch
 from .config import STEP_MY_STEP, STEP_MY_STEP_CH
 from .sps import SpsPolicy
 from .vec_env import DiralError, VecV2VEnv
+
+
+@contextlib.contextmanager
+def no_finalizers_during_capture():
+    """No finalizer may run inside a stream capture: a dead handle's `diral_env_destroy` (or a dead tensor's block going
+    back to the driver) is a hipFree, which a capture in the default (global) mode turns into a fatal error of the whole
+    process.  Collects what is dead NOW and holds the cyclic collector until the capture has ended."""
+    was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 class SlotClock:
@@ -95,7 +112,7 @@ class GraphRollout:
                 # run() keeps the phase aligned)
                 self._phase = env.set_capture_rotation(True) if self.K % 3 == 0 else None
                 try:
-                    with torch.cuda.stream(self._stream):
+                    with no_finalizers_during_capture(), torch.cuda.stream(self._stream):
                         with torch.cuda.graph(self.graph, stream=self._stream):
                             self._run_slots(eager=False)
                 finally:

@@ -28,6 +28,16 @@ _MODES = {"my_step": STEP_MY_STEP, "my_step_ch": STEP_MY_STEP_CH, "my_step_desig
           STEP_MY_STEP: STEP_MY_STEP, STEP_MY_STEP_CH: STEP_MY_STEP_CH, STEP_DESIGN: STEP_DESIGN}
 
 
+_PARKED: list = []          # (lib, handle) pairs whose owners died inside a stream capture (VecV2VEnv.close)
+
+
+def _capturing() -> bool:
+    try:
+        return bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return False
+
+
 class DiralError(RuntimeError):
     def __init__(self, status: int, where: str, detail: str = ""):
         self.status = status
@@ -156,8 +166,17 @@ class VecV2VEnv:
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._clock = None
-            self.lib.diral_env_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            # `diral_env_destroy` is a series of hipFree calls: inside a stream capture (the cyclic collector may run this
+            # finalizer at any allocation - also between two captured launches of ANOTHER handle) that is a fatal error of
+            # the process.  A handle that dies during a capture is parked and destroyed with the next one that does not.
+            if _capturing():
+                _PARKED.append((self.lib, h))
+                return
+            self.lib.diral_env_destroy(h)
+            while _PARKED:
+                lib, ph = _PARKED.pop()
+                lib.diral_env_destroy(ph)
 
     def __del__(self):
         try:

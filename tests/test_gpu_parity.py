@@ -2262,3 +2262,35 @@ def test_flagged_passes_whose_far_entries_stay_put_run_coded_and_propagation_fal
     run(90, 120)                                                   # one cluster again: everything comes back within the codes
     oe = tables_equal("merged")
     env.check()
+
+
+def test_a_handle_that_dies_inside_a_stream_capture_is_destroyed_later():
+    """`diral_env_destroy` frees device memory; a finalizer that the cyclic collector runs between two captured launches
+    of ANOTHER handle would take the process down (hipFree inside a capture).  VecV2VEnv.close parks such a handle and
+    destroys it with the next close outside a capture."""
+    import gc
+    from diral_amd import vec_env
+    cfg = c2_config()
+    victim = make_env(cfg, 4, dtype=torch.float32)
+    live = make_env(cfg, 4, dtype=torch.float32)
+    for e in (victim, live):
+        e.reset_topology(seed=2)
+    acts = live.sample(seed=1)
+    live.step(acts, 0)
+    torch.cuda.synchronize()
+    parked_before = len(vec_env._PARKED)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            live.step(acts, 1)
+            del victim                                              # dies here: inside the capture
+            gc.collect()
+            live.step(acts, 2)
+    assert len(vec_env._PARKED) == parked_before + 1
+    g.replay()
+    torch.cuda.synchronize()
+    live.check()
+    live.close()                                                    # outside a capture: the parked handle goes with it
+    assert len(vec_env._PARKED) == 0
